@@ -1,0 +1,195 @@
+/*
+ * lfvdm_hip.h — C ABI of the MI355X (gfx950) native layer under the `improved_diffusion`
+ * hot path (frame-conditioned video U-Net forward/backward + Gaussian-diffusion step math).
+ *
+ * The reference (plai-group/latent-flexible-video-diffusion-modeling) has NO native layer:
+ * its boundary is the Python module surface.  Every entry point below
+ * therefore replaces a stock ATen op sequence at the cited reference site and is what a
+ * ctypes / cffi stub in the reference's Python would bind.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 unless the name says otherwise
+ *     (`i64` = int64_t, `i32` = int32_t); nothing is allocated or freed here;
+ *   - every launcher is stream-ordered on `stream` (a hipStream_t passed as void*), is
+ *     re-entrant, keeps no global state and is hipGraph-capturable (no sync, no malloc);
+ *   - return value: 0 = launched, non-zero = LFVDM_E_* (invalid shape / unsupported config /
+ *     launch error); the Python shim turns non-zero into RuntimeError;
+ *   - activations are channels-last: [N][H][W][C] with N = B*T, n = b*T + t
+ *     (the reference's (B*T, C, H, W) is converted once at the model input and once at the
+ *     output: lfvdm_conv_in / LFVDM_OUT_NCHW).
+ */
+#ifndef LFVDM_HIP_H
+#define LFVDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFVDM_OK 0
+#define LFVDM_E_SHAPE 1   /* operand shapes violate the kernel's assumptions */
+#define LFVDM_E_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
+#define LFVDM_E_UNSUPPORTED 3
+
+#define LFVDM_ACT_NONE 0
+#define LFVDM_ACT_SILU 1
+
+#define LFVDM_OUT_ROWS 0 /* out[m*ldo + co]                        (channels-last rows) */
+#define LFVDM_OUT_NCHW 1 /* out[(n*Cout + co)*Ho*Wo + pix]          (reference frame layout) */
+
+int lfvdm_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces nn.Conv2d 3x3 (unet.py:76,108,155,169,313,402), the 1x1 skip conv (unet.py:180),
+ * nn.Linear qkv / proj_out (rpe.py:111-112,139,171) and — fused into the operand load — the
+ * preceding GroupNorm32 + SiLU (+FiLM) (nn.py:12-19, unet.py:152-171,199-203), the nearest-2x
+ * Upsample (unet.py:85-87), the skip concat (unet.py:460) and the residual add (unet.py:207,
+ * rpe.py:172).
+ *
+ *   out[m][co] = bias[co] + sum_{tap,ci} f(src[n, iy, ix, ci]) * W[co][tap*Cin + ci]
+ *              (+ bias2[co] + sum_ci src2[m][ci] * W2[co][ci])            second segment
+ *              (+ res[m][co] * resA[n][co] + resB[n][co])                 residual
+ *   f(v) = act(v * coefA[n][ci] + coefB[n][ci]), zero outside the (padded) image.
+ * ------------------------------------------------------------------------------------- */
+typedef struct lfvdm_conv_args {
+    /* main segment: virtual concat of src0 (C0 ch) and src1 (C1 ch, may be 0/NULL) */
+    const float* src0;
+    const float* src1;
+    int32_t C0, C1;
+    int32_t N;        /* samples (B*T) */
+    int32_t Hs, Ws;   /* spatial size of the stored source */
+    int32_t up;       /* 1: source is nearest-upsampled x2 on the fly */
+    int32_t stride;   /* 1 or 2 */
+    int32_t ksize;    /* 3 (pad 1) or 1 (pad 0) */
+    int32_t Ho, Wo;   /* output spatial size */
+    const float* coefA; /* [N][C0+C1] or NULL (identity) */
+    const float* coefB;
+    int32_t act;      /* LFVDM_ACT_* applied after the affine */
+    const float* W;   /* packed [Cout][ksize*ksize][C0+C1] (see lfvdm_pack_conv_weight) */
+    const float* bias;/* [Cout] or NULL */
+    int32_t Cout;
+    /* optional second segment: 1x1 on a raw (un-normalised) concat source at output res */
+    const float* s2src0;
+    const float* s2src1;
+    int32_t s2C0, s2C1;
+    const float* W2;  /* [Cout][s2C0+s2C1] */
+    const float* bias2;
+    /* optional residual, rows [M][ldr]; resA/resB [N][Cout] or NULL (plain add) */
+    const float* res;
+    int32_t ldr;
+    const float* resA;
+    const float* resB;
+    /* output */
+    float* out;
+    int32_t ldo;      /* row stride for LFVDM_OUT_ROWS */
+    int32_t out_mode; /* LFVDM_OUT_* */
+} lfvdm_conv_args;
+
+int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream);
+
+/* OIHW [Cout][Cin][k][k] -> [Cout][k*k][Cin] (k in {1,3}); state-dict layout stays OIHW. */
+int lfvdm_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int ksize, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Model prologue: input compositing + indicator channel + 3x3 input conv in one kernel
+ * (unet.py:441-450 and input_blocks.0, unet.py:310-316).
+ *   x, x0: (B,T,C,H,W) frame layout; obs: (B*T) floats; w: OIHW [Cout][C+1][3][3]
+ *   out: channels-last [B*T][H][W][Cout]
+ * ------------------------------------------------------------------------------------- */
+int lfvdm_conv_in(const float* x, const float* x0, const float* obs, const float* w, const float* bias,
+                  float* out, int N, int C, int H, int W, int Cout, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * GroupNorm(32) statistics -> per-(sample, channel) affine coefficients, optionally folded
+ * with the FiLM scale/shift of the ResBlock (nn.py:17-19,95-102; unet.py:199-203):
+ *   y = x*A + B,  A = rstd*gamma*(1+scale), B = (beta - mean*rstd*gamma)*(1+scale) + shift
+ * src is a virtual concat [N][P][C0+C1]; film: [Bf][2*C] rows (scale | shift) indexed by
+ * n / film_div (the embedding is per batch element, n = b*T + t), or NULL.
+ * ------------------------------------------------------------------------------------- */
+int lfvdm_gn_coef(const float* src0, const float* src1, int C0, int C1, int N, int P,
+                  const float* gamma, const float* beta, const float* film, int film_div, int film_ld,
+                  float eps, float* coefA, float* coefB, void* stream);
+
+/* Temporal GroupNorm of rpe.py:135-137: statistics over (C/32 channels x T frames) for each
+ * (b, pixel); writes the normalised tensor (it is also the residual of rpe.py:172).
+ * x, y: [B*T][P][C]. */
+int lfvdm_gn_temporal(const float* x, const float* gamma, const float* beta, float eps, float* y,
+                      int B, int T, int P, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Small-M grouped linear ("row-dot"): out[m][o] = sum_k actin(in[m][k]) * W[o][k] + b[o],
+ * m < M <= 8.  One launch evaluates a whole table of jobs (time_embed.{0,2}, every
+ * ResBlock.emb_layers.1, every RPENet.embed_diffusion_time: nn.py:105-123, unet.py:303-308,
+ * 157-163,196; rpe.py:29).  Job tables live in device memory (see lfvdm_rowdot_job).
+ * in_mode: 0 = plain, 1 = SiLU(in), 2 = in is a scalar timestep per row and the operand is its
+ * sinusoidal embedding [cos | sin] of width K (nn.py:105-123).
+ * ------------------------------------------------------------------------------------- */
+typedef struct lfvdm_rowdot_job {
+    const float* W;   /* [O][K] */
+    const float* b;   /* [O] */
+    const float* in;  /* [M][ldin] (or [M] timesteps for in_mode 2) */
+    float* out;       /* [M][ldout] */
+    int32_t K, O, M, ldin, ldout, in_mode;
+    int32_t row0;     /* first global output-row index of this job (prefix sum of O) */
+    int32_t pad_;
+} lfvdm_rowdot_job;
+
+int lfvdm_rowdot(const lfvdm_rowdot_job* jobs_dev, int njobs, int total_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * All RPENet output projections of one forward in one launch (rpe.py:20-31):
+ *   R[b,t,s,:] = Wout * SiLU(tproj[b,:] + Wd * feats(fi[b,t]-fi[b,s]) + bd) + bout
+ * tproj already holds embed_diffusion_time(emb)+its bias (from lfvdm_rowdot).
+ * ------------------------------------------------------------------------------------- */
+typedef struct lfvdm_rpe_job {
+    const float* tproj; /* [B][C] */
+    const float* Wd;    /* [C][3] */
+    const float* bd;    /* [C] */
+    const float* Wout;  /* [C][C] */
+    const float* bout;  /* [C] */
+    float* R;           /* [B][T][T][C] */
+    int32_t C;
+    int32_t tile0;      /* first workgroup index of this job */
+} lfvdm_rpe_job;
+
+int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, const int64_t* frame_indices_i64,
+                   int B, int T, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Attention cores (rpe.py:143-169).  qkv rows are token-major [M][3C] with the reference's
+ * channel order [3][heads][F]; o rows are [M][C].
+ *   spatial : tokens of one frame n attend to each other (no mask, no RPE)
+ *   temporal: the T frames of one (b, pixel) attend with RPE biases and the two-clique mask
+ * attn_out (optional, may be NULL): softmax probabilities for logging
+ *   spatial [N][heads][P][P], temporal [B*P][heads][T][T].
+ * ------------------------------------------------------------------------------------- */
+int lfvdm_attn_spatial(const float* qkv, float* o, float* attn_out, int N, int P, int C, int heads, void* stream);
+
+int lfvdm_attn_temporal(const float* qkv, const float* Rq, const float* Rk, const float* Rv,
+                        const float* mask /* [B][T] or NULL */, float* o, float* attn_out,
+                        int B, int T, int P, int C, int heads, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Diffusion step math (gaussian_diffusion.py).  Tables are device fp32 arrays gathered by
+ * the int64 timestep t[b]; tensors are (B, inner) contiguous.
+ * ------------------------------------------------------------------------------------- */
+/* q_sample, :200-218 */
+int lfvdm_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp,
+                   const float* sqrt_1macp, float* out, int B, int inner, void* stream);
+/* p_mean_variance (eps, fixed variance) + p_sample update, :290-346,369-401.
+ * pred_xstart / mean_out may be NULL. */
+int lfvdm_p_sample(const float* x, const float* eps, const float* noise, const int64_t* t,
+                   const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* coef1,
+                   const float* coef2, const float* log_var, int clip, float* sample, float* pred_xstart,
+                   float* mean_out, int B, int inner, void* stream);
+/* masked mean of squared error, :787-788 + nn.py:86-92: out[b] = mean_inner((a-b)^2 * mask[b,frame]).
+ * mask is (B, T) (broadcast over the per-frame block of `frame_inner` elements) or NULL. */
+int lfvdm_masked_mse(const float* a, const float* b, const float* mask, float* out, int B, int T,
+                     int frame_inner, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFVDM_HIP_H */

@@ -1,0 +1,56 @@
+"""Build the gfx950 shared library (C ABI in include/lfvdm_hip.h) with hipcc.
+
+    python latent-flexible-video-diffusion-modeling_amd/build.py [--force]
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting ``lib/liblfvdm_hip.so`` is
+git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "liblfvdm_hip.so")
+ARCH = "gfx950"
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(LIBDIR, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                   "-I", CSRC, "-c", s, "-o", o]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    if force or procs or _newer(LIB, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,42 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, fp32 MFMA, LDS tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lfvdm_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LFVDM_CHECK_LAUNCH()                                   \
+    do {                                                       \
+        if (hipGetLastError() != hipSuccess) return LFVDM_E_LAUNCH; \
+    } while (0)
+
+__device__ __forceinline__ float silu_f(float v) {
+    // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each <= 1 ulp)
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// Orders this wave's LDS stores before its later LDS loads for the COMPILER only: LDS operations
+// of one wave are executed in issue order by the hardware, so a tile staged and consumed by the
+// same wave needs no s_barrier (wave-private staging, see conv_igemm.hip).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

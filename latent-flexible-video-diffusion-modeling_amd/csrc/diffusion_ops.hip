@@ -1,0 +1,103 @@
+// Elementwise Gaussian-diffusion step math (gaussian_diffusion.py:200-218, 290-346, 369-401,
+// 787-788).  HBM-bound streaming kernels: float4 accesses, one table gather per batch row.
+#include "common.cuh"
+
+namespace {
+
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                       const int64_t* __restrict__ t, const float* __restrict__ sa,
+                                                       const float* __restrict__ sb, float* __restrict__ out, int inner) {
+    const int b = blockIdx.y;
+    const float ca = sa[t[b]], cb = sb[t[b]];
+    const size_t base = (size_t)b * inner;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < inner; i += gridDim.x * blockDim.x * 4) {
+        if (i + 3 < inner) {
+            st4(out + base + i, ca * ld4(x0 + base + i) + cb * ld4(noise + base + i));
+        } else {
+            for (int j = i; j < inner; ++j) out[base + j] = ca * x0[base + j] + cb * noise[base + j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void p_sample_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                       const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                                       const float* __restrict__ t_recip, const float* __restrict__ t_recipm1,
+                                                       const float* __restrict__ t_c1, const float* __restrict__ t_c2,
+                                                       const float* __restrict__ t_logvar, int clip,
+                                                       float* __restrict__ sample, float* __restrict__ pred,
+                                                       float* __restrict__ mean_out, int inner) {
+    const int b = blockIdx.y;
+    const int64_t tb = t[b];
+    const float r = t_recip[tb], rm1 = t_recipm1[tb], c1 = t_c1[tb], c2 = t_c2[tb];
+    // sample = mean + [t != 0] * exp(0.5 * log_variance) * noise     (:396-400)
+    const float sigma = tb != 0 ? expf(0.5f * t_logvar[tb]) : 0.f;
+    const size_t base = (size_t)b * inner;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < inner; i += gridDim.x * blockDim.x) {
+        const float xv = x[base + i];
+        float p0 = r * xv - rm1 * eps[base + i];   // _predict_xstart_from_eps (:341-346)
+        if (clip) p0 = fminf(fmaxf(p0, -1.f), 1.f);
+        const float mean = c1 * p0 + c2 * xv;       // q_posterior_mean_variance (:228-231)
+        float sv = mean;
+        if (tb != 0) sv += sigma * noise[base + i];
+        sample[base + i] = sv;
+        if (pred) pred[base + i] = p0;
+        if (mean_out) mean_out[base + i] = mean;
+    }
+}
+
+// out[b] = (1/inner_total) * sum_{t, i} (a - b)^2 * mask[b, t]; one workgroup per batch row
+__global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ a, const float* __restrict__ bb,
+                                                         const float* __restrict__ mask, float* __restrict__ out, int T,
+                                                         int frame_inner) {
+    const int b = blockIdx.x;
+    const size_t base = (size_t)b * T * frame_inner;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float mk = mask ? mask[b * T + t] : 1.f;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < frame_inner; i += blockDim.x) {
+            const float d = a[base + (size_t)t * frame_inner + i] - bb[base + (size_t)t * frame_inner + i];
+            s += d * d * mk;
+        }
+        acc += s;
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[b] = (red[0] + red[1] + red[2] + red[3]) / (float)((size_t)T * frame_inner);
+}
+
+}  // namespace
+
+extern "C" int lfvdm_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp,
+                              const float* sqrt_1macp, float* out, int B, int inner, void* stream) {
+    if (B <= 0 || inner <= 0) return LFVDM_E_SHAPE;
+    int gx = (inner / 4 + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x0, noise, t, sqrt_acp, sqrt_1macp, out, inner);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_p_sample(const float* x, const float* eps, const float* noise, const int64_t* t,
+                              const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* coef1,
+                              const float* coef2, const float* log_var, int clip, float* sample, float* pred_xstart,
+                              float* mean_out, int B, int inner, void* stream) {
+    if (B <= 0 || inner <= 0) return LFVDM_E_SHAPE;
+    int gx = (inner + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(p_sample_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, eps, noise, t, sqrt_recip_acp,
+                       sqrt_recipm1_acp, coef1, coef2, log_var, clip, sample, pred_xstart, mean_out, inner);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_masked_mse(const float* a, const float* b, const float* mask, float* out, int B, int T,
+                                int frame_inner, void* stream) {
+    if (B <= 0 || T <= 0 || frame_inner <= 0) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(masked_mse_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, b, mask, out, T, frame_inner);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}

@@ -1,0 +1,297 @@
+// GroupNorm statistics, the fused input compositing + first conv, and the small-M grouped
+// linear ("row-dot") used for every embedding projection.  All HBM/L2-bound; wave = 64.
+#include "common.cuh"
+
+namespace {
+
+// -------------------------------------------------------------------------------------
+// gn_coef: one workgroup per (sample n, slice of 8 groups).  Two exact passes (mean, then
+// centred variance) like ATen's CPU GroupNorm; the slice is re-read from L2 for pass 2.
+// Thread (pl, q): pixel lane pl strides over the P positions, q = float4 channel quad.
+// -------------------------------------------------------------------------------------
+constexpr int GN_GPW = 8;        // groups per workgroup
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAXCW = 256;    // channels per workgroup: supports C <= 1024
+
+__device__ __forceinline__ f32x4 ld_cat(const float* s0, const float* s1, int C0, int C1, size_t pos, int c) {
+    return c < C0 ? ld4(s0 + pos * C0 + c) : ld4(s1 + pos * C1 + (c - C0));
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
+    const float* __restrict__ s0, const float* __restrict__ s1, int C0, int C1, int P,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
+    int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB) {
+    const int C = C0 + C1;
+    const int cg = C / 32;
+    const int CW = GN_GPW * cg;       // channels handled here
+    const int Q = CW / 4;             // float4 quads
+    const int n = blockIdx.x;
+    const int cbase = blockIdx.y * CW;
+    const int PL = GN_THREADS / Q;    // pixel lanes
+    const int tid = threadIdx.x;
+    const bool active = tid < PL * Q;
+    const int q = active ? tid % Q : 0;
+    const int pl = active ? tid / Q : 0;
+    const int c = cbase + q * 4;
+
+    __shared__ float part[GN_THREADS * 4];  // [pl][CW] partial channel sums
+    __shared__ float chs[GN_MAXCW];
+    __shared__ float gmean[GN_GPW], grstd[GN_GPW];
+
+    const size_t pos0 = (size_t)n * P;
+    for (int pass = 0; pass < 2; ++pass) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            f32x4 mu = {0.f, 0.f, 0.f, 0.f};
+            if (pass) {
+                mu.x = gmean[(q * 4 + 0) / cg]; mu.y = gmean[(q * 4 + 1) / cg];
+                mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg];
+            }
+            for (int p = pl; p < P; p += PL) {
+                f32x4 v = ld_cat(s0, s1, C0, C1, pos0 + p, c);
+                if (pass) { v = v - mu; s += v * v; } else { s += v; }
+            }
+            st4(part + (pl * Q + q) * 4, s);
+        }
+        __syncthreads();
+        for (int cc = tid; cc < CW; cc += GN_THREADS) {
+            float t = 0.f;
+            for (int i = 0; i < PL; ++i) t += part[i * CW + cc];
+            chs[cc] = t;
+        }
+        __syncthreads();
+        if (tid < GN_GPW) {
+            float t = 0.f;
+            for (int i = 0; i < cg; ++i) t += chs[tid * cg + i];
+            const float inv = 1.0f / (float)(cg * P);
+            if (pass == 0) gmean[tid] = t * inv;
+            else grstd[tid] = 1.0f / sqrtf(t * inv + eps);
+        }
+        __syncthreads();
+    }
+    for (int cc = tid; cc < CW; cc += GN_THREADS) {
+        const int ch = cbase + cc;
+        const int g = cc / cg;
+        float A = grstd[g] * gamma[ch];
+        float B = beta[ch] - gmean[g] * A;
+        if (film) {
+            const float* f = film + (size_t)(n / film_div) * film_ld;
+            const float sc = 1.0f + f[ch];
+            A *= sc;
+            B = B * sc + f[C + ch];
+        }
+        coefA[(size_t)n * C + ch] = A;
+        coefB[(size_t)n * C + ch] = B;
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// gn_temporal: one wave per (b, pixel); the sample is [T][C] with row stride P*C.
+// Writes the normalised rows (they are also the residual of the attention block).
+// -------------------------------------------------------------------------------------
+constexpr int GT_MAXC = 512;
+
+__global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ y, int B, int T, int P, int C) {
+    __shared__ float chs_all[4][GT_MAXC];
+    __shared__ float gstat_all[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long sample = (long)blockIdx.x * 4 + wave;
+    if (sample >= (long)B * P) return;  // whole wave exits together
+    float* chs = chs_all[wave];
+    float* gstat = gstat_all[wave];
+    const int b = (int)(sample / P), p = (int)(sample % P);
+    const int cg = C / 32;
+    const int Q = C / 4;
+    const size_t base = ((size_t)b * T * P + p) * C;
+    const size_t tstride = (size_t)P * C;
+    const int E = T * Q;
+
+    // lane layout: QL lanes along the channel quads, TL lanes along the frames (TL > 1 only when
+    // the quads of one frame fill less than a wave); per-channel sums are combined with shuffles,
+    // so the result is deterministic (no LDS atomics).
+    const int TL = (Q <= 64 && 64 % Q == 0) ? 64 / Q : 1;
+    const int QL = 64 / TL;
+    const int ql = lane % QL, tl = lane / QL;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int q = ql; q < Q; q += QL) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            f32x4 mu = {0.f, 0.f, 0.f, 0.f};
+            if (pass) {
+                mu.x = gstat[(q * 4 + 0) / cg]; mu.y = gstat[(q * 4 + 1) / cg];
+                mu.z = gstat[(q * 4 + 2) / cg]; mu.w = gstat[(q * 4 + 3) / cg];
+            }
+            for (int t = tl; t < T; t += TL) {
+                f32x4 v = ld4(x + base + t * tstride + q * 4);
+                if (pass) { v = v - mu; s += v * v; } else { s += v; }
+            }
+            for (int o = QL; o < 64; o <<= 1) {
+                s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+                s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+            }
+            if (tl == 0) st4(chs + q * 4, s);
+        }
+        wave_lds_fence();
+        if (lane < 32) {
+            float t = 0.f;
+            for (int i = 0; i < cg; ++i) t += chs[lane * cg + i];
+            const float inv = 1.0f / (float)(cg * T);
+            if (pass == 0) gstat[lane] = t * inv;
+            else gstat[32 + lane] = 1.0f / sqrtf(t * inv + eps);
+        }
+        wave_lds_fence();
+    }
+    for (int e = lane; e < E; e += 64) {
+        const int t = e / Q, q = e - t * Q;
+        f32x4 v = ld4(x + base + t * tstride + q * 4);
+        const f32x4 ga = ld4(gamma + q * 4), be = ld4(beta + q * 4);
+        f32x4 o;
+        o.x = (v.x - gstat[(q * 4 + 0) / cg]) * gstat[32 + (q * 4 + 0) / cg] * ga.x + be.x;
+        o.y = (v.y - gstat[(q * 4 + 1) / cg]) * gstat[32 + (q * 4 + 1) / cg] * ga.y + be.y;
+        o.z = (v.z - gstat[(q * 4 + 2) / cg]) * gstat[32 + (q * 4 + 2) / cg] * ga.z + be.z;
+        o.w = (v.w - gstat[(q * 4 + 3) / cg]) * gstat[32 + (q * 4 + 3) / cg] * ga.w + be.w;
+        st4(y + base + t * tstride + q * 4, o);
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// conv_in: x*(1-obs)+x0*obs, indicator channel = obs, 3x3 pad-1 conv, channels-last output.
+// Thread = (pixel, quad of 4 output channels); weights [(C+1)*9][Cout] in LDS.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+                                                      const float* __restrict__ obs, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                      int C, int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [k = ci*9+tap][Cout]
+    const int Ci = C + 1;
+    const int K = Ci * 9;
+    for (int i = threadIdx.x; i < K * Cout; i += blockDim.x) {
+        const int co = i / K, k = i - co * K;  // w is OIHW: [co][ci][tap]
+        wl[k * Cout + co] = w[i];
+    }
+    __syncthreads();
+    const int QC = Cout / 4;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)N * H * W * QC;
+    if (gid >= total) return;
+    const int cq = (int)(gid % QC);
+    const long pix = gid / QC;
+    const int HW = H * W;
+    const int n = (int)(pix / HW);
+    const int p = (int)(pix - (long)n * HW);
+    const int oy = p / W, ox = p - oy * W;
+    const float ob = obs[n];
+    f32x4 acc = ld4(bias + cq * 4);
+    const float* xn = x + (size_t)n * C * HW;
+    const float* x0n = x0 + (size_t)n * C * HW;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const int ip = iy * W + ix;
+        for (int ci = 0; ci < Ci; ++ci) {
+            float v;
+            if (ci < C) v = xn[ci * HW + ip] * (1.0f - ob) + x0n[ci * HW + ip] * ob;
+            else v = ob;
+            acc += v * ld4(wl + (ci * 9 + tap) * Cout + cq * 4);
+        }
+    }
+    st4(out + (size_t)pix * Cout + cq * 4, acc);
+}
+
+// -------------------------------------------------------------------------------------
+// rowdot: one wave per output row o of a job; up to 8 input rows share each weight load.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowdot_kernel(const lfvdm_rowdot_job* __restrict__ jobs, int njobs, int total_rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= total_rows) return;
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].row0 <= row) ++j;
+    const lfvdm_rowdot_job J = jobs[j];
+    const int o = row - J.row0;
+    const float* wrow = J.W + (size_t)o * J.K;
+    const float bo = J.b ? J.b[o] : 0.f;
+    for (int m0 = 0; m0 < J.M; m0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int k = lane * 4; k < J.K; k += 256) {
+            const f32x4 wv = ld4(wrow + k);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (m0 + i >= J.M) break;
+                f32x4 v;
+                if (J.in_mode == 2) {
+                    // sinusoidal embedding [cos | sin]; frequency table appended after the timesteps
+                    const float t = J.in[m0 + i];
+                    const float* fr = J.in + J.ldin;  // freqs[K/2]
+                    const int half = J.K >> 1;
+                    float e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int kk = k + u;
+                        e[u] = kk < half ? cosf(t * fr[kk]) : sinf(t * fr[kk - half]);
+                    }
+                    v.x = e[0]; v.y = e[1]; v.z = e[2]; v.w = e[3];
+                } else {
+                    v = ld4(J.in + (size_t)(m0 + i) * J.ldin + k);
+                    if (J.in_mode == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                }
+                acc[i] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (m0 + i >= J.M) break;
+            const float s = wave_sum(acc[i]);
+            if (lane == 0) J.out[(size_t)(m0 + i) * J.ldout + o] = s + bo;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lfvdm_gn_coef(const float* src0, const float* src1, int C0, int C1, int N, int P, const float* gamma,
+                             const float* beta, const float* film, int film_div, int film_ld, float eps, float* coefA,
+                             float* coefB, void* stream) {
+    const int C = C0 + C1;
+    if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
+    if (C1 > 0 && !src1) return LFVDM_E_SHAPE;
+    if (film && film_div <= 0) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0, C1,
+                       P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_temporal(const float* x, const float* gamma, const float* beta, float eps, float* y, int B, int T,
+                                 int P, int C, void* stream) {
+    if (B <= 0 || T <= 0 || P <= 0 || C % 32 || C > GT_MAXC) return LFVDM_E_SHAPE;
+    const long samples = (long)B * P;
+    hipLaunchKernelGGL(gn_temporal_kernel, dim3((unsigned)((samples + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                       beta, eps, y, B, T, P, C);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_conv_in(const float* x, const float* x0, const float* obs, const float* w, const float* bias,
+                             float* out, int N, int C, int H, int W, int Cout, void* stream) {
+    if (N <= 0 || C <= 0 || Cout % 4 || H <= 0 || W <= 0) return LFVDM_E_SHAPE;
+    const size_t lds = (size_t)(C + 1) * 9 * Cout * sizeof(float);
+    if (lds > 64 * 1024) return LFVDM_E_UNSUPPORTED;
+    const long total = (long)N * H * W * (Cout / 4);
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, (hipStream_t)stream, x, x0, obs,
+                       w, bias, out, N, C, H, W, Cout);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_rowdot(const lfvdm_rowdot_job* jobs_dev, int njobs, int total_rows, void* stream) {
+    if (njobs <= 0 || total_rows <= 0) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((total_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs,
+                       total_rows);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}

@@ -1,0 +1,190 @@
+"""ctypes binding of the gfx950 C ABI (include/lfvdm_hip.h).
+
+PyTorch is used for device memory and streams only: every call passes raw device pointers,
+integer shapes and the current HIP stream.  There is NO fallback: if ``liblfvdm_hip.so`` is
+missing, importing the product on a GPU path raises immediately (build it with
+``python latent-flexible-video-diffusion-modeling_amd/build.py``).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "liblfvdm_hip.so")
+
+ACT_NONE, ACT_SILU = 0, 1
+OUT_ROWS, OUT_NCHW = 0, 1
+
+_lib = None
+
+c_fp = C.c_void_p
+c_i = C.c_int
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("src0", c_fp), ("src1", c_fp), ("C0", C.c_int32), ("C1", C.c_int32), ("N", C.c_int32),
+        ("Hs", C.c_int32), ("Ws", C.c_int32), ("up", C.c_int32), ("stride", C.c_int32), ("ksize", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("coefA", c_fp), ("coefB", c_fp), ("act", C.c_int32),
+        ("W", c_fp), ("bias", c_fp), ("Cout", C.c_int32),
+        ("s2src0", c_fp), ("s2src1", c_fp), ("s2C0", C.c_int32), ("s2C1", C.c_int32), ("W2", c_fp), ("bias2", c_fp),
+        ("res", c_fp), ("ldr", C.c_int32), ("resA", c_fp), ("resB", c_fp),
+        ("out", c_fp), ("ldo", C.c_int32), ("out_mode", C.c_int32),
+    ]
+
+
+class RowdotJob(C.Structure):
+    _fields_ = [("W", c_fp), ("b", c_fp), ("inp", c_fp), ("out", c_fp), ("K", C.c_int32), ("O", C.c_int32),
+                ("M", C.c_int32), ("ldin", C.c_int32), ("ldout", C.c_int32), ("in_mode", C.c_int32),
+                ("row0", C.c_int32), ("pad_", C.c_int32)]
+
+
+class RpeJob(C.Structure):
+    _fields_ = [("tproj", c_fp), ("Wd", c_fp), ("bd", c_fp), ("Wout", c_fp), ("bout", c_fp), ("R", c_fp),
+                ("C", C.c_int32), ("tile0", C.c_int32)]
+
+
+_SIGS = {
+    "lfvdm_abi_version": ([], c_i),
+    "lfvdm_conv_igemm": ([C.POINTER(ConvArgs), c_fp], c_i),
+    "lfvdm_pack_conv_weight": ([c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_conv_in": ([c_fp] * 6 + [c_i] * 5 + [c_fp], c_i),
+    "lfvdm_gn_coef": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp], c_i),
+    "lfvdm_gn_temporal": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_rowdot": ([c_fp, c_i, c_i, c_fp], c_i),
+    "lfvdm_rpe_nets": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
+    "lfvdm_attn_spatial": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_attn_temporal": ([c_fp] * 7 + [c_i] * 5 + [c_fp], c_i),
+    "lfvdm_q_sample": ([c_fp] * 6 + [c_i, c_i, c_fp], c_i),
+    "lfvdm_p_sample": ([c_fp] * 9 + [c_i] + [c_fp] * 3 + [c_i, c_i, c_fp], c_i),
+    "lfvdm_masked_mse": ([c_fp] * 4 + [c_i, c_i, c_i, c_fp], c_i),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"native library {LIB_PATH} is missing - build it with "
+                "`python latent-flexible-video-diffusion-modeling_amd/build.py` (there is no fallback path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (argt, rest) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = argt
+            fn.restype = rest
+        _lib = L
+    return _lib
+
+
+_ERR = {1: "invalid shape", 2: "HIP launch error", 3: "unsupported configuration"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("native ops need device (HIP) tensors; the product has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------------------ thin wrappers
+def conv_igemm(**kw):
+    """Fill an lfvdm_conv_args from keyword tensors/ints and launch.  Required: src0, C0, N, Hs, Ws,
+    Ho, Wo, W, Cout, out, ldo.  Everything else defaults to 'absent'."""
+    a = ConvArgs()
+    a.src0 = ptr(kw["src0"]); a.src1 = ptr(kw.get("src1")); a.C0 = kw["C0"]; a.C1 = kw.get("C1", 0)
+    a.N = kw["N"]; a.Hs = kw["Hs"]; a.Ws = kw["Ws"]; a.up = kw.get("up", 0); a.stride = kw.get("stride", 1)
+    a.ksize = kw.get("ksize", 3); a.Ho = kw["Ho"]; a.Wo = kw["Wo"]
+    a.coefA = ptr(kw.get("coefA")); a.coefB = ptr(kw.get("coefB")); a.act = kw.get("act", ACT_NONE)
+    a.W = ptr(kw["W"]); a.bias = ptr(kw.get("bias")); a.Cout = kw["Cout"]
+    a.s2src0 = ptr(kw.get("s2src0")); a.s2src1 = ptr(kw.get("s2src1")); a.s2C0 = kw.get("s2C0", 0); a.s2C1 = kw.get("s2C1", 0)
+    a.W2 = ptr(kw.get("W2")); a.bias2 = ptr(kw.get("bias2"))
+    a.res = ptr(kw.get("res")); a.ldr = kw.get("ldr", kw["Cout"]); a.resA = ptr(kw.get("resA")); a.resB = ptr(kw.get("resB"))
+    a.out = ptr(kw["out"]); a.ldo = kw["ldo"]; a.out_mode = kw.get("out_mode", OUT_ROWS)
+    check(lib().lfvdm_conv_igemm(C.byref(a), stream()), "lfvdm_conv_igemm")
+
+
+def conv_igemm_struct(a):
+    check(lib().lfvdm_conv_igemm(C.byref(a), stream()), "lfvdm_conv_igemm")
+
+
+def pack_conv_weight(w, out):
+    Cout, Cin, k, _ = w.shape
+    check(lib().lfvdm_pack_conv_weight(ptr(w), ptr(out), Cout, Cin, k, stream()), "lfvdm_pack_conv_weight")
+
+
+def conv_in(x, x0, obs, w, bias, out, N, Cc, H, W, Cout):
+    check(lib().lfvdm_conv_in(ptr(x), ptr(x0), ptr(obs), ptr(w), ptr(bias), ptr(out), N, Cc, H, W, Cout, stream()),
+          "lfvdm_conv_in")
+
+
+def gn_coef(src0, src1, C0, C1, N, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB):
+    check(lib().lfvdm_gn_coef(ptr(src0), ptr(src1), C0, C1, N, P, ptr(gamma), ptr(beta), ptr(film), film_div, film_ld,
+                              eps, ptr(coefA), ptr(coefB), stream()), "lfvdm_gn_coef")
+
+
+def gn_temporal(x, gamma, beta, eps, y, B, T, P, Cc):
+    check(lib().lfvdm_gn_temporal(ptr(x), ptr(gamma), ptr(beta), eps, ptr(y), B, T, P, Cc, stream()), "lfvdm_gn_temporal")
+
+
+def rowdot(jobs_dev, njobs, total_rows):
+    check(lib().lfvdm_rowdot(ptr(jobs_dev, torch.uint8), njobs, total_rows, stream()), "lfvdm_rowdot")
+
+
+def rpe_nets(jobs_dev, njobs, total_tiles, frame_indices, B, T):
+    check(lib().lfvdm_rpe_nets(ptr(jobs_dev, torch.uint8), njobs, total_tiles, ptr(frame_indices, torch.int64), B, T,
+                               stream()), "lfvdm_rpe_nets")
+
+
+def attn_spatial(qkv, o, attn_out, N, P, Cc, heads):
+    check(lib().lfvdm_attn_spatial(ptr(qkv), ptr(o), ptr(attn_out), N, P, Cc, heads, stream()), "lfvdm_attn_spatial")
+
+
+def attn_temporal(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, Cc, heads):
+    check(lib().lfvdm_attn_temporal(ptr(qkv), ptr(Rq), ptr(Rk), ptr(Rv), ptr(mask), ptr(o), ptr(attn_out), B, T, P, Cc,
+                                    heads, stream()), "lfvdm_attn_temporal")
+
+
+def q_sample(x0, noise, t, sa, sb, out):
+    B = x0.shape[0]
+    check(lib().lfvdm_q_sample(ptr(x0), ptr(noise), ptr(t, torch.int64), ptr(sa), ptr(sb), ptr(out), B,
+                               x0.numel() // B, stream()), "lfvdm_q_sample")
+
+
+def p_sample(x, eps, noise, t, recip, recipm1, c1, c2, logvar, clip, sample, pred=None, mean=None):
+    B = x.shape[0]
+    check(lib().lfvdm_p_sample(ptr(x), ptr(eps), ptr(noise), ptr(t, torch.int64), ptr(recip), ptr(recipm1), ptr(c1),
+                               ptr(c2), ptr(logvar), int(bool(clip)), ptr(sample), ptr(pred), ptr(mean), B,
+                               x.numel() // B, stream()), "lfvdm_p_sample")
+
+
+def masked_mse(a, b, mask, out, B, T, frame_inner):
+    check(lib().lfvdm_masked_mse(ptr(a), ptr(b), ptr(mask), ptr(out), B, T, frame_inner, stream()), "lfvdm_masked_mse")
+
+
+def jobs_to_device(jobs, device):
+    """Pack a list of ctypes Structures into one uint8 device tensor (job table)."""
+    if not jobs:
+        return None
+    arr = (type(jobs[0]) * len(jobs))(*jobs)
+    raw = bytes(memoryview(arr))
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)

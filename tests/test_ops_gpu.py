@@ -1,0 +1,328 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against the CPU oracle.  GPU only.
+
+Tolerances are fp32: the kernels use exact-fp32 MFMA (a k-ordered fmaf chain) and differ from
+ATen only by summation order and by v_exp/v_rcp (<= 1 ulp each) inside SiLU / softmax.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import recipe, unet_oracle as uo, diffusion_oracle as do
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from improved_diffusion import _native
+    _native.lib()
+    return _native
+
+
+def rnd(tag, *shape, scale=1.0):
+    return torch.from_numpy((scale * recipe.gaussianish(tag, int(np.prod(shape)))).reshape(shape).astype(np.float32))
+
+
+def cl(x):  # NCHW -> channels-last rows [N, H, W, C] contiguous, on device
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def from_cl(y, N, H, W, Cc):
+    return y.view(N, H, W, Cc).permute(0, 3, 1, 2).cpu()
+
+
+def close(a, b, atol, rtol=1e-4):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = float((a - b).abs().max())
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), f"max|d|={err:.3e} (scale {float(b.abs().max()):.3e})"
+
+
+def packed(nat, w):
+    o = torch.empty(w.shape[0], w.shape[2] * w.shape[3], w.shape[1], device="cuda")
+    nat.pack_conv_weight(w.cuda().contiguous(), o)
+    return o
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H", [(3, 64, 64, 16), (5, 128, 96, 8), (40, 256, 128, 2), (2, 32, 4, 16),
+                                          (1, 64, 192, 5)])
+def test_conv3x3_plain(nat, N, Cin, Cout, H):
+    x = rnd("c3/x", N, Cin, H, H)
+    w = rnd("c3/w", Cout, Cin, 3, 3, scale=0.05)
+    b = rnd("c3/b", Cout)
+    ref = F.conv2d(x, w, b, padding=1)
+    out = torch.empty(N * H * H, Cout, device="cuda")
+    nat.conv_igemm(src0=cl(x), C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, W=packed(nat, w), bias=b.cuda(), Cout=Cout,
+                   out=out, ldo=Cout)
+    close(from_cl(out, N, H, H, Cout), ref, 2e-5)
+
+
+def test_conv3x3_nchw_out(nat):
+    N, Cin, Cout, H = 4, 64, 4, 16
+    x, w, b = rnd("c3n/x", N, Cin, H, H), rnd("c3n/w", Cout, Cin, 3, 3, scale=0.05), rnd("c3n/b", Cout)
+    out = torch.empty(N, Cout, H, H, device="cuda")
+    nat.conv_igemm(src0=cl(x), C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, W=packed(nat, w), bias=b.cuda(), Cout=Cout,
+                   out=out, ldo=Cout, out_mode=nat.OUT_NCHW)
+    close(out, F.conv2d(x, w, b, padding=1), 2e-5)
+
+
+def test_conv_stride2_and_upsample(nat):
+    N, Cc, H = 3, 64, 8
+    x, w, b = rnd("cs/x", N, Cc, H, H), rnd("cs/w", Cc, Cc, 3, 3, scale=0.05), rnd("cs/b", Cc)
+    wp = packed(nat, w)
+    out = torch.empty(N * (H // 2) ** 2, Cc, device="cuda")
+    nat.conv_igemm(src0=cl(x), C0=Cc, N=N, Hs=H, Ws=H, stride=2, Ho=H // 2, Wo=H // 2, W=wp, bias=b.cuda(), Cout=Cc,
+                   out=out, ldo=Cc)
+    close(from_cl(out, N, H // 2, H // 2, Cc), F.conv2d(x, w, b, stride=2, padding=1), 2e-5)
+    out = torch.empty(N * (2 * H) ** 2, Cc, device="cuda")
+    nat.conv_igemm(src0=cl(x), C0=Cc, N=N, Hs=H, Ws=H, up=1, Ho=2 * H, Wo=2 * H, W=wp, bias=b.cuda(), Cout=Cc,
+                   out=out, ldo=Cc)
+    close(from_cl(out, N, 2 * H, 2 * H, Cc), F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1), 2e-5)
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,H", [(4, 64, 64, 64, 16), (6, 128, 64, 128, 8), (40, 128, 128, 128, 2)])
+def test_resblock_fused(nat, N, C0, C1, Cout, H):
+    """gn_coef + conv(GN+SiLU prologue) + gn_coef(FiLM) + conv(+1x1 skip segment) vs oracle res_block on a
+    virtual concat input (unet.py:194-207,460)."""
+    Cin = C0 + C1
+    xa, xb = rnd("rb/xa", N, C0, H, H), rnd("rb/xb", N, C1, H, H, scale=1.5)
+    x = torch.cat([xa, xb], 1)
+    T = 2
+    emb = rnd("rb/emb", N // T, 256)
+    emb_n = emb.repeat_interleave(T, 0)
+    shapes = {"in_layers.0.weight": (Cin,), "in_layers.0.bias": (Cin,), "in_layers.2.weight": (Cout, Cin, 3, 3),
+              "in_layers.2.bias": (Cout,), "emb_layers.1.weight": (2 * Cout, 256), "emb_layers.1.bias": (2 * Cout,),
+              "out_layers.0.weight": (Cout,), "out_layers.0.bias": (Cout,), "out_layers.3.weight": (Cout, Cout, 3, 3),
+              "out_layers.3.bias": (Cout,), "skip_connection.weight": (Cout, Cin, 1, 1), "skip_connection.bias": (Cout,)}
+    sd = {"p." + k: torch.from_numpy(recipe.fill_param("rbt." + k, s)) for k, s in shapes.items()}
+    ref = uo.res_block(sd, "p", x, emb_n)
+    d = {k: v.cuda() for k, v in sd.items()}
+    a, b = cl(xa), cl(xb)
+    P = H * H
+    film = F.linear(uo.silu(emb), sd["p.emb_layers.1.weight"], sd["p.emb_layers.1.bias"]).cuda().contiguous()
+    cA, cB = torch.empty(N, Cin, device="cuda"), torch.empty(N, Cin, device="cuda")
+    nat.gn_coef(a, b, C0, C1, N, P, d["p.in_layers.0.weight"], d["p.in_layers.0.bias"], None, 1, 0, 1e-5, cA, cB)
+    h1 = torch.empty(N * P, Cout, device="cuda")
+    nat.conv_igemm(src0=a, src1=b, C0=C0, C1=C1, N=N, Hs=H, Ws=H, Ho=H, Wo=H, coefA=cA, coefB=cB, act=nat.ACT_SILU,
+                   W=packed(nat, sd["p.in_layers.2.weight"]), bias=d["p.in_layers.2.bias"], Cout=Cout, out=h1, ldo=Cout)
+    ref_h1 = F.conv2d(uo.silu(uo.group_norm32(x, sd["p.in_layers.0.weight"], sd["p.in_layers.0.bias"])),
+                      sd["p.in_layers.2.weight"], sd["p.in_layers.2.bias"], padding=1)
+    close(from_cl(h1, N, H, H, Cout), ref_h1, 5e-5)
+    cA2, cB2 = torch.empty(N, Cout, device="cuda"), torch.empty(N, Cout, device="cuda")
+    nat.gn_coef(h1, None, Cout, 0, N, P, d["p.out_layers.0.weight"], d["p.out_layers.0.bias"], film, T, 2 * Cout, 1e-5, cA2, cB2)
+    out = torch.empty(N * P, Cout, device="cuda")
+    nat.conv_igemm(src0=h1, C0=Cout, N=N, Hs=H, Ws=H, Ho=H, Wo=H, coefA=cA2, coefB=cB2, act=nat.ACT_SILU,
+                   W=packed(nat, sd["p.out_layers.3.weight"]), bias=d["p.out_layers.3.bias"], Cout=Cout,
+                   s2src0=a, s2src1=b, s2C0=C0, s2C1=C1, W2=d["p.skip_connection.weight"].view(Cout, Cin).contiguous(),
+                   bias2=d["p.skip_connection.bias"], out=out, ldo=Cout)
+    close(from_cl(out, N, H, H, Cout), ref, 1e-4)
+
+
+def test_resblock_identity_skip(nat):
+    N, Cc, H, T = 4, 64, 8, 2
+    x = rnd("rbi/x", N, Cc, H, H)
+    emb = rnd("rbi/emb", N // T, 128)
+    shapes = {"in_layers.0.weight": (Cc,), "in_layers.0.bias": (Cc,), "in_layers.2.weight": (Cc, Cc, 3, 3),
+              "in_layers.2.bias": (Cc,), "emb_layers.1.weight": (2 * Cc, 128), "emb_layers.1.bias": (2 * Cc,),
+              "out_layers.0.weight": (Cc,), "out_layers.0.bias": (Cc,), "out_layers.3.weight": (Cc, Cc, 3, 3),
+              "out_layers.3.bias": (Cc,)}
+    sd = {"p." + k: torch.from_numpy(recipe.fill_param("rbi." + k, s)) for k, s in shapes.items()}
+    ref = uo.res_block(sd, "p", x, emb.repeat_interleave(T, 0))
+    d = {k: v.cuda() for k, v in sd.items()}
+    a, P = cl(x), H * H
+    film = F.linear(uo.silu(emb), sd["p.emb_layers.1.weight"], sd["p.emb_layers.1.bias"]).cuda().contiguous()
+    cA, cB = torch.empty(N, Cc, device="cuda"), torch.empty(N, Cc, device="cuda")
+    nat.gn_coef(a, None, Cc, 0, N, P, d["p.in_layers.0.weight"], d["p.in_layers.0.bias"], None, 1, 0, 1e-5, cA, cB)
+    h1 = torch.empty(N * P, Cc, device="cuda")
+    nat.conv_igemm(src0=a, C0=Cc, N=N, Hs=H, Ws=H, Ho=H, Wo=H, coefA=cA, coefB=cB, act=nat.ACT_SILU,
+                   W=packed(nat, sd["p.in_layers.2.weight"]), bias=d["p.in_layers.2.bias"], Cout=Cc, out=h1, ldo=Cc)
+    nat.gn_coef(h1, None, Cc, 0, N, P, d["p.out_layers.0.weight"], d["p.out_layers.0.bias"], film, T, 2 * Cc, 1e-5, cA, cB)
+    out = torch.empty(N * P, Cc, device="cuda")
+    nat.conv_igemm(src0=h1, C0=Cc, N=N, Hs=H, Ws=H, Ho=H, Wo=H, coefA=cA, coefB=cB, act=nat.ACT_SILU,
+                   W=packed(nat, sd["p.out_layers.3.weight"]), bias=d["p.out_layers.3.bias"], Cout=Cc,
+                   res=a, ldr=Cc, out=out, ldo=Cc)
+    close(from_cl(out, N, H, H, Cc), ref, 1e-4)
+
+
+def test_conv_in(nat):
+    B, T, Cc, H, Cout = 2, 3, 4, 16, 64
+    x, x0 = rnd("ci/x", B, T, Cc, H, H), rnd("ci/x0", B, T, Cc, H, H)
+    obs = torch.tensor([[1., 0, 1], [0, 0, 1]]).view(B, T, 1, 1, 1)
+    w, b = rnd("ci/w", Cout, Cc + 1, 3, 3, scale=0.2), rnd("ci/b", Cout)
+    comp = torch.cat([x * (1 - obs) + x0 * obs, torch.ones_like(x[:, :, :1]) * obs], 2).reshape(B * T, Cc + 1, H, H)
+    ref = F.conv2d(comp, w, b, padding=1)
+    out = torch.empty(B * T * H * H, Cout, device="cuda")
+    nat.conv_in(x.cuda(), x0.cuda(), obs.reshape(-1).cuda().contiguous(), w.cuda(), b.cuda(), out, B * T, Cc, H, H, Cout)
+    close(from_cl(out, B * T, H, H, Cout), ref, 1e-5)
+
+
+def test_rowdot_time_embed(nat):
+    """sinusoid -> Linear -> SiLU -> Linear, then a grouped SiLU->Linear (nn.py:105-123, unet.py:303-308)."""
+    B, ch = 3, 64
+    ted = 4 * ch
+    t = torch.tensor([0.0, 37.5, 999.0])
+    w0, b0 = rnd("rd/w0", ted, ch, scale=0.1), rnd("rd/b0", ted, scale=0.1)
+    w2, b2 = rnd("rd/w2", ted, ted, scale=0.05), rnd("rd/b2", ted, scale=0.1)
+    w3, b3 = rnd("rd/w3", 96, ted, scale=0.05), rnd("rd/b3", 96, scale=0.1)
+    e0 = F.linear(uo.timestep_embedding(t, ch), w0, b0)
+    emb = F.linear(uo.silu(e0), w2, b2)
+    e3 = F.linear(uo.silu(emb), w3, b3)
+    e4 = F.linear(emb, w3, b3)
+    import math
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(ch // 2, dtype=torch.float32) / (ch // 2))
+    tin = torch.cat([t, torch.zeros(8 - B), freqs]).cuda()  # timesteps | pad | freqs at offset 8
+    dev = {k: v.cuda() for k, v in dict(w0=w0, b0=b0, w2=w2, b2=b2, w3=w3, b3=b3).items()}
+    o0, o1 = torch.empty(B, ted, device="cuda"), torch.empty(B, ted, device="cuda")
+    o3, o4 = torch.empty(B, 96, device="cuda"), torch.empty(B, 96, device="cuda")
+
+    def job(W, b, inp, out, K, O, ldin, ldout, mode, row0):
+        return nat.RowdotJob(W.data_ptr(), b.data_ptr(), inp.data_ptr(), out.data_ptr(), K, O, B, ldin, ldout, mode, row0, 0)
+
+    j0 = nat.jobs_to_device([job(dev["w0"], dev["b0"], tin, o0, ch, ted, 8, ted, 2, 0)], "cuda")
+    nat.rowdot(j0, 1, ted)
+    close(o0, e0, 2e-5)
+    j1 = nat.jobs_to_device([job(dev["w2"], dev["b2"], o0, o1, ted, ted, ted, ted, 1, 0)], "cuda")
+    nat.rowdot(j1, 1, ted)
+    close(o1, emb, 2e-5)
+    j2 = nat.jobs_to_device([job(dev["w3"], dev["b3"], o1, o3, ted, 96, ted, 96, 1, 0),
+                             job(dev["w3"], dev["b3"], o1, o4, ted, 96, ted, 96, 0, 96)], "cuda")
+    nat.rowdot(j2, 2, 192)
+    close(o3, e3, 2e-5)
+    close(o4, e4, 2e-5)
+
+
+@pytest.mark.parametrize("Cc,heads", [(64, 4), (128, 4), (32, 2)])
+def test_rpe_nets(nat, Cc, heads):
+    B, T, ted = 2, 5, 128
+    fi = torch.tensor([[0, 1, 2, 3, 4], [3, 17, 18, 400, 999]])
+    temb_b = rnd("rn/temb", B, ted)
+    temb = temb_b.repeat_interleave(T, 0)
+    jobs, refs, keep = [], [], []
+    tile0 = 0
+    for i in range(3):
+        shapes = {"embed_distances.weight": (Cc, 3), "embed_distances.bias": (Cc,),
+                  "embed_diffusion_time.weight": (Cc, ted), "embed_diffusion_time.bias": (Cc,),
+                  "out.weight": (Cc, Cc), "out.bias": (Cc,)}
+        sd = {"p." + k: torch.from_numpy(recipe.fill_param(f"rn{i}." + k, s)) for k, s in shapes.items()}
+        rel = fi.unsqueeze(-1) - fi.unsqueeze(-2)
+        refs.append(uo.rpe_net(sd, "p", temb, rel, heads).reshape(B, T, T, Cc))
+        d = {k: v.cuda() for k, v in sd.items()}
+        tproj = F.linear(temb_b, sd["p.embed_diffusion_time.weight"], sd["p.embed_diffusion_time.bias"]).cuda().contiguous()
+        R = torch.empty(B, T, T, Cc, device="cuda")
+        keep.append((d, tproj, R))
+        jobs.append(nat.RpeJob(tproj.data_ptr(), d["p.embed_distances.weight"].data_ptr(), d["p.embed_distances.bias"].data_ptr(),
+                               d["p.out.weight"].data_ptr(), d["p.out.bias"].data_ptr(), R.data_ptr(), Cc, tile0))
+        tile0 += (B * T * T + 31) // 32
+    jd = nat.jobs_to_device(jobs, "cuda")
+    nat.rpe_nets(jd, 3, tile0, fi.cuda(), B, T)
+    for (d, tp, R), ref in zip(keep, refs):
+        close(R, ref, 2e-5)
+
+
+@pytest.mark.parametrize("N,P,Cc,heads", [(3, 256, 64, 4), (2, 64, 128, 4), (5, 4, 128, 4), (2, 100, 64, 2), (1, 256, 32, 2)])
+def test_attn_spatial(nat, N, P, Cc, heads):
+    qkv = rnd("as/qkv", N, P, 3 * Cc)
+    Fh = Cc // heads
+    q, k, v = (qkv.view(N, P, 3, heads, Fh)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    attn = torch.softmax((q * Fh ** -0.5) @ k.transpose(-1, -2), -1)
+    ref = (attn @ v).permute(0, 2, 1, 3).reshape(N, P, Cc)
+    o = torch.empty(N * P, Cc, device="cuda")
+    a = torch.empty(N, heads, P, P, device="cuda")
+    nat.attn_spatial(qkv.cuda(), o, a, N, P, Cc, heads)
+    close(o.view(N, P, Cc), ref, 2e-5)
+    close(a, attn, 1e-5)
+
+
+@pytest.mark.parametrize("B,T,P,Cc,heads", [(2, 20, 16, 64, 4), (2, 5, 4, 128, 4), (1, 14, 9, 64, 4), (2, 32, 3, 32, 2)])
+def test_temporal_attention_block(nat, B, T, P, Cc, heads):
+    """gn_temporal + qkv GEMM + RPE nets + temporal core + proj GEMM vs oracle rpe_attention (rpe.py:133-174)."""
+    ted = 128
+    shapes = {"qkv.weight": (3 * Cc, Cc), "qkv.bias": (3 * Cc,), "proj_out.weight": (Cc, Cc), "proj_out.bias": (Cc,),
+              "norm.weight": (Cc,), "norm.bias": (Cc,)}
+    for r in ("rpe_q", "rpe_k", "rpe_v"):
+        shapes.update({f"{r}.rpe_net.embed_distances.weight": (Cc, 3), f"{r}.rpe_net.embed_distances.bias": (Cc,),
+                       f"{r}.rpe_net.embed_diffusion_time.weight": (Cc, ted), f"{r}.rpe_net.embed_diffusion_time.bias": (Cc,),
+                       f"{r}.rpe_net.out.weight": (Cc, Cc), f"{r}.rpe_net.out.bias": (Cc,)})
+    sd = {"p." + k: torch.from_numpy(recipe.fill_param("ta." + k, s)) for k, s in shapes.items()}
+    x = rnd("ta/x", B, P, Cc, T)  # oracle layout (B, D, C, T)
+    temb_b = rnd("ta/temb", B, ted)
+    fi = torch.stack([torch.arange(T), torch.sort(torch.from_numpy(np.argsort(recipe.uniform_pm1("ta/fi", 1000))[:T].copy()))[0]])[:B]
+    mask = (torch.from_numpy(recipe.uniform_pm1("ta/mask", B * T)).view(B, T) > 0).float()
+    ref, ref_attn = uo.rpe_attention(sd, "p", x, temb_b.repeat_interleave(T, 0), fi, mask, heads, True)
+    d = {k: v.cuda() for k, v in sd.items()}
+    # channels-last activation [B*T][P][C]
+    xc = x.permute(0, 3, 1, 2).reshape(B * T, P, Cc).contiguous().cuda()
+    xn = torch.empty_like(xc)
+    nat.gn_temporal(xc, d["p.norm.weight"], d["p.norm.bias"], 1e-5, xn, B, T, P, Cc)
+    M = B * T * P
+    qkv = torch.empty(M, 3 * Cc, device="cuda")
+    nat.conv_igemm(src0=xn, C0=Cc, N=B * T, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.qkv.weight"], bias=d["p.qkv.bias"],
+                   Cout=3 * Cc, out=qkv, ldo=3 * Cc)
+    jobs, Rs, keep, tile0 = [], {}, [], 0
+    for r in ("rpe_q", "rpe_k", "rpe_v"):
+        pre = f"p.{r}.rpe_net."
+        tproj = F.linear(temb_b, sd[pre + "embed_diffusion_time.weight"], sd[pre + "embed_diffusion_time.bias"]).cuda().contiguous()
+        Rs[r] = torch.empty(B, T, T, Cc, device="cuda")
+        keep.append(tproj)
+        jobs.append(nat.RpeJob(tproj.data_ptr(), d[pre + "embed_distances.weight"].data_ptr(), d[pre + "embed_distances.bias"].data_ptr(),
+                               d[pre + "out.weight"].data_ptr(), d[pre + "out.bias"].data_ptr(), Rs[r].data_ptr(), Cc, tile0))
+        tile0 += (B * T * T + 31) // 32
+    nat.rpe_nets(nat.jobs_to_device(jobs, "cuda"), 3, tile0, fi.cuda(), B, T)
+    o = torch.empty(M, Cc, device="cuda")
+    attn = torch.empty(B * P, heads, T, T, device="cuda")
+    nat.attn_temporal(qkv, Rs["rpe_q"], Rs["rpe_k"], Rs["rpe_v"], mask.cuda(), o, attn, B, T, P, Cc, heads)
+    close(attn.view(B, P, heads, T, T), ref_attn, 2e-5)
+    y = torch.empty(M, Cc, device="cuda")
+    nat.conv_igemm(src0=o, C0=Cc, N=B * T, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.proj_out.weight"], bias=d["p.proj_out.bias"],
+                   Cout=Cc, res=xn.view(M, Cc), ldr=Cc, out=y, ldo=Cc)
+    got = y.view(B, T, P, Cc).permute(0, 2, 3, 1)  # -> (B, P, C, T)
+    close(got, ref, 1e-4)
+
+
+def test_spatial_attention_block(nat):
+    """gn_coef + qkv GEMM (affine prologue) + spatial core + proj GEMM (affine residual) vs oracle."""
+    N, P, Cc, heads = 3, 64, 64, 4
+    shapes = {"qkv.weight": (3 * Cc, Cc), "qkv.bias": (3 * Cc,), "proj_out.weight": (Cc, Cc), "proj_out.bias": (Cc,),
+              "norm.weight": (Cc,), "norm.bias": (Cc,)}
+    sd = {"p." + k: torch.from_numpy(recipe.fill_param("sa." + k, s)) for k, s in shapes.items()}
+    x = rnd("sa/x", 1, N, Cc, P)  # (B=1, D=N frames, C, T=P tokens)
+    ref, _ = uo.rpe_attention(sd, "p", x, None, None, None, heads, False)
+    d = {k: v.cuda() for k, v in sd.items()}
+    xc = x[0].permute(0, 2, 1).contiguous().cuda()  # [N][P][C]
+    cA, cB = torch.empty(N, Cc, device="cuda"), torch.empty(N, Cc, device="cuda")
+    nat.gn_coef(xc, None, Cc, 0, N, P, d["p.norm.weight"], d["p.norm.bias"], None, 1, 0, 1e-5, cA, cB)
+    M = N * P
+    qkv = torch.empty(M, 3 * Cc, device="cuda")
+    nat.conv_igemm(src0=xc, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=cA, coefB=cB, W=d["p.qkv.weight"],
+                   bias=d["p.qkv.bias"], Cout=3 * Cc, out=qkv, ldo=3 * Cc)
+    o = torch.empty(M, Cc, device="cuda")
+    nat.attn_spatial(qkv, o, None, N, P, Cc, heads)
+    y = torch.empty(M, Cc, device="cuda")
+    nat.conv_igemm(src0=o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.proj_out.weight"], bias=d["p.proj_out.bias"],
+                   Cout=Cc, res=xc.view(M, Cc), ldr=Cc, resA=cA, resB=cB, out=y, ldo=Cc)
+    close(y.view(N, P, Cc).permute(0, 2, 1), ref[0], 1e-4)
+
+
+def test_diffusion_ops(nat):
+    B, T, Cc, H = 3, 4, 4, 8
+    tab = do.Tables(do.linear_betas(1000))
+    x0, noise, x, eps = (rnd(f"df/{n}", B, T, Cc, H, H) for n in ("x0", "noise", "x", "eps"))
+    t = torch.tensor([999, 0, 417])
+    dev = lambda a: torch.from_numpy(a).float().cuda()
+    out = torch.empty(B, T, Cc, H, H, device="cuda")
+    nat.q_sample(x0.cuda(), noise.cuda(), t.cuda(), dev(tab.sqrt_alphas_cumprod), dev(tab.sqrt_one_minus_alphas_cumprod), out)
+    close(out, do.q_sample(tab, x0, t, noise), 1e-6)
+    smp, pred, mean = (torch.empty_like(out) for _ in range(3))
+    nat.p_sample(x.cuda(), eps.cuda(), noise.cuda(), t.cuda(), dev(tab.sqrt_recip_alphas_cumprod),
+                 dev(tab.sqrt_recipm1_alphas_cumprod), dev(tab.posterior_mean_coef1), dev(tab.posterior_mean_coef2),
+                 dev(tab.fixed_large_log_variance), True, smp, pred, mean)
+    ref_s, ref_p = do.p_sample(tab, eps, x, t, noise)
+    close(smp, ref_s, 1e-5)
+    close(pred, ref_p, 1e-4)  # 157x amplification at t=999 before the clamp
+    close(mean, do.p_mean_variance(tab, eps, x, t)["mean"], 1e-5)
+    mask = torch.tensor([[1., 0, 1, 1], [0, 0, 0, 0], [1, 1, 1, 1]])
+    mo = torch.empty(B, device="cuda")
+    nat.masked_mse(x.cuda(), eps.cuda(), mask.cuda(), mo, B, T, Cc * H * H)
+    close(mo, do.masked_mean_flat((x - eps) ** 2, mask.view(B, T, 1, 1, 1)), 1e-6, rtol=1e-5)
