@@ -106,11 +106,13 @@ __global__ __launch_bounds__(256) void rpe_nets_kernel(const lfvdm_rpe_job* __re
 // (K rows padded to F+8, V rows to F+4 floats: conflict-free b128 / b32 fragment reads).
 // k-index mapping inside a 16-wide f group g: MFMA step e uses f = 16g + 4*kk + e (kk = lane>>4)
 // on both K (A operand) and Q (B operand).
-template <int F>
+// FP = head dim padded to a multiple of 16 (compile time); F = real head dim (multiple of 4): the
+// pad columns are zero in LDS / in the Q fragments and are never stored.
+template <int FP>
 __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restrict__ qkv, float* __restrict__ o, int P,
-                                                           int C, int heads) {
-    constexpr int FG = F / 16;   // 16-wide f groups
-    constexpr int KLD = F + 8, VLD = F + 4;
+                                                           int C, int heads, int F) {
+    constexpr int FG = FP / 16;   // 16-wide f groups
+    constexpr int KLD = FP + 8, VLD = FP + 4;
     __shared__ __attribute__((aligned(16))) float Ks[64 * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * VLD];
     const int lane = threadIdx.x & 63;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
 #pragma unroll
         for (int g = 0; g < FG; ++g) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < P) v = ld4(base + (size_t)q * ld + 16 * g + 4 * kk);
+            if (q < P && 16 * g + 4 * kk < F) v = ld4(base + (size_t)q * ld + 16 * g + 4 * kk);
             qf[g] = v * scale;
         }
     }
@@ -140,10 +142,10 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
 
     for (int kb = 0; kb < P; kb += 64) {
         __syncthreads();  // previous block fully consumed
-        for (int e = threadIdx.x; e < 64 * (F / 4); e += 256) {
-            const int key = e / (F / 4), fq = e - key * (F / 4);
+        for (int e = threadIdx.x; e < 64 * (FP / 4); e += 256) {
+            const int key = e / (FP / 4), fq = e - key * (FP / 4);
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (kb + key < P) {
+            if (kb + key < P && fq * 4 < F) {
                 const float* row = base + (size_t)(kb + key) * ld + fq * 4;
                 kv = ld4(row + C);
                 vv = ld4(row + 2 * C);
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
     if (q < P) {
 #pragma unroll
         for (int g = 0; g < FG; ++g)
-            st4(o + ((size_t)n * P + q) * C + h * F + 16 * g + 4 * kk, oacc[g] * inv);
+            if (16 * g + 4 * kk < F) st4(o + ((size_t)n * P + q) * C + h * F + 16 * g + 4 * kk, oacc[g] * inv);
     }
 }
 
@@ -338,11 +340,13 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const float* __restr
     }
 
     // o[t][f] = sum_s p[t][s] * (v[s][f] + Rv[t][s][f])
+    constexpr int FO = F < 16 ? F : 16;   // output channels per pass
+    constexpr int NU = FO / 4;
 #pragma unroll
-    for (int f0 = 0; f0 < F; f0 += 16) {
-        f32x4 acc[4];
+    for (int f0 = 0; f0 < F; f0 += FO) {
+        f32x4 acc[NU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NU; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < TA_MAXT / 2; ++i) {
             const int s = 2 * i + half;
@@ -350,18 +354,18 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const float* __restr
                 const float pr = logit[i] * inv;
                 const float* rv = Rv + (((size_t)(b * T + tt) * T + s) * C) + h * F + f0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] += pr * (ld4(vs + s * LD + f0 + 4 * u) + ld4(rv + 4 * u));
+                for (int u = 0; u < NU; ++u) acc[u] += pr * (ld4(vs + s * LD + f0 + 4 * u) + ld4(rv + 4 * u));
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             acc[u].x += __shfl_xor(acc[u].x, 32, 64); acc[u].y += __shfl_xor(acc[u].y, 32, 64);
             acc[u].z += __shfl_xor(acc[u].z, 32, 64); acc[u].w += __shfl_xor(acc[u].w, 32, 64);
         }
         if (tv && half == 0) {
             float* orow = o + ((size_t)(b * T + tt) * P + p) * C + h * F + f0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) st4(orow + 4 * u, acc[u]);
+            for (int u = 0; u < NU; ++u) st4(orow + 4 * u, acc[u]);
         }
     }
 }
@@ -391,11 +395,14 @@ extern "C" int lfvdm_attn_spatial(const float* qkv, float* o, float* attn_out, i
     const int F = C / heads;
     const dim3 grid((P + 63) / 64, heads, N);
     hipStream_t s = (hipStream_t)stream;
-    switch (F) {
-        case 16: hipLaunchKernelGGL(attn_spatial_kernel<16>, grid, dim3(256), 0, s, qkv, o, P, C, heads); break;
-        case 32: hipLaunchKernelGGL(attn_spatial_kernel<32>, grid, dim3(256), 0, s, qkv, o, P, C, heads); break;
-        case 64: hipLaunchKernelGGL(attn_spatial_kernel<64>, grid, dim3(256), 0, s, qkv, o, P, C, heads); break;
-        case 96: hipLaunchKernelGGL(attn_spatial_kernel<96>, grid, dim3(256), 0, s, qkv, o, P, C, heads); break;
+    if (F % 4 || F > 96) return LFVDM_E_UNSUPPORTED;
+    const int FP = (F + 15) / 16 * 16;
+    switch (FP) {
+        case 16: hipLaunchKernelGGL(attn_spatial_kernel<16>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 32: hipLaunchKernelGGL(attn_spatial_kernel<32>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 48: hipLaunchKernelGGL(attn_spatial_kernel<48>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 64: hipLaunchKernelGGL(attn_spatial_kernel<64>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 96: hipLaunchKernelGGL(attn_spatial_kernel<96>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
         default: return LFVDM_E_UNSUPPORTED;
     }
     LFVDM_CHECK_LAUNCH();
@@ -415,6 +422,7 @@ extern "C" int lfvdm_attn_temporal(const float* qkv, const float* Rq, const floa
     const dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
     switch (F) {
+        case 8: hipLaunchKernelGGL(attn_temporal_kernel<8>, grid, dim3(256), 0, s, qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads); break;
         case 16: hipLaunchKernelGGL(attn_temporal_kernel<16>, grid, dim3(256), 0, s, qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads); break;
         case 32: hipLaunchKernelGGL(attn_temporal_kernel<32>, grid, dim3(256), 0, s, qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads); break;
         case 64: hipLaunchKernelGGL(attn_temporal_kernel<64>, grid, dim3(256), 0, s, qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads); break;

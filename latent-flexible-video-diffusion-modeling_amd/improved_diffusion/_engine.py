@@ -1,0 +1,374 @@
+"""Native execution engine of ``UNetVideoModel``: turns the module tree into a flat sequence of
+gfx950 kernel launches (C ABI of include/lfvdm_hip.h) for one input shape.
+
+Design (MI355X-first, not a translation of the reference's ATen op stream, unet.py:428-464):
+  * activations are channels-last [B*T][H][W][C]; no layout permutes exist anywhere — temporal
+    attention strides over frames, spatial attention over pixels of the same buffer;
+  * GroupNorm+SiLU(+FiLM) is never materialised: a statistics kernel emits per-(sample,channel)
+    affine coefficients that the consuming implicit-GEMM applies while staging its A operand;
+  * skip concat, nearest-2x upsample, the 1x1 skip conv and every residual add are operands /
+    epilogues of the implicit-GEMM kernel;
+  * everything that depends only on (t, frame_indices) — time-embedding MLP, all ResBlock FiLM
+    projections, all 3*L RPE networks — is evaluated up front in 4 grouped launches;
+  * a forward is ~130 launches with no host synchronisation and no allocation, so the whole
+    denoising step is captured into one hipGraph by the sampler (gaussian_diffusion.py).
+"""
+import ctypes as C
+
+import torch as th
+import torch.nn as nn
+
+from . import _native as nat
+from .nn import timestep_freqs
+
+
+def _p(t):
+    return t.data_ptr()
+
+
+class Plan:
+    """Launch sequence + workspaces for one (B, T, H, W)."""
+
+    def __init__(self, engine, B, T, H, W, want_attn):
+        self.engine = engine
+        self.model = engine.model
+        self.B, self.T, self.H, self.W = B, T, H, W
+        self.want_attn = want_attn
+        self.dev = next(self.model.parameters()).device
+        self.keep = []      # tensors / ctypes objects that must outlive the plan's raw pointers
+        self.steps = []     # (callable, args) executed in order; every callable takes the stream last
+        self.packs = []     # (conv weight parameter, packed buffer)
+        self.attn_t, self.attn_s = [], []
+        self._build()
+
+    # ------------------------------------------------------------------ helpers
+    def buf(self, *shape, dtype=th.float32):
+        t = th.empty(*shape, device=self.dev, dtype=dtype)
+        self.keep.append(t)
+        return t
+
+    def packed(self, weight):
+        Cout, Cin, k, _ = weight.shape
+        out = self.buf(Cout, k * k, Cin)
+        self.packs.append((weight, out))
+        return out
+
+    def add(self, fn, *args):
+        self.steps.append((fn, args))
+
+    def add_conv(self, **kw):
+        a = nat.ConvArgs()
+        g = kw.get
+        a.src0 = _p(kw["src0"]); a.src1 = _p(g("src1")) if g("src1") is not None else None
+        a.C0 = kw["C0"]; a.C1 = g("C1", 0); a.N = kw["N"]; a.Hs = kw["Hs"]; a.Ws = kw["Ws"]
+        a.up = g("up", 0); a.stride = g("stride", 1); a.ksize = g("ksize", 3); a.Ho = kw["Ho"]; a.Wo = kw["Wo"]
+        a.coefA = _p(g("coefA")) if g("coefA") is not None else None
+        a.coefB = _p(g("coefB")) if g("coefB") is not None else None
+        a.act = g("act", nat.ACT_NONE)
+        a.W = _p(kw["W"]); a.bias = _p(g("bias")) if g("bias") is not None else None; a.Cout = kw["Cout"]
+        a.s2src0 = _p(g("s2src0")) if g("s2src0") is not None else None
+        a.s2src1 = _p(g("s2src1")) if g("s2src1") is not None else None
+        a.s2C0 = g("s2C0", 0); a.s2C1 = g("s2C1", 0)
+        a.W2 = _p(g("W2")) if g("W2") is not None else None
+        a.bias2 = _p(g("bias2")) if g("bias2") is not None else None
+        a.res = _p(g("res")) if g("res") is not None else None
+        a.ldr = g("ldr", kw["Cout"])
+        a.resA = _p(g("resA")) if g("resA") is not None else None
+        a.resB = _p(g("resB")) if g("resB") is not None else None
+        a.out = _p(kw["out"]); a.ldo = kw["ldo"]; a.out_mode = g("out_mode", nat.OUT_ROWS)
+        self.keep.append(a)
+        self.add(nat.lib().lfvdm_conv_igemm, C.byref(a))
+
+    # ------------------------------------------------------------------ build
+    def _build(self):
+        m, L = self.model, nat.lib()
+        B, T, H, W = self.B, self.T, self.H, self.W
+        N = B * T
+        if T > 32:
+            raise RuntimeError("native temporal attention supports at most 32 frames per window")
+        if m.dims != 2:
+            raise NotImplementedError("only dims=2 is on the native path (the reference scripts use 2)")
+        if not m.use_scale_shift_norm:
+            raise NotImplementedError("use_scale_shift_norm=False is not on the native path (default True)")
+        ch = m.model_channels
+        ted = 4 * ch
+        Cx = m.in_channels - 1
+
+        # ---- static inputs
+        self.x_in = self.buf(B, T, Cx, H, W)
+        self.x0_in = self.buf(B, T, Cx, H, W)
+        self.obs = self.buf(N)
+        self.mask = self.buf(B, T)
+        self.fi = self.buf(B, T, dtype=th.int64)
+        half = ch // 2
+        self.Bpad = (B + 3) // 4 * 4
+        self.tin = self.buf(self.Bpad + half)
+        self.tin.zero_()
+        self.tin[self.Bpad:] = timestep_freqs(ch).to(self.dev)
+
+        # ---- embeddings: 3 row-dot launches for the whole network
+        e0, self.emb = self.buf(B, ted), self.buf(B, ted)
+        te0, te2 = m.time_embed[0], m.time_embed[2]
+
+        def rjob(lin, inp, out, K, ldin, mode, row0):
+            O = lin.weight.shape[0]
+            return nat.RowdotJob(_p(lin.weight), _p(lin.bias), _p(inp), _p(out), K, O, B, ldin, O, mode, row0, 0)
+
+        j0 = nat.jobs_to_device([rjob(te0, self.tin, e0, ch, self.Bpad, 2, 0)], self.dev)
+        j1 = nat.jobs_to_device([rjob(te2, e0, self.emb, ted, ted, 1, 0)], self.dev)
+        self.keep += [j0, j1]
+        self.add(L.lfvdm_rowdot, _p(j0), 1, ted)
+        self.add(L.lfvdm_rowdot, _p(j1), 1, ted)
+
+        from .unet import ResBlock, FactorizedAttentionBlock
+        jobs, row0 = [], 0
+        self.film = {}
+        self.tproj = {}
+        for mod in m.modules():
+            if isinstance(mod, ResBlock):
+                lin = mod.emb_layers[1]
+                out = self.buf(B, lin.weight.shape[0])
+                self.film[mod] = out
+                jobs.append(rjob(lin, self.emb, out, ted, ted, 1, row0))
+                row0 += lin.weight.shape[0]
+            elif isinstance(mod, FactorizedAttentionBlock):
+                ta = mod.temporal_attention
+                for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v):
+                    lin = r.rpe_net.embed_diffusion_time
+                    out = self.buf(B, lin.weight.shape[0])
+                    self.tproj[r] = out
+                    jobs.append(rjob(lin, self.emb, out, ted, ted, 0, row0))
+                    row0 += lin.weight.shape[0]
+        jg = nat.jobs_to_device(jobs, self.dev)
+        self.keep.append(jg)
+        self.add(L.lfvdm_rowdot, _p(jg), len(jobs), row0)
+
+        # ---- all RPE networks in one launch
+        rjobs, tile0 = [], 0
+        self.R = {}
+        tiles_per = (B * T * T + 31) // 32
+        for mod in m.modules():
+            if isinstance(mod, FactorizedAttentionBlock):
+                ta = mod.temporal_attention
+                for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v):
+                    net = r.rpe_net
+                    Cc = net.channels
+                    if Cc > 512:
+                        raise RuntimeError("RPE nets support at most 512 channels natively")
+                    Rb = self.buf(B, T, T, Cc)
+                    self.R[r] = Rb
+                    rjobs.append(nat.RpeJob(_p(self.tproj[r]), _p(net.embed_distances.weight), _p(net.embed_distances.bias),
+                                            _p(net.out.weight), _p(net.out.bias), _p(Rb), Cc, tile0))
+                    tile0 += tiles_per
+        if rjobs:
+            jr = nat.jobs_to_device(rjobs, self.dev)
+            self.keep.append(jr)
+            self.add(L.lfvdm_rpe_nets, _p(jr), len(rjobs), tile0, _p(self.fi), B, T)
+
+        # ---- scratch shared by all blocks (forward-only plan)
+        maxC = max(mod.channels for mod in m.modules() if isinstance(mod, FactorizedAttentionBlock))
+        maxCin = max(mod.channels for mod in m.modules() if isinstance(mod, ResBlock))
+        Mmax = N * H * W
+        self.s_qkv = self.buf(Mmax * 3 * maxC)
+        self.s_o = self.buf(Mmax * maxC)
+        self.s_xn = self.buf(Mmax * maxC)
+        self.s_cA, self.s_cB = self.buf(N * max(maxCin, maxC)), self.buf(N * max(maxCin, maxC))
+        self.s_cA2, self.s_cB2 = self.buf(N * max(maxCin, maxC)), self.buf(N * max(maxCin, maxC))
+
+        # ---- network body
+        conv0 = m.input_blocks[0][0]
+        h0 = self.buf(N * H * W, ch)
+        self.add(L.lfvdm_conv_in, _p(self.x_in), _p(self.x0_in), _p(self.obs), _p(conv0.weight), _p(conv0.bias), _p(h0),
+                 N, Cx, H, W, ch)
+        cur = dict(parts=[(h0, ch)], H=H, W=W)
+        hs = [cur]
+        for blk in list(m.input_blocks)[1:]:
+            cur = self._stage(blk, cur)
+            hs.append(cur)
+        cur = self._stage(m.middle_block, cur)
+        for blk in m.output_blocks:
+            skip = hs.pop()
+            assert skip["H"] == cur["H"] and len(cur["parts"]) == 1 and len(skip["parts"]) == 1
+            cur = self._stage(blk, dict(parts=cur["parts"] + skip["parts"], H=cur["H"], W=cur["W"]))
+        # head: GN + SiLU + 3x3 conv straight into the (B,T,C,H,W) layout
+        (hb, hc), = cur["parts"]
+        gn, conv = m.out[0], m.out[2]
+        self.add(L.lfvdm_gn_coef, _p(hb), None, hc, 0, N, H * W, _p(gn.weight), _p(gn.bias), None, 1, 0, gn.eps,
+                 _p(self.s_cA), _p(self.s_cB))
+        self.out = self.buf(B, T, m.out_channels, H, W)
+        self.add_conv(src0=hb, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA, coefB=self.s_cB, act=nat.ACT_SILU,
+                      W=self.packed(conv.weight), bias=conv.bias, Cout=m.out_channels, out=self.out,
+                      ldo=m.out_channels, out_mode=nat.OUT_NCHW)
+
+    def _stage(self, blk, cur):
+        from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
+        for layer in blk:
+            if isinstance(layer, ResBlock):
+                cur = self._res(layer, cur)
+            elif isinstance(layer, FactorizedAttentionBlock):
+                cur = self._attn(layer, cur)
+            elif isinstance(layer, Downsample):
+                cur = self._resample(layer.op, cur, down=True)
+            elif isinstance(layer, Upsample):
+                cur = self._resample(layer.conv, cur, down=False)
+            else:
+                raise NotImplementedError(type(layer))
+        return cur
+
+    def _res(self, rb, cur):
+        L = nat.lib()
+        N, H, W = self.B * self.T, cur["H"], cur["W"]
+        P = H * W
+        parts = cur["parts"]
+        (a, C0) = parts[0]
+        (b, C1) = parts[1] if len(parts) > 1 else (None, 0)
+        Cin, Cout = C0 + C1, rb.out_channels
+        assert Cin == rb.channels
+        if rb.use_conv:
+            raise NotImplementedError("ResBlock(use_conv=True) skip is not used by the reference factory")
+        gn1, conv1 = rb.in_layers[0], rb.in_layers[2]
+        gn2, conv2 = rb.out_layers[0], rb.out_layers[3]
+        pb = _p(b) if b is not None else None
+        self.add(L.lfvdm_gn_coef, _p(a), pb, C0, C1, N, P, _p(gn1.weight), _p(gn1.bias), None, 1, 0, gn1.eps,
+                 _p(self.s_cA), _p(self.s_cB))
+        h1 = self.buf(N * P, Cout)
+        self.add_conv(src0=a, src1=b, C0=C0, C1=C1, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA, coefB=self.s_cB,
+                      act=nat.ACT_SILU, W=self.packed(conv1.weight), bias=conv1.bias, Cout=Cout, out=h1, ldo=Cout)
+        film = self.film[rb]
+        self.add(L.lfvdm_gn_coef, _p(h1), None, Cout, 0, N, P, _p(gn2.weight), _p(gn2.bias), _p(film), self.T, 2 * Cout,
+                 gn2.eps, _p(self.s_cA2), _p(self.s_cB2))
+        out = self.buf(N * P, Cout)
+        kw = dict(src0=h1, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA2, coefB=self.s_cB2, act=nat.ACT_SILU,
+                  W=self.packed(conv2.weight), bias=conv2.bias, Cout=Cout, out=out, ldo=Cout)
+        if isinstance(rb.skip_connection, nn.Identity):
+            assert b is None
+            kw.update(res=a, ldr=Cout)
+        else:
+            sk = rb.skip_connection
+            kw.update(s2src0=a, s2src1=b, s2C0=C0, s2C1=C1, W2=sk.weight, bias2=sk.bias)
+        self.add_conv(**kw)
+        return dict(parts=[(out, Cout)], H=H, W=W)
+
+    def _attn(self, ab, cur):
+        L = nat.lib()
+        B, T = self.B, self.T
+        N, H, W = B * T, cur["H"], cur["W"]
+        P = H * W
+        (x, Cc), = cur["parts"]
+        M = N * P
+        heads = ab.num_heads
+        ta, sa = ab.temporal_attention, ab.spatial_attention
+        # --- temporal: GN over (C/32 x T) per (b, pixel); residual on the normalised tensor (rpe.py:136,172)
+        self.add(L.lfvdm_gn_temporal, _p(x), _p(ta.norm.weight), _p(ta.norm.bias), ta.norm.eps, _p(self.s_xn), B, T, P, Cc)
+        self.add_conv(src0=self.s_xn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.qkv.weight, bias=ta.qkv.bias,
+                      Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
+        at = None
+        if self.want_attn:
+            at = self.buf(B * P, heads, T, T)
+            self.attn_t.append(at)
+        self.add(L.lfvdm_attn_temporal, _p(self.s_qkv), _p(self.R[ta.rpe_q]), _p(self.R[ta.rpe_k]), _p(self.R[ta.rpe_v]),
+                 _p(self.mask), _p(self.s_o), _p(at) if at is not None else None, B, T, P, Cc, heads)
+        yt = self.buf(M, Cc)
+        self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.proj_out.weight,
+                      bias=ta.proj_out.bias, Cout=Cc, res=self.s_xn, ldr=Cc, out=yt, ldo=Cc)
+        # --- spatial: GN over (C/32 x HW) per frame, folded into the qkv GEMM operand and the residual
+        self.add(L.lfvdm_gn_coef, _p(yt), None, Cc, 0, N, P, _p(sa.norm.weight), _p(sa.norm.bias), None, 1, 0, sa.norm.eps,
+                 _p(self.s_cA), _p(self.s_cB))
+        self.add_conv(src0=yt, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=self.s_cA, coefB=self.s_cB,
+                      W=sa.qkv.weight, bias=sa.qkv.bias, Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
+        asp = None
+        if self.want_attn:
+            asp = self.buf(N, heads, P, P)
+            self.attn_s.append(asp)
+        self.add(L.lfvdm_attn_spatial, _p(self.s_qkv), _p(self.s_o), _p(asp) if asp is not None else None, N, P, Cc, heads)
+        ys = self.buf(M, Cc)
+        self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
+                      bias=sa.proj_out.bias, Cout=Cc, res=yt, ldr=Cc, resA=self.s_cA, resB=self.s_cB, out=ys, ldo=Cc)
+        return dict(parts=[(ys, Cc)], H=H, W=W)
+
+    def _resample(self, conv, cur, down):
+        if not isinstance(conv, nn.Conv2d):
+            raise NotImplementedError("conv_resample=False (pooling) is not on the native path")
+        N, H, W = self.B * self.T, cur["H"], cur["W"]
+        (x, Cc), = cur["parts"]
+        Ho, Wo = (((H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1) if down else (2 * H, 2 * W))
+        out = self.buf(N * Ho * Wo, Cc)
+        self.add_conv(src0=x, C0=Cc, N=N, Hs=H, Ws=W, up=0 if down else 1, stride=2 if down else 1, Ho=Ho, Wo=Wo,
+                      W=self.packed(conv.weight), bias=conv.bias, Cout=Cc, out=out, ldo=Cc)
+        return dict(parts=[(out, Cc)], H=Ho, W=Wo)
+
+    # ------------------------------------------------------------------ run
+    def weight_signature(self):
+        return tuple(w._version for w, _ in self.packs)
+
+    def refresh_weights(self):
+        """(Re)pack the OIHW conv weights into the [Cout][tap][Cin] layout the kernels read."""
+        s = nat.stream()
+        L = nat.lib()
+        for w, out in self.packs:
+            nat.check(L.lfvdm_pack_conv_weight(_p(w), _p(out), w.shape[0], w.shape[1], w.shape[2], s), "pack")
+        self._sig = self.weight_signature()
+
+    def launch(self):
+        """Enqueue the whole forward on the current stream (graph-capturable: no sync, no alloc)."""
+        s = nat.stream()
+        for fn, args in self.steps:
+            rc = fn(*args, s)
+            if rc:
+                nat.check(rc, getattr(fn, "__name__", "kernel"))
+
+    def set_inputs(self, x, x0, timesteps, frame_indices, obs_mask, latent_mask):
+        B, T = self.B, self.T
+        if x.data_ptr() != self.x_in.data_ptr():
+            self.x_in.copy_(x)
+        if x0.data_ptr() != self.x0_in.data_ptr():
+            self.x0_in.copy_(x0)
+        ob = obs_mask.reshape(B, T).to(th.float32)
+        self.obs.copy_(ob.reshape(-1))
+        th.clamp(ob + latent_mask.reshape(B, T).to(th.float32), max=1.0, out=self.mask)
+        self.fi.copy_(frame_indices)
+        self.tin[:B].copy_(timesteps)  # int or float timesteps -> float (reference nn.py:119)
+
+
+class Engine:
+    """Per-model cache of plans keyed by input shape."""
+
+    def __init__(self, model):
+        nat.lib()  # fail loudly if the native library is missing
+        self.model = model
+        self.plans = {}
+        for p in model.parameters():
+            if p.dtype != th.float32:
+                raise RuntimeError("the native path is fp32 (use_fp16 is off in the reference defaults)")
+
+    def plan(self, B, T, H, W, want_attn=False):
+        key = (B, T, H, W, bool(want_attn))
+        pl = self.plans.get(key)
+        if pl is None:
+            pl = Plan(self, B, T, H, W, bool(want_attn))
+            pl.refresh_weights()
+            self.plans[key] = pl
+        elif pl._sig != pl.weight_signature():
+            pl.refresh_weights()
+        return pl
+
+    def invalidate(self):
+        for pl in self.plans.values():
+            pl._sig = None
+
+    def forward(self, x, x0, timesteps, frame_indices, obs_mask, latent_mask, return_attn_weights=False):
+        B, T, Cx, H, W = x.shape
+        grad_needed = th.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.model.parameters()))
+        if grad_needed:
+            from ._autograd import unet_apply
+            return unet_apply(self, x, x0, timesteps, frame_indices, obs_mask, latent_mask, return_attn_weights)
+        pl = self.plan(B, T, H, W, return_attn_weights)
+        pl.set_inputs(x.detach(), x0.detach(), timesteps, frame_indices, obs_mask, latent_mask)
+        pl.launch()
+        out = pl.out.clone()
+        attns = None
+        if return_attn_weights:
+            # reference logs |mean over heads| per attention layer (rpe.py:128-131)
+            attns = {"spatial": [a.mean(dim=1).abs() for a in pl.attn_s],
+                     "temporal": [a.mean(dim=1).abs() for a in pl.attn_t], "mixed": []}
+        return out, attns

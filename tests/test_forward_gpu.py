@@ -1,0 +1,79 @@
+"""Full ``UNetVideoModel.forward`` on the MI355X vs the golden vectors of the REAL reference and
+vs the CPU oracle (same seeded inputs, closed-form parameters).  GPU only.
+
+Stated fp32 tolerance for one forward: |d| <= 2e-4 + 1e-3*|ref| (the reference's
+own fp32 CPU result sits 4e-5..1.4e-4 from an fp64 evaluation of the same network).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe, unet_oracle as uo
+from conftest import GOLDEN
+from test_oracle_golden import CONFIGS, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def build_native(cfg, sd):
+    from improved_diffusion.unet import UNetVideoModel
+    m = UNetVideoModel(in_channels=cfg["in_channels"], model_channels=cfg["model_channels"],
+                       out_channels=cfg["out_channels"], num_res_blocks=cfg["num_res_blocks"],
+                       attention_resolutions=cfg["attention_resolutions"], dropout=0.0, channel_mult=cfg["channel_mult"],
+                       num_heads=cfg["num_heads"], use_scale_shift_norm=True, use_rpe_net=True)
+    assert [k for k, _ in m.named_parameters()] == list(sd.keys())
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_forward_vs_reference_golden(name):
+    g = np.load(os.path.join(GOLDEN, f"forward_{name}.npz"))
+    cfg, sd, inp = load_case(name)
+    model = build_native(cfg, sd)
+    d = {k: v.cuda() for k, v in inp.items()}
+    with torch.no_grad():
+        out, attn = model(d["x"], x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"],
+                          obs_mask=d["obs_mask"], latent_mask=d["latent_mask"], return_attn_weights=True)
+        out2, none = model(d["x"], x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"],
+                           obs_mask=d["obs_mask"], latent_mask=d["latent_mask"])
+    assert none is None
+    assert torch.equal(out, out2), "forward must be deterministic run to run"
+    ref = torch.from_numpy(g["out"])
+    err = float((out.cpu() - ref).abs().max())
+    print(f"[{name}] max|hip - reference| = {err:.3e} (max|ref| {float(ref.abs().max()):.3f})")
+    assert torch.allclose(out.cpu(), ref, atol=2e-4, rtol=1e-3), err
+    np.testing.assert_allclose(attn["temporal"][0].cpu().numpy()[:8], g["attn_t0"], atol=1e-4)
+    np.testing.assert_allclose(attn["spatial"][0].cpu().numpy()[:1, :32, :32], g["attn_s0"], atol=1e-4)
+    assert len(attn["temporal"]) == len(attn["spatial"]) and attn["mixed"] == []
+
+
+def test_forward_error_vs_fp64_truth():
+    """The HIP result must be as close to an fp64 evaluation as the fp32 CPU oracle is (x3)."""
+    name = "cfgB"
+    cfg, sd, inp = load_case(name)
+    model = build_native(cfg, sd)
+    d = {k: v.cuda() for k, v in inp.items()}
+    with torch.no_grad():
+        out, _ = model(d["x"], x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"],
+                       obs_mask=d["obs_mask"], latent_mask=d["latent_mask"])
+        sd64 = {k: v.double() for k, v in sd.items()}
+        f64 = lambda t: t.double() if t.is_floating_point() else t
+        t64, _ = uo.unet_forward(sd64, cfg, f64(inp["x"]), f64(inp["x0"]), inp["t"].double(), inp["frame_indices"],
+                                 f64(inp["obs_mask"]), f64(inp["latent_mask"]))
+        o32, _ = uo.unet_forward(sd, cfg, inp["x"], inp["x0"], inp["t"].float(), inp["frame_indices"],
+                                 inp["obs_mask"], inp["latent_mask"])
+    e_hip = float((out.cpu().double() - t64).abs().max())
+    e_cpu = float((o32.double() - t64).abs().max())
+    print(f"error vs fp64: hip {e_hip:.3e}  cpu-oracle-fp32 {e_cpu:.3e}")
+    assert e_hip < 3 * e_cpu + 2e-5
+
+
+def test_cpu_input_is_rejected():
+    cfg, sd, inp = load_case("micro")
+    model = build_native(cfg, sd)
+    with pytest.raises(RuntimeError):
+        model(inp["x"], x0=inp["x0"], timesteps=inp["t"].float(), frame_indices=inp["frame_indices"],
+              obs_mask=inp["obs_mask"], latent_mask=inp["latent_mask"])
