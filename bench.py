@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising steps/sec of the latent-video hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sample|train] [--no-cpu]
+
+Workload (BASELINE.json configs[1]): latent U-Net num_channels=64, num_res_blocks=1, max_frames=20,
+batch 2, 1000-step DDPM ancestral sampling (p_sample loop) on synthetic 4x16x16 latents.  A "step" is one
+denoising step of the whole batch: timestep remap + U-Net forward + noise draw + x_{t-1} update, i.e. one
+iteration of reference gaussian_diffusion.py:509-522.  Inputs/state are resident in HBM; the step is one
+hipGraph replay.  N > 1 (launched with torch.distributed.run, one rank per GPU): sampling does not
+communicate (the reference parallelises sampling over videos, video_sample.py:192-200), so every rank
+samples its own videos — weak scaling, value = N*K / max-over-ranks time.
+
+One JSON line on stdout (rank 0) with `roofline` (dominant kernel = the implicit-GEMM conv, live
+HIP-event timing) and `cpu_baseline` (the CPU oracle restatement of the same step, bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch as th  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def make_model_and_diffusion(num_channels, device, steps=1000, respacing=""):
+    from improved_diffusion import script_util as su
+    kw = su.model_and_diffusion_defaults()
+    kw.update(image_size=16, in_channels=4, num_channels=num_channels, num_res_blocks=1, num_heads=4,
+              attention_resolutions="16,8", diffusion_steps=steps, timestep_respacing=respacing,
+              diffusion_space_kwargs={"diffusion_space": "pixel", "pre_encoded": False, "pre_encoded_stats_dict": None})
+    model, diffusion = su.create_model_and_diffusion(**kw)
+    # random-init EVERY parameter (the reference zero-initialises some layers, which would make the
+    # network output exact zeros and let the chip clock up on zero operands)
+    g = th.Generator().manual_seed(7)
+    with th.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 1:
+                p.copy_((1.0 if name.endswith("weight") else 0.0) + 0.1 * th.randn(p.shape, generator=g))
+            else:
+                fan_in = p[0].numel()
+                p.copy_(th.randn(p.shape, generator=g) / math.sqrt(fan_in))
+    return model.to(device).eval(), diffusion
+
+
+def synthetic_inputs(B, T, rank, device):
+    g = th.Generator().manual_seed(1234 + rank)
+    x0 = th.randn(B, T, 4, 16, 16, generator=g)
+    fi = th.stack([th.arange(T) if b % 2 == 0 else th.sort(th.randperm(1000, generator=g)[:T])[0] for b in range(B)])
+    obs = th.zeros(B, T, 1, 1, 1)
+    obs[:, :T // 3] = 1.0
+    kw = dict(x0=x0, frame_indices=fi, obs_mask=obs, latent_mask=1.0 - obs)
+    return {k: v.to(device) for k, v in kw.items()}
+
+
+def conv_flops(a):
+    M = a.N * a.Ho * a.Wo
+    K = a.ksize * a.ksize * (a.C0 + a.C1) + a.s2C0 + a.s2C1
+    return 2.0 * M * a.Cout * K
+
+
+def kernel_breakdown(plan, reps=20):
+    """Per-launch HIP-event timing of every step of the forward plan (eager, same stream)."""
+    import ctypes as C
+    from improved_diffusion import _native as nat
+    L = nat.lib()
+    s = nat.stream()
+    n = len(plan.steps)
+    tot = [0.0] * n
+    ev = [(th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for rep in range(reps + 2):
+        for i, (fn, args) in enumerate(plan.steps):
+            ev[i][0].record()
+            fn(*args, s)
+            ev[i][1].record()
+        th.cuda.synchronize()
+        if rep >= 2:
+            for i in range(n):
+                tot[i] += ev[i][0].elapsed_time(ev[i][1])
+    groups = {}
+    for i, (fn, args) in enumerate(plan.steps):
+        name = fn.__name__
+        flops = 0.0
+        if name == "lfvdm_conv_igemm":
+            a = args[0]._obj
+            nt, nw = C.c_int(), C.c_int()
+            L.lfvdm_conv_igemm_config(C.byref(a), C.byref(nt), C.byref(nw))
+            name = f"conv_igemm_kernel<{nt.value},{nw.value}>"
+            flops = conv_flops(a)
+        gsum = groups.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+        gsum["launches"] += 1
+        gsum["ms"] += tot[i] / reps
+        gsum["flops"] += flops
+    return groups
+
+
+def cpu_baseline_sample(model, diffusion, inputs, B, T, budget_s=12.0):
+    """CPU oracle restatement of the same denoising step (kind 'port'), all host cores."""
+    from oracle import unet_oracle as uo, diffusion_oracle as do
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the GPU box grants 16 host cores per GPU
+    th.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = uo.make_cfg(model_channels=model.model_channels, channel_mult=model.channel_mult,
+                      attention_resolutions=model.attention_resolutions, num_heads=model.num_heads)
+    tab = do.Tables(do.linear_betas(1000))
+    ci = {k: v.cpu() for k, v in inputs.items()}
+    x = th.randn(B, T, 4, 16, 16)
+    n, t0 = 0, None
+    with th.no_grad():
+        for i in range(999, -1, -1):
+            if n == 2:
+                t0 = time.perf_counter()
+            t = th.full((B,), i, dtype=th.long)
+            eps, _ = uo.unet_forward(sd, cfg, x, ci["x0"], do.model_timesteps(tab, t), ci["frame_indices"],
+                                     ci["obs_mask"], ci["latent_mask"])
+            x, _ = do.p_sample(tab, eps, x, t, th.randn_like(x))
+            n += 1
+            if t0 is not None and time.perf_counter() - t0 > budget_s:
+                break
+    el = time.perf_counter() - t0
+    return dict(value=round((n - 2) / el, 3), unit="steps/s", cores=cores, kind="port",
+                sample=f"{n - 2} p_sample steps of the same workload (oracle/unet_oracle.py + diffusion_oracle.py, torch CPU fp32)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=900)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not th.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    th.cuda.set_device(local)
+    dev = th.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, T = 2, 20
+    model, diffusion = make_model_and_diffusion(64, dev)
+    inputs = synthetic_inputs(B, T, rank, dev)
+    shape = (B, T, 4, 16, 16)
+
+    sampler = diffusion._graph_sampler(model, shape, True)
+    th.manual_seed(1234 + rank)
+    sampler.begin(th.randn(*shape, device=dev), inputs)
+    i = diffusion.num_timesteps - 1
+    for _ in range(args.warmup):
+        sampler.step(i)
+        i = max(i - 1, 0)
+    th.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sampler.step(i)
+        i = max(i - 1, 0)
+    th.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    th.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = th.tensor([el], device=dev, dtype=th.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    finite = bool(th.isfinite(sampler.plan.x_in).all().item())
+
+    out = {
+        "metric": "denoising steps/sec (train+sample) on 20-frame 4x16x16 latents", "value": round(world * args.steps / el, 2),
+        "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * el / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "sample: p_sample loop, latent U-Net num_channels=64 num_res_blocks=1 max_frames=20 "
+                               "batch=2 1000-step DDPM on synthetic 4x16x16 latents (BASELINE.json configs[1])",
+                   "batch": B, "frames": T, "latent": "4x16x16", "parallelism": f"replicas x{world} (no collective)",
+                   "frames_steps_per_s": round(world * args.steps * B * T / el, 1), "finite": finite},
+    }
+    if rank == 0:
+        if not args.no_breakdown:
+            groups = kernel_breakdown(sampler.plan)
+            tot_ms = sum(g["ms"] for g in groups.values())
+            convs = {k: g for k, g in groups.items() if k.startswith("conv_igemm")}
+            dom_name, dom = max(convs.items(), key=lambda kv: kv[1]["ms"])
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel": dom_name,
+                               "launches_per_step": dom["launches"],
+                               "avg_launch_us": round(1000.0 * dom["ms"] / dom["launches"], 2),
+                               "note": "fp32 MFMA; achieved = algorithmic conv/GEMM FLOPs of these launches / their HIP-event time"}
+            all_conv_flops = sum(g["flops"] for g in convs.values())
+            all_conv_ms = sum(g["ms"] for g in convs.values())
+            out["breakdown"] = {"eager_sum_ms": round(tot_ms, 4), "launches": len(sampler.plan.steps),
+                                "all_conv_gemm_tflops": round(all_conv_flops / (all_conv_ms * 1e-3) / 1e12, 2),
+                                "step_flops_g": round(all_conv_flops / 1e9, 2),
+                                "whole_step_frac_of_mfma_peak": round(all_conv_flops * out["value"] / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                "kernels": {k: {"n": g["launches"], "us": round(1000 * g["ms"], 1)} for k, g in
+                                            sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}}
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline_sample(model, diffusion, inputs, B, T)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

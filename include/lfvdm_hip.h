@@ -88,6 +88,9 @@ typedef struct lfvdm_conv_args {
 } lfvdm_conv_args;
 
 int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream);
+/* template instance (NT = 32-column tiles per wave, nwaves = K-split waves per workgroup) that
+ * lfvdm_conv_igemm picks for these arguments; profiling aid, launches nothing. */
+int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* nwaves);
 
 /* OIHW [Cout][Cin][k][k] -> [Cout][k*k][Cin] (k in {1,3}); state-dict layout stays OIHW. */
 int lfvdm_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int ksize, void* stream);

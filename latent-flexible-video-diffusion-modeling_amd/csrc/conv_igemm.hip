@@ -24,17 +24,27 @@ struct RowInfo {
     bool valid;
 };
 
+// Raw operands of one K chunk as they come back from memory.  Loads are issued unconditionally
+// (out-of-image taps and rows past M read a clamped, valid address and are masked afterwards), so
+// no s_waitcnt sits between them: the whole chunk is in flight while the previous chunk's MFMAs run.
 template <int NT>
 struct ChunkRegs {
     f32x4 a[4];
+    f32x4 ca[4], cb[4];
     f32x4 w[4 * NT];
+    unsigned amask;   // bit r: row r of this lane is inside the image
+    unsigned wmask;   // bit r: filter row r exists (co < Cout)
+    bool main_seg;
 };
 
 template <int NT>
-__device__ __forceinline__ void load_chunk(const lfvdm_conv_args& p, int kc, int NK1, int cpt, int Cin, int n0,
-                                           const RowInfo (&ri)[4], int m0, int lane, ChunkRegs<NT>& R) {
+__device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, int NK1, int cpt, int Cin, int n0,
+                                            const RowInfo (&ri)[4], int m0, int M, int lane, ChunkRegs<NT>& R) {
     const int col = (lane & 7) * 4;
     const int rsub = lane >> 3;
+    R.amask = 0;
+    R.wmask = 0;
+    R.main_seg = kc < NK1;
     if (kc < NK1) {
         const int tap = kc / cpt;
         const int cc = (kc - tap * cpt) * KC;
@@ -58,29 +68,22 @@ __device__ __forceinline__ void load_chunk(const lfvdm_conv_args& p, int kc, int
             const int iy = q.oy * p.stride + dy;
             const int ix = q.ox * p.stride + dx;
             const bool inb = q.valid && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (inb) {
-                const int sy = p.up ? (iy >> 1) : iy;
-                const int sx = p.up ? (ix >> 1) : ix;
-                v = ld4(src + ((size_t)(q.n * p.Hs + sy) * p.Ws + sx) * Csrc + cl + col);
-                if (p.coefA) {
-                    const f32x4 ca = ld4(p.coefA + (size_t)q.n * Cin + cc + col);
-                    const f32x4 cb = ld4(p.coefB + (size_t)q.n * Cin + cc + col);
-                    v = v * ca + cb;
-                }
-                if (p.act == LFVDM_ACT_SILU) {
-                    v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
-                }
+            R.amask |= (inb ? 1u : 0u) << r;
+            const int cy = min(max(iy, 0), Hin - 1), cx = min(max(ix, 0), Win - 1);
+            const int sy = p.up ? (cy >> 1) : cy;
+            const int sx = p.up ? (cx >> 1) : cx;
+            R.a[r] = ld4(src + ((size_t)(q.n * p.Hs + sy) * p.Ws + sx) * Csrc + cl + col);
+            if (p.coefA) {
+                R.ca[r] = ld4(p.coefA + (size_t)q.n * Cin + cc + col);
+                R.cb[r] = ld4(p.coefB + (size_t)q.n * Cin + cc + col);
             }
-            R.a[r] = v;
         }
         const int Ktot = NK1 * KC;
 #pragma unroll
         for (int r = 0; r < 4 * NT; ++r) {
             const int co = n0 + r * 8 + rsub;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (co < p.Cout) v = ld4(p.W + (size_t)co * Ktot + kc * KC + col);
-            R.w[r] = v;
+            R.wmask |= (co < p.Cout ? 1u : 0u) << r;
+            R.w[r] = ld4(p.W + (size_t)min(co, p.Cout - 1) * Ktot + kc * KC + col);
         }
     } else {
         const int cc = (kc - NK1) * KC;
@@ -94,18 +97,36 @@ __device__ __forceinline__ void load_chunk(const lfvdm_conv_args& p, int kc, int
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ri[r].valid) v = ld4(src + (size_t)(m0 + r * 8 + rsub) * Csrc + cl + col);
-            R.a[r] = v;
+            R.amask |= (ri[r].valid ? 1u : 0u) << r;
+            R.a[r] = ld4(src + (size_t)min(m0 + r * 8 + rsub, M - 1) * Csrc + cl + col);
         }
 #pragma unroll
         for (int r = 0; r < 4 * NT; ++r) {
             const int co = n0 + r * 8 + rsub;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (co < p.Cout) v = ld4(p.W2 + (size_t)co * C2 + cc + col);
-            R.w[r] = v;
+            R.wmask |= (co < p.Cout ? 1u : 0u) << r;
+            R.w[r] = ld4(p.W2 + (size_t)min(co, p.Cout - 1) * C2 + cc + col);
         }
     }
+}
+
+// affine + activation + masking in registers, then the wave-private LDS stores
+template <int NT>
+__device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs<NT>& R, float* As, float* Ws, int st_off) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        f32x4 v = R.a[r];
+        if (R.main_seg) {
+            if (p.coefA) v = v * R.ca[r] + R.cb[r];
+            if (p.act == LFVDM_ACT_SILU) {
+                v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
+            }
+        }
+        v = ((R.amask >> r) & 1u) ? v : zero;
+        st4(As + r * 8 * LDR + st_off, v);
+    }
+#pragma unroll
+    for (int r = 0; r < 4 * NT; ++r) st4(Ws + r * 8 * LDR + st_off, ((R.wmask >> r) & 1u) ? R.w[r] : zero);
 }
 
 template <int NT, int NWAVES>
@@ -152,18 +173,15 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const lfvdm_con
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     ChunkRegs<NT> R;
-    if (kbeg < kend) load_chunk<NT>(p, kbeg, NK1, cpt, Cin, n0, ri, m0, lane, R);
+    if (kbeg < kend) issue_chunk<NT>(p, kbeg, NK1, cpt, Cin, n0, ri, m0, M, lane, R);
 
     const int st_off = (lane >> 3) * LDR + (lane & 7) * 4;          // staging store offset
     const int fr_off = (lane & 31) * LDR + (lane >> 5) * 4;         // fragment read offset
 
     for (int kc = kbeg; kc < kend; ++kc) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st4(As + r * 8 * LDR + st_off, R.a[r]);
-#pragma unroll
-        for (int r = 0; r < 4 * NT; ++r) st4(Ws + r * 8 * LDR + st_off, R.w[r]);
+        finish_chunk<NT>(p, R, As, Ws, st_off);
         wave_lds_fence();
-        if (kc + 1 < kend) load_chunk<NT>(p, kc + 1, NK1, cpt, Cin, n0, ri, m0, lane, R);
+        if (kc + 1 < kend) issue_chunk<NT>(p, kc + 1, NK1, cpt, Cin, n0, ri, m0, M, lane, R);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 a4 = ld4(As + fr_off + g * 8);
@@ -240,6 +258,28 @@ int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, int mt, int ntiles) {
     return LFVDM_OK;
 }
 
+// (NT, NWAVES) by a small makespan model: 256 CUs, 4 SIMDs, 64 cycles per 32x32x2 MFMA.
+void pick_cfg(int Cout, int mt, int NK, int* oNT, int* oNW) {
+    int bestNT = 1, bestNW = 1;
+    double best = 1e30;
+    for (int NT = 1; NT <= 2; ++NT) {
+        if (NT == 2 && Cout < 64) continue;
+        const int ntiles = (Cout + 32 * NT - 1) / (32 * NT);
+        for (int NW = 1; NW <= 16; NW *= 2) {
+            if (NW > NK) continue;
+            if (NW == 16 && NT == 2) continue;  // LDS budget
+            const double chunk = 16.0 * NT * 64.0 + 350.0;
+            const double per_wave = (double)((NK + NW - 1) / NW) * chunk;
+            const long wgs = (long)mt * ntiles;
+            const double waves_per_simd = (double)((wgs + 255) / 256) * ((NW + 3) / 4);
+            const double est = waves_per_simd * per_wave + 600.0 + 40.0 * NW + (NT == 1 ? 0.0 : -1.0);
+            if (est < best) { best = est; bestNT = NT; bestNW = NW; }
+        }
+    }
+    *oNT = bestNT;
+    *oNW = bestNW;
+}
+
 }  // namespace
 
 extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
@@ -263,23 +303,8 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     const int mt = (int)((M + 31) / 32);
     const int NK = a->ksize * a->ksize * (Cin / 32) + C2 / 32;
 
-    // pick (NT, NWAVES) by a small makespan model: 256 CUs, 4 SIMDs, 64 cycles per 32x32x2 MFMA
     int bestNT = 1, bestNW = 1;
-    double best = 1e30;
-    for (int NT = 1; NT <= 2; ++NT) {
-        if (NT == 2 && a->Cout < 64) continue;
-        const int ntiles = (a->Cout + 32 * NT - 1) / (32 * NT);
-        for (int NW = 1; NW <= 16; NW *= 2) {
-            if (NW > NK) continue;
-            if (NW == 16 && NT == 2) continue;  // LDS budget
-            const double chunk = 16.0 * NT * 64.0 + 350.0;
-            const double per_wave = (double)((NK + NW - 1) / NW) * chunk;
-            const long wgs = (long)mt * ntiles;
-            const double waves_per_simd = (double)((wgs + 255) / 256) * ((NW + 3) / 4);
-            const double est = waves_per_simd * per_wave + 600.0 + 40.0 * NW + (NT == 1 ? 0.0 : -1.0);
-            if (est < best) { best = est; bestNT = NT; bestNW = NW; }
-        }
-    }
+    pick_cfg(a->Cout, mt, NK, &bestNT, &bestNW);
     const int ntiles = (a->Cout + 32 * bestNT - 1) / (32 * bestNT);
 #define LFVDM_CASE(NT_, NW_) if (bestNT == NT_ && bestNW == NW_) return launch_cfg<NT_, NW_>(a, s, mt, ntiles)
     LFVDM_CASE(1, 1); LFVDM_CASE(1, 2); LFVDM_CASE(1, 4); LFVDM_CASE(1, 8); LFVDM_CASE(1, 16);
@@ -294,6 +319,16 @@ extern "C" int lfvdm_pack_conv_weight(const float* w, float* o, int Cout, int Ci
     const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, o, Cout, Cin, ksize * ksize);
     LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+// Which template instance lfvdm_conv_igemm would launch for these arguments (profiling aid: lets
+// bench.py attribute per-launch HIP-event timings to the kernel symbol rocprofv3 reports).
+extern "C" int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* nwaves) {
+    const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
+    if (Cin <= 0 || Cin % 32 || C2 % 32) return LFVDM_E_SHAPE;
+    const long M = (long)a->N * a->Ho * a->Wo;
+    pick_cfg(a->Cout, (int)((M + 31) / 32), a->ksize * a->ksize * (Cin / 32) + C2 / 32, nt, nwaves);
     return LFVDM_OK;
 }
 

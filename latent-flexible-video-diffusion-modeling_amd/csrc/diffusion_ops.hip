@@ -19,12 +19,13 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void p_sample_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+// x and sample may alias (the sampler updates its state in place): no __restrict__ on them.
+__global__ __launch_bounds__(256) void p_sample_kernel(const float* x, const float* __restrict__ eps,
                                                        const float* __restrict__ noise, const int64_t* __restrict__ t,
                                                        const float* __restrict__ t_recip, const float* __restrict__ t_recipm1,
                                                        const float* __restrict__ t_c1, const float* __restrict__ t_c2,
                                                        const float* __restrict__ t_logvar, int clip,
-                                                       float* __restrict__ sample, float* __restrict__ pred,
+                                                       float* sample, float* __restrict__ pred,
                                                        float* __restrict__ mean_out, int inner) {
     const int b = blockIdx.y;
     const int64_t tb = t[b];

@@ -48,6 +48,7 @@ class RpeJob(C.Structure):
 _SIGS = {
     "lfvdm_abi_version": ([], c_i),
     "lfvdm_conv_igemm": ([C.POINTER(ConvArgs), c_fp], c_i),
+    "lfvdm_conv_igemm_config": ([C.POINTER(ConvArgs), C.POINTER(c_i), C.POINTER(c_i)], c_i),
     "lfvdm_pack_conv_weight": ([c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_conv_in": ([c_fp] * 6 + [c_i] * 5 + [c_fp], c_i),
     "lfvdm_gn_coef": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp], c_i),
