@@ -95,7 +95,8 @@ def kernel_breakdown(plan, reps=20):
             a = args[0]._obj
             nt, nw = C.c_int(), C.c_int()
             L.lfvdm_conv_igemm_config(C.byref(a), C.byref(nt), C.byref(nw))
-            name = f"conv_igemm_kernel<{nt.value},{nw.value}>"
+            v = nt.value
+            name = f"conv_igemm_kernel<{v // 1000},{v // 100 % 10},{v // 10 % 10},{v % 10}>"
             flops = conv_flops(a)
         gsum = groups.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
         gsum["launches"] += 1

@@ -1,17 +1,22 @@
 // Implicit-GEMM convolution / linear for gfx950 on fp32 MFMA (v_mfma_f32_32x32x2_f32).
 //
-// One workgroup = one 32(M) x 32*NT(N) output tile; its NWAVES waves split the K dimension
-// (K = taps*Cin in 32-channel chunks, plus the optional fused 1x1 skip segment) and are summed
-// through LDS at the end.  Each wave stages its own A chunk (32 output pixels x 32 channels of
-// one filter tap, gathered from the channels-last activation with the GroupNorm/FiLM affine and
-// SiLU applied on the fly, zero outside the image) and W chunk (32*NT filters x 32 k) in a
-// wave-private LDS region, so the main loop has no s_barrier; the next chunk's global loads are
-// issued before the current chunk's 16*NT MFMAs.  LDS rows are padded to 36 floats so that the
-// ds_read_b128 fragment reads (lane (i, h) reads k = 8g+4h..+3 of row i) are conflict-free.
+// Workgroup = WK "k-groups" of WM x WN waves.  A k-group owns a contiguous slice of the K loop
+// (K = taps*Cin in 32-channel chunks, plus the optional fused 1x1 skip segment) and computes the
+// whole (32*WM) x (32*NT*WN) block tile for that slice; the k-groups' partial tiles are summed
+// through LDS at the end.  Inside a k-group the A tile (output pixels x 32 channels of one filter
+// tap, gathered from the channels-last activation, GroupNorm/FiLM affine + SiLU applied on the
+// fly, zero outside the image) and the W tile are staged COOPERATIVELY by the group's threads
+// into a double-buffered LDS stage, so every operand byte fetched from L2 feeds WN (A) or WM (W)
+// waves.  Loads of chunk k+1 are issued (unconditionally, clamped + masked) before the MFMAs of
+// chunk k; one s_barrier per chunk.  The K loop runs channel-chunk-major / tap-minor so the
+// per-(sample,channel) GroupNorm coefficients are fetched once per channel chunk, not per tap.
+// LDS rows are padded to 36 floats: the ds_read_b128 fragment reads are conflict-free.
 //
 // MFMA operand mapping (cdna guide §3): A lane l holds A[i=l&31][k=l>>5], B lane l holds
 // B[k=l>>5][j=l&31]; within a group of 8 k the e-th MFMA uses k = 8g + 4h + e on both operands.
 // D: lane l holds column j=l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r=0..15.
+#include <stdlib.h>
+
 #include "common.cuh"
 
 namespace {
@@ -19,152 +24,187 @@ namespace {
 constexpr int KC = 32;    // channels per chunk
 constexpr int LDR = 36;   // padded LDS row (floats)
 
+template <int WM, int WN, int WK, int NT>
+struct Cfg {
+    static constexpr int BM = 32 * WM;
+    static constexpr int BN = 32 * NT * WN;
+    static constexpr int GT = 64 * WM * WN;              // threads per k-group
+    static constexpr int NTHREADS = GT * WK;
+    static constexpr int AE = (BM * 8) / GT;             // float4 A elements per thread per chunk
+    static constexpr int WE = (BN * 8) / GT;             // float4 W elements per thread per chunk
+    static constexpr int STAGE = (BM + BN) * LDR;        // floats per LDS stage
+    static constexpr int GROUP_LDS = 2 * STAGE;          // double buffered
+    static constexpr size_t LDS_BYTES = (size_t)WK * GROUP_LDS * sizeof(float);
+    static_assert((BM * 8) % GT == 0 && (BN * 8) % GT == 0, "tile must divide over the group");
+};
+
+template <class T>
+__device__ __forceinline__ T sel(bool c, T a, T b) {
+    return c ? a : b;
+}
+
 struct RowInfo {
     int n, oy, ox;
     bool valid;
 };
 
-// Raw operands of one K chunk as they come back from memory.  Loads are issued unconditionally
-// (out-of-image taps and rows past M read a clamped, valid address and are masked afterwards), so
-// no s_waitcnt sits between them: the whole chunk is in flight while the previous chunk's MFMAs run.
-template <int NT>
+template <int AE, int WE>
 struct ChunkRegs {
-    f32x4 a[4];
-    f32x4 ca[4], cb[4];
-    f32x4 w[4 * NT];
-    unsigned amask;   // bit r: row r of this lane is inside the image
-    unsigned wmask;   // bit r: filter row r exists (co < Cout)
+    f32x4 a[AE];
+    f32x4 w[WE];
+    f32x4 ca[AE], cb[AE];   // GroupNorm/FiLM coefficients: loaded WITH the first chunk of a channel chunk so
+                            // that they sit in front of younger prefetches in the in-order vmcnt queue
+    unsigned amask;
+    int coef_cc;            // >= 0: first chunk of a channel chunk -> (re)load the GroupNorm/FiLM coefficients
     bool main_seg;
 };
 
-template <int NT>
-__device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, int NK1, int cpt, int Cin, int n0,
-                                            const RowInfo (&ri)[4], int m0, int M, int lane, ChunkRegs<NT>& R) {
-    const int col = (lane & 7) * 4;
-    const int rsub = lane >> 3;
-    R.amask = 0;
-    R.wmask = 0;
-    R.main_seg = kc < NK1;
-    if (kc < NK1) {
-        const int tap = kc / cpt;
-        const int cc = (kc - tap * cpt) * KC;
-        int dy = 0, dx = 0;
-        if (p.ksize == 3) {
-            dy = tap / 3 - 1;
-            dx = tap - (tap / 3) * 3 - 1;
-        }
-        const float* src;
-        int Csrc, cl;
-        if (cc < p.C0) {
-            src = p.src0; Csrc = p.C0; cl = cc;
-        } else {
-            src = p.src1; Csrc = p.C1; cl = cc - p.C0;
-        }
-        const int Hin = p.up ? 2 * p.Hs : p.Hs;
-        const int Win = p.up ? 2 * p.Ws : p.Ws;
+// Issue the global loads of K chunk `kc` (branch-free: every address is clamped to a valid one and
+// the parts that must not contribute are masked when the chunk is written to LDS).  `live` is false
+// for the padding iterations of k-groups that own fewer chunks than the others.  All per-lane
+// address arithmetic is 32-bit (element offsets < 2^31 is checked by the launcher); the chunk
+// parameters are wave-uniform and live in SGPRs.
+template <class CF>
+__device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bool live, int kfirst, int NK1, int taps,
+                                            int Cin, const RowInfo (&ri)[CF::AE], const int (&wrow)[CF::WE], int col,
+                                            ChunkRegs<CF::AE, CF::WE>& R) {
+    const bool main_seg = kc < NK1;
+    // ---- wave-uniform chunk parameters (scalar selects, no divergent code) ----
+    // (sel() takes its operands by value: a plain `c ? p.a : p.b` is an lvalue select, i.e. a load from
+    // a selected ADDRESS, which pins the whole argument struct in scratch memory)
+    const int kk = main_seg ? kc : kc - NK1;
+    const int ci = main_seg ? kk / taps : kk;
+    const int tap = main_seg ? kk - ci * taps : 0;
+    const int cc = ci * KC;
+    const int dy = (main_seg && p.ksize == 3) ? tap / 3 - 1 : 0;
+    const int dx = (main_seg && p.ksize == 3) ? tap - (tap / 3) * 3 - 1 : 0;
+    const int c0 = sel(main_seg, p.C0, p.s2C0);
+    const bool second = cc >= c0;
+    const float* src = sel(main_seg, sel(second, p.src1, p.src0), sel(second, p.s2src1, p.s2src0));
+    const int Csrc = sel(main_seg, sel(second, p.C1, p.C0), sel(second, p.s2C1, p.s2C0));
+    const int cl = second ? cc - c0 : cc;
+    const int up = sel(main_seg, p.up, 0);
+    const int stride = sel(main_seg, p.stride, 1);
+    const int Hst = sel(main_seg, p.Hs, p.Ho);      // stored source extent
+    const int Wst = sel(main_seg, p.Ws, p.Wo);
+    const int Hin = Hst << up;
+    const int Win = Wst << up;
+    const float* wbase = sel(main_seg, p.W + (size_t)tap * Cin + cc, p.W2 + cc);
+    const int wld = sel(main_seg, taps * Cin, p.s2C0 + p.s2C1);
+
+    R.main_seg = main_seg;
+    R.coef_cc = (p.coefA && main_seg && live && (tap == 0 || kc == kfirst)) ? cc : -1;
+    if (R.coef_cc >= 0) {   // wave-uniform
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const RowInfo& q = ri[r];
-            const int iy = q.oy * p.stride + dy;
-            const int ix = q.ox * p.stride + dx;
-            const bool inb = q.valid && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
-            R.amask |= (inb ? 1u : 0u) << r;
-            const int cy = min(max(iy, 0), Hin - 1), cx = min(max(ix, 0), Win - 1);
-            const int sy = p.up ? (cy >> 1) : cy;
-            const int sx = p.up ? (cx >> 1) : cx;
-            R.a[r] = ld4(src + ((size_t)(q.n * p.Hs + sy) * p.Ws + sx) * Csrc + cl + col);
-            if (p.coefA) {
-                R.ca[r] = ld4(p.coefA + (size_t)q.n * Cin + cc + col);
-                R.cb[r] = ld4(p.coefB + (size_t)q.n * Cin + cc + col);
-            }
-        }
-        const int Ktot = NK1 * KC;
-#pragma unroll
-        for (int r = 0; r < 4 * NT; ++r) {
-            const int co = n0 + r * 8 + rsub;
-            R.wmask |= (co < p.Cout ? 1u : 0u) << r;
-            R.w[r] = ld4(p.W + (size_t)min(co, p.Cout - 1) * Ktot + kc * KC + col);
-        }
-    } else {
-        const int cc = (kc - NK1) * KC;
-        const int C2 = p.s2C0 + p.s2C1;
-        const float* src;
-        int Csrc, cl;
-        if (cc < p.s2C0) {
-            src = p.s2src0; Csrc = p.s2C0; cl = cc;
-        } else {
-            src = p.s2src1; Csrc = p.s2C1; cl = cc - p.s2C0;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            R.amask |= (ri[r].valid ? 1u : 0u) << r;
-            R.a[r] = ld4(src + (size_t)min(m0 + r * 8 + rsub, M - 1) * Csrc + cl + col);
-        }
-#pragma unroll
-        for (int r = 0; r < 4 * NT; ++r) {
-            const int co = n0 + r * 8 + rsub;
-            R.wmask |= (co < p.Cout ? 1u : 0u) << r;
-            R.w[r] = ld4(p.W2 + (size_t)min(co, p.Cout - 1) * C2 + cc + col);
+        for (int j = 0; j < CF::AE; ++j) {
+            R.ca[j] = ld4(p.coefA + (unsigned)(ri[j].n * Cin + cc + col));
+            R.cb[j] = ld4(p.coefB + (unsigned)(ri[j].n * Cin + cc + col));
         }
     }
+    unsigned am = 0;
+    const float* srcc = src + cl;
+#pragma unroll
+    for (int j = 0; j < CF::AE; ++j) {
+        const RowInfo& q = ri[j];
+        const int iy = q.oy * stride + dy;
+        const int ix = q.ox * stride + dx;
+        const bool inb = live && q.valid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        am |= (inb ? 1u : 0u) << j;
+        const int sy = min(max(iy, 0), Hin - 1) >> up;
+        const int sx = min(max(ix, 0), Win - 1) >> up;
+        const unsigned off = (unsigned)(((q.n * Hst + sy) * Wst + sx) * Csrc + col);
+        R.a[j] = ld4(srcc + off);
+    }
+    R.amask = am;
+#pragma unroll
+    for (int j = 0; j < CF::WE; ++j) R.w[j] = ld4(wbase + (unsigned)(wrow[j] * wld + col));
 }
 
-// affine + activation + masking in registers, then the wave-private LDS stores
-template <int NT>
-__device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs<NT>& R, float* As, float* Ws, int st_off) {
+// PRO: 0 = raw operand, 1 = affine (GroupNorm coefficients), 2 = affine + SiLU
+template <class CF, int PRO>
+__device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs<CF::AE, CF::WE>& R,
+                                             f32x4 (&ca)[CF::AE], f32x4 (&cb)[CF::AE], unsigned wmask, float* As,
+                                             float* Ws, int gt) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int col = (gt & 7) * 4;
+    if (PRO > 0 && R.coef_cc >= 0) {   // once per channel chunk (the 9 taps share it)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        f32x4 v = R.a[r];
-        if (R.main_seg) {
-            if (p.coefA) v = v * R.ca[r] + R.cb[r];
-            if (p.act == LFVDM_ACT_SILU) {
-                v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
-            }
-        }
-        v = ((R.amask >> r) & 1u) ? v : zero;
-        st4(As + r * 8 * LDR + st_off, v);
+        for (int j = 0; j < CF::AE; ++j) { ca[j] = R.ca[j]; cb[j] = R.cb[j]; }
     }
 #pragma unroll
-    for (int r = 0; r < 4 * NT; ++r) st4(Ws + r * 8 * LDR + st_off, ((R.wmask >> r) & 1u) ? R.w[r] : zero);
+    for (int j = 0; j < CF::WE; ++j)
+        st4(Ws + ((gt + j * CF::GT) >> 3) * LDR + col, ((wmask >> j) & 1u) ? R.w[j] : zero);
+#pragma unroll
+    for (int j = 0; j < CF::AE; ++j) {
+        f32x4 v = R.a[j];
+        if (PRO > 0) {
+            const f32x4 t = v * ca[j] + cb[j];
+            v = R.main_seg ? t : v;
+        }
+        if (PRO > 1) {
+            f32x4 t;
+            t.x = silu_f(v.x); t.y = silu_f(v.y); t.z = silu_f(v.z); t.w = silu_f(v.w);
+            v = R.main_seg ? t : v;
+        }
+        v = ((R.amask >> j) & 1u) ? v : zero;
+        st4(As + ((gt + j * CF::GT) >> 3) * LDR + col, v);
+    }
 }
 
-template <int NT, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const lfvdm_conv_args p) {
-    constexpr int BN = 32 * NT;
-    constexpr int WAVE_LDS = (32 + BN) * LDR;  // floats per wave
+template <int WM, int WN, int WK, int NT, int PRO>
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfvdm_conv_args p_in) {
+    const lfvdm_conv_args p = p_in;   // private SSA copy: helpers take it by reference (keeps it out of scratch)
+    using CF = Cfg<WM, WN, WK, NT>;
+    constexpr int BM = CF::BM, BN = CF::BN;
     constexpr int RED_LD = BN + 1;
+    static_assert(BM * RED_LD <= CF::GROUP_LDS, "reduction tile must fit the group's stages");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wk = wave / (WM * WN);
+    const int wmn = wave - wk * (WM * WN);
+    const int wm = wmn / WN, wn = wmn - wm * WN;
+    const int gt = tid - wk * CF::GT;
+    const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int HoWo = p.Ho * p.Wo;
     const int M = p.N * HoWo;
     const int Cin = p.C0 + p.C1;
-    const int cpt = Cin / KC;
-    const int NK1 = p.ksize * p.ksize * cpt;
+    const int taps = p.ksize * p.ksize;
+    const int NK1 = taps * (Cin / KC);
     const int NK = NK1 + (p.s2C0 + p.s2C1) / KC;
 
-    float* As = smem + wave * WAVE_LDS;
-    float* Ws = As + 32 * LDR;
+    float* gbase = smem + wk * CF::GROUP_LDS;
 
-    // balanced K split across the waves of this workgroup
-    const int kbeg = (int)(((long)NK * wave) / NWAVES);
-    const int kend = (int)(((long)NK * (wave + 1)) / NWAVES);
+    // contiguous K slice of this k-group; every group runs `iters` iterations (same barrier count),
+    // a group that owns fewer chunks replays its last chunk with everything masked to zero
+    const int kbeg = (int)(((long)NK * wk) / WK);
+    const int kend = (int)(((long)NK * (wk + 1)) / WK);
+    const int iters = ((NK + WK - 1) / WK + 1) & ~1;   // even: the loop is unrolled by two
 
-    RowInfo ri[4];
+    RowInfo ri[CF::AE];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + r * 8 + (lane >> 3);
-        ri[r].valid = m < M;
-        const int mm = ri[r].valid ? m : 0;
-        ri[r].n = mm / HoWo;
-        const int rem = mm - ri[r].n * HoWo;
-        ri[r].oy = rem / p.Wo;
-        ri[r].ox = rem - ri[r].oy * p.Wo;
+    for (int j = 0; j < CF::AE; ++j) {
+        const int m = m0 + ((gt + j * CF::GT) >> 3);
+        ri[j].valid = m < M;
+        const int mm = ri[j].valid ? m : 0;
+        ri[j].n = mm / HoWo;
+        const int rem = mm - ri[j].n * HoWo;
+        ri[j].oy = rem / p.Wo;
+        ri[j].ox = rem - ri[j].oy * p.Wo;
     }
+
+    int wrow[CF::WE];       // clamped filter row of this thread's W elements
+    unsigned wmask = 0;     // bit j: that filter row exists
+#pragma unroll
+    for (int j = 0; j < CF::WE; ++j) {
+        const int co = n0 + ((gt + j * CF::GT) >> 3);
+        wmask |= (co < p.Cout ? 1u : 0u) << j;
+        wrow[j] = min(co, p.Cout - 1);
+    }
+    const int col = (gt & 7) * 4;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -172,62 +212,117 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const lfvdm_con
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    ChunkRegs<NT> R;
-    if (kbeg < kend) issue_chunk<NT>(p, kbeg, NK1, cpt, Cin, n0, ri, m0, M, lane, R);
+    // Two chunks are kept in flight in registers (R0, R1): the loads of chunk k+2 are issued before the
+    // MFMAs of chunk k, so a load has two compute phases (~2 x 1024 MFMA cycles) to come back.
+    ChunkRegs<CF::AE, CF::WE> R0, R1;
+    f32x4 ca[CF::AE], cb[CF::AE];
+#pragma unroll
+    for (int j = 0; j < CF::AE; ++j) { ca[j] = (f32x4){1.f, 1.f, 1.f, 1.f}; cb[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int klast = kend - 1;
+    issue_chunk<CF>(p, min(kbeg, klast), kbeg < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R0);
+    issue_chunk<CF>(p, min(kbeg + 1, klast), kbeg + 1 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R1);
 
-    const int st_off = (lane >> 3) * LDR + (lane & 7) * 4;          // staging store offset
-    const int fr_off = (lane & 31) * LDR + (lane >> 5) * 4;         // fragment read offset
+    const int fra = (32 * wm + (lane & 31)) * LDR + (lane >> 5) * 4;                    // A fragment offset
+    const int frw = (BM + 32 * NT * wn + (lane & 31)) * LDR + (lane >> 5) * 4;          // W fragment offset
 
-    for (int kc = kbeg; kc < kend; ++kc) {
-        finish_chunk<NT>(p, R, As, Ws, st_off);
-        wave_lds_fence();
-        if (kc + 1 < kend) issue_chunk<NT>(p, kc + 1, NK1, cpt, Cin, n0, ri, m0, M, lane, R);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a4 = ld4(As + fr_off + g * 8);
-            f32x4 b4[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) b4[t] = ld4(Ws + t * 32 * LDR + fr_off + g * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[t][e], acc[t], 0, 0, 0);
-        }
-        wave_lds_fence();
+#define LFVDM_PHASE(KC_, ST_, R_)                                                                              \
+    do {                                                                                                       \
+        float* st_ = (ST_);                                                                                    \
+        finish_chunk<CF, PRO>(p, R_, ca, cb, wmask, st_, st_ + BM * LDR, gt);                                  \
+        __syncthreads();                                                                                       \
+        issue_chunk<CF>(p, min((KC_) + 2, klast), (KC_) + 2 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R_);  \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                        \
+            const f32x4 a4 = ld4(st_ + fra + g * 8);                                                           \
+            f32x4 b4[NT];                                                                                      \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) b4[t] = ld4(st_ + frw + t * 32 * LDR + g * 8);      \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                      \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                 \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[t][e], acc[t], 0, 0, 0);           \
+        }                                                                                                      \
+    } while (0)
+    for (int it = 0; it < iters; it += 2) {
+        LFVDM_PHASE(kbeg + it, gbase, R0);
+        LFVDM_PHASE(kbeg + it + 1, gbase + CF::STAGE, R1);
     }
+#undef LFVDM_PHASE
+    __syncthreads();   // all fragment reads done before the stages are reused for the reduction
 
-    // ---- cross-wave K reduction through LDS (each wave reuses its own staging region) ----
-    float* red = smem + wave * WAVE_LDS;
+    // ---- cross-k-group reduction through LDS: group wk writes its partial block tile ----
+    float* red = gbase;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            red[row * RED_LD + t * 32 + (lane & 31)] = acc[t][r];
+            const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            red[row * RED_LD + 32 * NT * wn + t * 32 + (lane & 31)] = acc[t][r];
         }
     __syncthreads();
 
+    // ---- epilogue: every thread owns one output column (row for the NCHW layout) and EPT elements of
+    // it, so bias is read once and all residual loads are issued back to back before the first use
+    // (a per-element "load, wait, add" loop costs one L2 round trip per element).
+    constexpr int EPT = (BM * BN) / CF::NTHREADS;
+    static_assert((BM * BN) % CF::NTHREADS == 0, "tile must divide over the workgroup");
     const bool nchw = p.out_mode == LFVDM_OUT_NCHW;
-    for (int e = threadIdx.x; e < 32 * BN; e += NWAVES * 64) {
-        int row, col;
-        if (nchw) { col = e >> 5; row = e & 31; } else { row = e / BN; col = e - row * BN; }
-        const int m = m0 + row;
-        const int co = n0 + col;
-        if (m >= M || co >= p.Cout) continue;
-        float v = 0.f;
+    float v[EPT];
+    if (!nchw) {
+        static_assert(CF::NTHREADS % BN == 0 || BN % CF::NTHREADS == 0, "column ownership");
+        constexpr int RSTEP = CF::NTHREADS >= BN ? CF::NTHREADS / BN : 1;
+        constexpr int CSTEP = CF::NTHREADS >= BN ? 0 : CF::NTHREADS;   // (BN > NTHREADS: several columns)
+        const int col0 = tid % BN, row0 = tid / BN;
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) v += smem[w * WAVE_LDS + row * RED_LD + col];
-        if (p.bias) v += p.bias[co];
-        if (p.bias2) v += p.bias2[co];
-        const int n = m / HoWo;
-        if (p.res) {
-            float rv = p.res[(size_t)m * p.ldr + co];
-            if (p.resA) rv = rv * p.resA[(size_t)n * p.Cout + co] + p.resB[(size_t)n * p.Cout + co];
-            v += rv;
+        for (int i = 0; i < EPT; ++i) {
+            const int row = CSTEP ? (i * CSTEP + tid) / BN : row0 + i * RSTEP;
+            const int col = CSTEP ? (i * CSTEP + tid) % BN : col0;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) t += smem[w * CF::GROUP_LDS + row * RED_LD + col];
+            v[i] = t;
         }
-        if (nchw) p.out[((size_t)n * p.Cout + co) * HoWo + (m - n * HoWo)] = v;
-        else p.out[(size_t)m * p.ldo + co] = v;
+        float rv[EPT], ra[EPT], rb[EPT];
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int row = CSTEP ? (i * CSTEP + tid) / BN : row0 + i * RSTEP;
+            const int col = CSTEP ? (i * CSTEP + tid) % BN : col0;
+            const int m = min(m0 + row, M - 1), co = min(n0 + col, p.Cout - 1);
+            rv[i] = p.res ? p.res[(unsigned)(m * p.ldr + co)] : 0.f;
+            ra[i] = 1.f;
+            rb[i] = 0.f;
+            if (p.resA) {
+                const int n = m / HoWo;
+                ra[i] = p.resA[(unsigned)(n * p.Cout + co)];
+                rb[i] = p.resB[(unsigned)(n * p.Cout + co)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int row = CSTEP ? (i * CSTEP + tid) / BN : row0 + i * RSTEP;
+            const int col = CSTEP ? (i * CSTEP + tid) % BN : col0;
+            const int m = m0 + row, co = n0 + col;
+            const int cc = min(co, p.Cout - 1);
+            float t = v[i] + (p.bias ? p.bias[cc] : 0.f) + (p.bias2 ? p.bias2[cc] : 0.f);
+            if (p.res) t += rv[i] * ra[i] + rb[i];
+            if (m < M && co < p.Cout) p.out[(size_t)m * p.ldo + co] = t;
+        }
+    } else {
+        // frame layout out[(n*Cout + co)*HoWo + pix]: consecutive threads take consecutive pixels
+        for (int e = tid; e < BM * BN; e += CF::NTHREADS) {
+            const int col = e / BM, row = e - col * BM;
+            const int m = m0 + row, co = n0 + col;
+            if (m >= M || co >= p.Cout) continue;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) t += smem[w * CF::GROUP_LDS + row * RED_LD + col];
+            if (p.bias) t += p.bias[co];
+            if (p.bias2) t += p.bias2[co];
+            const int n = m / HoWo;
+            if (p.res) {
+                float r = p.res[(size_t)m * p.ldr + co];
+                if (p.resA) r = r * p.resA[(size_t)n * p.Cout + co] + p.resB[(size_t)n * p.Cout + co];
+                t += r;
+            }
+            p.out[((size_t)n * p.Cout + co) * HoWo + (m - n * HoWo)] = t;
+        }
     }
 }
 
@@ -243,41 +338,79 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     }
 }
 
-template <int NT, int NWAVES>
-int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, int mt, int ntiles) {
-    constexpr size_t lds = (size_t)NWAVES * (32 + 32 * NT) * LDR * sizeof(float);
+template <int WM, int WN, int WK, int NT, int PRO>
+int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M) {
+    using CF = Cfg<WM, WN, WK, NT>;
     static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<NT, NWAVES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, PRO>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::LDS_BYTES) != hipSuccess)
             return LFVDM_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<NT, NWAVES>), dim3(mt, ntiles), dim3(NWAVES * 64), lds, s, *a);
+    const dim3 grid((unsigned)((M + CF::BM - 1) / CF::BM), (unsigned)((a->Cout + CF::BN - 1) / CF::BN));
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, PRO>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
 
-// (NT, NWAVES) by a small makespan model: 256 CUs, 4 SIMDs, 64 cycles per 32x32x2 MFMA.
-void pick_cfg(int Cout, int mt, int NK, int* oNT, int* oNW) {
-    int bestNT = 1, bestNW = 1;
-    double best = 1e30;
-    for (int NT = 1; NT <= 2; ++NT) {
-        if (NT == 2 && Cout < 64) continue;
-        const int ntiles = (Cout + 32 * NT - 1) / (32 * NT);
-        for (int NW = 1; NW <= 16; NW *= 2) {
-            if (NW > NK) continue;
-            if (NW == 16 && NT == 2) continue;  // LDS budget
-            const double chunk = 16.0 * NT * 64.0 + 350.0;
-            const double per_wave = (double)((NK + NW - 1) / NW) * chunk;
-            const long wgs = (long)mt * ntiles;
-            const double waves_per_simd = (double)((wgs + 255) / 256) * ((NW + 3) / 4);
-            const double est = waves_per_simd * per_wave + 600.0 + 40.0 * NW + (NT == 1 ? 0.0 : -1.0);
-            if (est < best) { best = est; bestNT = NT; bestNW = NW; }
-        }
+template <int WM, int WN, int WK, int NT>
+int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, long M) {
+    if (!a->coefA) return launch_pro<WM, WN, WK, NT, 0>(a, s, M);
+    if (a->act == LFVDM_ACT_SILU) return launch_pro<WM, WN, WK, NT, 2>(a, s, M);
+    return launch_pro<WM, WN, WK, NT, 1>(a, s, M);
+}
+
+// Tile configurations: {WM, WN, WK, NT, waves/SIMD allowed by the VGPR allocation}.
+struct TileCfg { int WM, WN, WK, NT, vgpr_waves; };
+constexpr TileCfg kCfgs[] = {
+    {2, 2, 1, 1, 4},  // 0: 64x64,  4 waves
+    {2, 2, 1, 2, 3},  // 1: 64x128, 4 waves
+    {1, 2, 2, 1, 3},  // 2: 32x64,  2 k-groups (4 waves)
+    {1, 2, 4, 1, 3},  // 3: 32x64,  4 k-groups (8 waves)
+    {1, 1, 8, 1, 2},  // 4: 32x32,  8 k-groups (8 waves)   (tiny M: low-resolution levels)
+    {2, 2, 2, 1, 3},  // 5: 64x64,  2 k-groups (8 waves)
+    {1, 1, 4, 1, 2},  // 6: 32x32,  4 k-groups (4 waves)   (narrow outputs, e.g. Cout = 4)
+    {2, 2, 2, 2, 2},  // 7: 64x128, 2 k-groups (8 waves)
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+// Modelled makespan (cycles) of one launch: 256 CUs x 4 SIMDs, 64 cycles per 32x32x2 MFMA, one barrier
+// per 32-channel chunk, loads prefetched two chunks ahead.
+double model_cycles(const TileCfg& c, int Cout, long M, int NK) {
+    const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
+    const int waves = c.WM * c.WN * c.WK;
+    const double lds = (double)c.WK * 2.0 * (BM + BN) * LDR * 4.0;
+    int resident = (int)(160.0 * 1024.0 / lds);
+    const int by_vgpr = (c.vgpr_waves * 4) / waves;
+    if (by_vgpr < resident) resident = by_vgpr;
+    if (resident < 1) resident = 1;
+    const long wgs = ((M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
+    const long slots = 256L * resident;
+    const long rounds = (wgs + slots - 1) / slots;
+    long per_cu = (wgs + 255) / 256;
+    if (per_cu > resident) per_cu = resident;
+    const double simd_waves = (double)per_cu * ((waves + 3) / 4);
+    const double chunks = (double)((NK + c.WK - 1) / c.WK);
+    const double mfma = 16.0 * c.NT * 64.0;
+    double per_iter = mfma * simd_waves;
+    const double floor_iter = 1000.0 + 0.3 * mfma;   // barrier + staging + exposed latency of a lone wave
+    if (per_iter < floor_iter) per_iter = floor_iter;
+    return (double)rounds * (chunks * per_iter + 3500.0 + 900.0 + 250.0 * c.WK);
+}
+
+int pick_cfg(int Cout, long M, int NK) {
+    int best = 0;
+    double best_t = 1e30;
+    for (int i = 0; i < kNumCfgs; ++i) {
+        const TileCfg c = kCfgs[i];
+        if (c.WK > NK) continue;
+        const int BN = 32 * c.NT * c.WN;
+        if (Cout <= 32 && BN > 32) continue;
+        const double est = model_cycles(c, Cout, M, NK);
+        if (est < best_t) { best_t = est; best = i; }
     }
-    *oNT = bestNT;
-    *oNW = bestNW;
+    return best;
 }
 
 }  // namespace
@@ -300,16 +433,23 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
         if ((Win + 2 * pad - a->ksize) / a->stride + 1 != a->Wo) return LFVDM_E_SHAPE;
     }
     const long M = (long)a->N * a->Ho * a->Wo;
-    const int mt = (int)((M + 31) / 32);
+    // the kernel's per-lane address arithmetic is 32-bit (element offsets)
+    if ((long)a->N * a->Hs * a->Ws * (a->C0 > a->C1 ? a->C0 : a->C1) >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
+    if (M * (long)(C2 > a->Cout ? C2 : a->Cout) >= (1L << 31) || (long)a->N * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
+    if ((long)a->Cout * a->ksize * a->ksize * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     const int NK = a->ksize * a->ksize * (Cin / 32) + C2 / 32;
-
-    int bestNT = 1, bestNW = 1;
-    pick_cfg(a->Cout, mt, NK, &bestNT, &bestNW);
-    const int ntiles = (a->Cout + 32 * bestNT - 1) / (32 * bestNT);
-#define LFVDM_CASE(NT_, NW_) if (bestNT == NT_ && bestNW == NW_) return launch_cfg<NT_, NW_>(a, s, mt, ntiles)
-    LFVDM_CASE(1, 1); LFVDM_CASE(1, 2); LFVDM_CASE(1, 4); LFVDM_CASE(1, 8); LFVDM_CASE(1, 16);
-    LFVDM_CASE(2, 1); LFVDM_CASE(2, 2); LFVDM_CASE(2, 4); LFVDM_CASE(2, 8);
-#undef LFVDM_CASE
+    static const int forced = getenv("LFVDM_CONV_CFG") ? atoi(getenv("LFVDM_CONV_CFG")) : -1;  // tuning aid
+    const int id = (forced >= 0 && forced < kNumCfgs && kCfgs[forced].WK <= NK) ? forced : pick_cfg(a->Cout, M, NK);
+    switch (id) {
+        case 0: return launch_cfg<2, 2, 1, 1>(a, s, M);
+        case 1: return launch_cfg<2, 2, 1, 2>(a, s, M);
+        case 2: return launch_cfg<1, 2, 2, 1>(a, s, M);
+        case 3: return launch_cfg<1, 2, 4, 1>(a, s, M);
+        case 4: return launch_cfg<1, 1, 8, 1>(a, s, M);
+        case 5: return launch_cfg<2, 2, 2, 1>(a, s, M);
+        case 6: return launch_cfg<1, 1, 4, 1>(a, s, M);
+        case 7: return launch_cfg<2, 2, 2, 2>(a, s, M);
+    }
     return LFVDM_E_UNSUPPORTED;
 }
 
@@ -328,7 +468,10 @@ extern "C" int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* n
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
     if (Cin <= 0 || Cin % 32 || C2 % 32) return LFVDM_E_SHAPE;
     const long M = (long)a->N * a->Ho * a->Wo;
-    pick_cfg(a->Cout, (int)((M + 31) / 32), a->ksize * a->ksize * (Cin / 32) + C2 / 32, nt, nwaves);
+    const int id = pick_cfg(a->Cout, M, a->ksize * a->ksize * (Cin / 32) + C2 / 32);
+    // encoded as (WM*1000 + WN*100 + WK*10 + NT, waves) so that callers can print the template instance
+    *nt = kCfgs[id].WM * 1000 + kCfgs[id].WN * 100 + kCfgs[id].WK * 10 + kCfgs[id].NT;
+    *nwaves = kCfgs[id].WM * kCfgs[id].WN * kCfgs[id].WK;
     return LFVDM_OK;
 }
 

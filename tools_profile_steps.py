@@ -1,0 +1,60 @@
+"""Developer aid: per-launch timing table of one forward plan (not part of the product)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd"))
+sys.path.insert(0, ROOT)
+import torch as th  # noqa: E402
+
+import bench  # noqa: E402
+from improved_diffusion import _native as nat  # noqa: E402
+from improved_diffusion._engine import Plan  # noqa: E402
+
+
+def main():
+    ch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    dev = th.device("cuda")
+    model, diffusion = bench.make_model_and_diffusion(ch, dev)
+    B, T = 2, 20
+    inputs = bench.synthetic_inputs(B, T, 0, dev)
+    pl = Plan(model.native_engine(), B, T, 16, 16, False)
+    pl.refresh_weights()
+    pl.set_inputs(th.randn(B, T, 4, 16, 16, device=dev), inputs["x0"], th.tensor([500.0, 20.0], device=dev),
+                  inputs["frame_indices"], inputs["obs_mask"], inputs["latent_mask"])
+    L = nat.lib()
+    s = nat.stream()
+    n = len(pl.steps)
+    reps = 30
+    tot = [0.0] * n
+    ev = [(th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for rep in range(reps + 3):
+        for i, (fn, args) in enumerate(pl.steps):
+            ev[i][0].record()
+            fn(*args, s)
+            ev[i][1].record()
+        th.cuda.synchronize()
+        if rep >= 3:
+            for i in range(n):
+                tot[i] += ev[i][0].elapsed_time(ev[i][1]) * 1000 / reps
+    for i, (fn, args) in enumerate(pl.steps):
+        name = fn.__name__
+        extra = ""
+        if name == "lfvdm_conv_igemm":
+            a = args[0]._obj
+            nt, nw = C.c_int(), C.c_int()
+            L.lfvdm_conv_igemm_config(C.byref(a), C.byref(nt), C.byref(nw))
+            fl = bench.conv_flops(a)
+            M = a.N * a.Ho * a.Wo
+            v = nt.value
+            extra = (f"<{v // 1000},{v // 100 % 10},{v // 10 % 10},{v % 10}> M={M} Cin={a.C0 + a.C1} Cout={a.Cout} k={a.ksize} s2={a.s2C0 + a.s2C1} "
+                     f"coef={int(bool(a.coefA))} act={a.act} {fl / 1e6:8.1f} MF {fl / tot[i] / 1e6:6.1f} TF/s")
+        elif name in ("lfvdm_attn_spatial", "lfvdm_attn_temporal", "lfvdm_gn_coef", "lfvdm_gn_temporal"):
+            extra = " ".join(str(a) for a in args if isinstance(a, int) and a < 100000)
+        print(f"{i:3d} {tot[i]:8.1f} us  {name:22s} {extra}")
+    print("sum", sum(tot))
+
+
+if __name__ == "__main__":
+    main()
