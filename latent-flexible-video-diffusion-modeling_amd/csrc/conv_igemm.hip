@@ -19,23 +19,36 @@
 
 #include "common.cuh"
 
+#ifdef LFVDM_STAMP
+// diagnostic build only: shader-clock stamps of workgroup 0 / thread 0 (never compiled into the product)
+__device__ unsigned long long g_stamps[128];
+#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[(i)] = clock64(); } while (0)
+extern "C" int lfvdm_debug_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 2;
+}
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
-constexpr int KC = 32;    // channels per chunk
-constexpr int LDR = 36;   // padded LDS row (floats)
-
-template <int WM, int WN, int WK, int NT>
+// KCH = channels per K chunk (32 or 64; 64 halves the barriers / staging overhead per MFMA)
+template <int WM, int WN, int WK, int NT, int KCH>
 struct Cfg {
+    static constexpr int KC = KCH;
+    static constexpr int LDR = KCH + 4;                  // padded LDS row (floats): conflict-free b128 reads
+    static constexpr int QPR = KCH / 4;                  // float4 per row
+    static constexpr int RSH = KCH == 64 ? 4 : 3;        // log2(QPR)
     static constexpr int BM = 32 * WM;
     static constexpr int BN = 32 * NT * WN;
     static constexpr int GT = 64 * WM * WN;              // threads per k-group
     static constexpr int NTHREADS = GT * WK;
-    static constexpr int AE = (BM * 8) / GT;             // float4 A elements per thread per chunk
-    static constexpr int WE = (BN * 8) / GT;             // float4 W elements per thread per chunk
+    static constexpr int AE = (BM * QPR) / GT;           // float4 A elements per thread per chunk
+    static constexpr int WE = (BN * QPR) / GT;           // float4 W elements per thread per chunk
     static constexpr int STAGE = (BM + BN) * LDR;        // floats per LDS stage
     static constexpr int GROUP_LDS = 2 * STAGE;          // double buffered
     static constexpr size_t LDS_BYTES = (size_t)WK * GROUP_LDS * sizeof(float);
-    static_assert((BM * 8) % GT == 0 && (BN * 8) % GT == 0, "tile must divide over the group");
+    static_assert((BM * QPR) % GT == 0 && (BN * QPR) % GT == 0, "tile must divide over the group");
 };
 
 template <class T>
@@ -46,7 +59,20 @@ __device__ __forceinline__ T sel(bool c, T a, T b) {
 struct RowInfo {
     int n, oy, ox;
     bool valid;
+    int pix;        // (n*Hs + oy*stride)*Ws + ox*stride : source pixel of the centre tap (non-upsampled sources)
+    unsigned taps;  // bit t: filter tap t of this output pixel lies inside the image
+    int m;          // clamped output row index (second-segment / residual addressing)
 };
+
+// exact floor(a / d) for 0 <= a < 2^24 with rd = 1.0f / d (one fix-up step; avoids the ~40-instruction
+// integer division sequence in the kernel prologue)
+__device__ __forceinline__ int fast_div(int a, int d, float rd) {
+    int q = (int)((float)a * rd);
+    const int r = a - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
 
 template <int AE, int WE>
 struct ChunkRegs {
@@ -75,7 +101,7 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
     const int kk = main_seg ? kc : kc - NK1;
     const int ci = main_seg ? kk / taps : kk;
     const int tap = main_seg ? kk - ci * taps : 0;
-    const int cc = ci * KC;
+    const int cc = ci * CF::KC;
     const int dy = (main_seg && p.ksize == 3) ? tap / 3 - 1 : 0;
     const int dx = (main_seg && p.ksize == 3) ? tap - (tap / 3) * 3 - 1 : 0;
     const int c0 = sel(main_seg, p.C0, p.s2C0);
@@ -89,7 +115,7 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
     const int Wst = sel(main_seg, p.Ws, p.Wo);
     const int Hin = Hst << up;
     const int Win = Wst << up;
-    const float* wbase = sel(main_seg, p.W + (size_t)tap * Cin + cc, p.W2 + cc);
+    const float* wbase = sel(main_seg, p.W + (tap * Cin + cc), p.W2 + cc);
     const int wld = sel(main_seg, taps * Cin, p.s2C0 + p.s2C1);
 
     R.main_seg = main_seg;
@@ -102,22 +128,41 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
         }
     }
     unsigned am = 0;
-    const float* srcc = src + cl;
+    const float* srcc = src + cl + col;
+    if (!main_seg) {
+        // fused 1x1 skip segment: row m of a raw source at output resolution
 #pragma unroll
-    for (int j = 0; j < CF::AE; ++j) {
-        const RowInfo& q = ri[j];
-        const int iy = q.oy * stride + dy;
-        const int ix = q.ox * stride + dx;
-        const bool inb = live && q.valid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-        am |= (inb ? 1u : 0u) << j;
-        const int sy = min(max(iy, 0), Hin - 1) >> up;
-        const int sx = min(max(ix, 0), Win - 1) >> up;
-        const unsigned off = (unsigned)(((q.n * Hst + sy) * Wst + sx) * Csrc + col);
-        R.a[j] = ld4(srcc + off);
+        for (int j = 0; j < CF::AE; ++j) {
+            am |= ((live && ri[j].valid) ? 1u : 0u) << j;
+            R.a[j] = ld4(srcc + (unsigned)__mul24(ri[j].m, Csrc));
+        }
+    } else if (!up) {
+        // common case: the tap is a wave-uniform pixel offset from the precomputed centre pixel
+        const int tappix = dy * Wst + dx;
+#pragma unroll
+        for (int j = 0; j < CF::AE; ++j) {
+            const bool inb = live && ((ri[j].taps >> tap) & 1u);
+            am |= (inb ? 1u : 0u) << j;
+            const int px = inb ? ri[j].pix + tappix : ri[j].pix;
+            R.a[j] = ld4(srcc + (unsigned)__mul24(px, Csrc));
+        }
+    } else {
+        // nearest-2x upsampled source (3 launches per forward): general clamp-and-shift addressing
+#pragma unroll
+        for (int j = 0; j < CF::AE; ++j) {
+            const RowInfo& q = ri[j];
+            const int iy = q.oy * stride + dy;
+            const int ix = q.ox * stride + dx;
+            const bool inb = live && q.valid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+            am |= (inb ? 1u : 0u) << j;
+            const int sy = min(max(iy, 0), Hin - 1) >> 1;
+            const int sx = min(max(ix, 0), Win - 1) >> 1;
+            R.a[j] = ld4(srcc + (unsigned)(((q.n * Hst + sy) * Wst + sx) * Csrc));
+        }
     }
     R.amask = am;
 #pragma unroll
-    for (int j = 0; j < CF::WE; ++j) R.w[j] = ld4(wbase + (unsigned)(wrow[j] * wld + col));
+    for (int j = 0; j < CF::WE; ++j) R.w[j] = ld4(wbase + col + (unsigned)__mul24(wrow[j], wld));
 }
 
 // PRO: 0 = raw operand, 1 = affine (GroupNorm coefficients), 2 = affine + SiLU
@@ -126,14 +171,14 @@ __device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs
                                              f32x4 (&ca)[CF::AE], f32x4 (&cb)[CF::AE], unsigned wmask, float* As,
                                              float* Ws, int gt) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const int col = (gt & 7) * 4;
+    const int col = (gt & (CF::QPR - 1)) * 4;
     if (PRO > 0 && R.coef_cc >= 0) {   // once per channel chunk (the 9 taps share it)
 #pragma unroll
         for (int j = 0; j < CF::AE; ++j) { ca[j] = R.ca[j]; cb[j] = R.cb[j]; }
     }
 #pragma unroll
     for (int j = 0; j < CF::WE; ++j)
-        st4(Ws + ((gt + j * CF::GT) >> 3) * LDR + col, ((wmask >> j) & 1u) ? R.w[j] : zero);
+        st4(Ws + ((gt + j * CF::GT) >> CF::RSH) * CF::LDR + col, ((wmask >> j) & 1u) ? R.w[j] : zero);
 #pragma unroll
     for (int j = 0; j < CF::AE; ++j) {
         f32x4 v = R.a[j];
@@ -147,15 +192,15 @@ __device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs
             v = R.main_seg ? t : v;
         }
         v = ((R.amask >> j) & 1u) ? v : zero;
-        st4(As + ((gt + j * CF::GT) >> 3) * LDR + col, v);
+        st4(As + ((gt + j * CF::GT) >> CF::RSH) * CF::LDR + col, v);
     }
 }
 
-template <int WM, int WN, int WK, int NT, int PRO>
+template <int WM, int WN, int WK, int NT, int KCH, int PRO>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfvdm_conv_args p_in) {
     const lfvdm_conv_args p = p_in;   // private SSA copy: helpers take it by reference (keeps it out of scratch)
-    using CF = Cfg<WM, WN, WK, NT>;
-    constexpr int BM = CF::BM, BN = CF::BN;
+    using CF = Cfg<WM, WN, WK, NT, KCH>;
+    constexpr int BM = CF::BM, BN = CF::BN, KC = CF::KC, LDR = CF::LDR;
     constexpr int RED_LD = BN + 1;
     static_assert(BM * RED_LD <= CF::GROUP_LDS, "reduction tile must fit the group's stages");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -176,6 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     const int NK1 = taps * (Cin / KC);
     const int NK = NK1 + (p.s2C0 + p.s2C1) / KC;
 
+    STAMP(0);
     float* gbase = smem + wk * CF::GROUP_LDS;
 
     // contiguous K slice of this k-group; every group runs `iters` iterations (same barrier count),
@@ -185,26 +231,44 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     const int iters = ((NK + WK - 1) / WK + 1) & ~1;   // even: the loop is unrolled by two
 
     RowInfo ri[CF::AE];
+    {
+        const float rHoWo = 1.0f / (float)HoWo, rWo = 1.0f / (float)p.Wo;
+        const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
 #pragma unroll
-    for (int j = 0; j < CF::AE; ++j) {
-        const int m = m0 + ((gt + j * CF::GT) >> 3);
-        ri[j].valid = m < M;
-        const int mm = ri[j].valid ? m : 0;
-        ri[j].n = mm / HoWo;
-        const int rem = mm - ri[j].n * HoWo;
-        ri[j].oy = rem / p.Wo;
-        ri[j].ox = rem - ri[j].oy * p.Wo;
+        for (int j = 0; j < CF::AE; ++j) {
+            const int m = m0 + ((gt + j * CF::GT) >> CF::RSH);
+            ri[j].valid = m < M;
+            const int mm = ri[j].valid ? m : 0;
+            ri[j].m = mm;
+            ri[j].n = fast_div(mm, HoWo, rHoWo);
+            const int rem = mm - ri[j].n * HoWo;
+            ri[j].oy = fast_div(rem, p.Wo, rWo);
+            ri[j].ox = rem - ri[j].oy * p.Wo;
+            const int cy = ri[j].oy * p.stride, cx = ri[j].ox * p.stride;
+            ri[j].pix = (ri[j].n * p.Hs + cy) * p.Ws + cx;
+            unsigned tm = 0;
+            if (p.ksize == 3) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+                    tm |= ((unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win ? 1u : 0u) << t;
+                }
+            } else {
+                tm = 1u;
+            }
+            ri[j].taps = ri[j].valid ? tm : 0u;
+        }
     }
 
     int wrow[CF::WE];       // clamped filter row of this thread's W elements
     unsigned wmask = 0;     // bit j: that filter row exists
 #pragma unroll
     for (int j = 0; j < CF::WE; ++j) {
-        const int co = n0 + ((gt + j * CF::GT) >> 3);
+        const int co = n0 + ((gt + j * CF::GT) >> CF::RSH);
         wmask |= (co < p.Cout ? 1u : 0u) << j;
         wrow[j] = min(co, p.Cout - 1);
     }
-    const int col = (gt & 7) * 4;
+    const int col = (gt & (CF::QPR - 1)) * 4;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -222,16 +286,21 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     issue_chunk<CF>(p, min(kbeg, klast), kbeg < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R0);
     issue_chunk<CF>(p, min(kbeg + 1, klast), kbeg + 1 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R1);
 
+    STAMP(1);
     const int fra = (32 * wm + (lane & 31)) * LDR + (lane >> 5) * 4;                    // A fragment offset
     const int frw = (BM + 32 * NT * wn + (lane & 31)) * LDR + (lane >> 5) * 4;          // W fragment offset
 
 #define LFVDM_PHASE(KC_, ST_, R_)                                                                              \
     do {                                                                                                       \
         float* st_ = (ST_);                                                                                    \
+        STAMP(4 + 4 * ((KC_) - kbeg));                                                                         \
         finish_chunk<CF, PRO>(p, R_, ca, cb, wmask, st_, st_ + BM * LDR, gt);                                  \
+        STAMP(5 + 4 * ((KC_) - kbeg));                                                                         \
         __syncthreads();                                                                                       \
+        STAMP(6 + 4 * ((KC_) - kbeg));                                                                         \
         issue_chunk<CF>(p, min((KC_) + 2, klast), (KC_) + 2 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R_);  \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                        \
+        STAMP(7 + 4 * ((KC_) - kbeg));                                                                         \
+        _Pragma("unroll") for (int g = 0; g < KC / 8; ++g) {                                                   \
             const f32x4 a4 = ld4(st_ + fra + g * 8);                                                           \
             f32x4 b4[NT];                                                                                      \
             _Pragma("unroll") for (int t = 0; t < NT; ++t) b4[t] = ld4(st_ + frw + t * 32 * LDR + g * 8);      \
@@ -245,6 +314,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         LFVDM_PHASE(kbeg + it + 1, gbase + CF::STAGE, R1);
     }
 #undef LFVDM_PHASE
+    STAMP(2);
     __syncthreads();   // all fragment reads done before the stages are reused for the reduction
 
     // ---- cross-k-group reduction through LDS: group wk writes its partial block tile ----
@@ -258,52 +328,51 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         }
     __syncthreads();
 
-    // ---- epilogue: every thread owns one output column (row for the NCHW layout) and EPT elements of
-    // it, so bias is read once and all residual loads are issued back to back before the first use
-    // (a per-element "load, wait, add" loop costs one L2 round trip per element).
-    constexpr int EPT = (BM * BN) / CF::NTHREADS;
-    static_assert((BM * BN) % CF::NTHREADS == 0, "tile must divide over the workgroup");
+    // ---- epilogue: a thread owns 4 consecutive output columns of EPV rows: bias is read once as a
+    // float4, all residual loads are issued back to back, stores are 16-byte.
+    constexpr int QN = BN / 4;                              // float4 per tile row
+    constexpr int EPV = (BM * QN + CF::NTHREADS - 1) / CF::NTHREADS;   // float4 per thread
     const bool nchw = p.out_mode == LFVDM_OUT_NCHW;
-    float v[EPT];
     if (!nchw) {
-        static_assert(CF::NTHREADS % BN == 0 || BN % CF::NTHREADS == 0, "column ownership");
-        constexpr int RSTEP = CF::NTHREADS >= BN ? CF::NTHREADS / BN : 1;
-        constexpr int CSTEP = CF::NTHREADS >= BN ? 0 : CF::NTHREADS;   // (BN > NTHREADS: several columns)
-        const int col0 = tid % BN, row0 = tid / BN;
+        const int c4 = (tid % QN) * 4;
+        const int row0 = tid / QN;
+        constexpr int RSTEP = CF::NTHREADS / QN;
+        static_assert(CF::NTHREADS % QN == 0, "column ownership");
+        const int co = n0 + c4;
+        const bool cok = co < p.Cout && row0 < BM;   // Cout % 4 == 0 is checked by the launcher for this layout
+        const int cc = cok ? co : 0;
+        f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bsum += ld4(p.bias + cc);
+        if (p.bias2) bsum += ld4(p.bias2 + cc);
+        f32x4 rv[EPV], ra[EPV], rb[EPV];
+        const float rHoWo = 1.0f / (float)HoWo;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int row = CSTEP ? (i * CSTEP + tid) / BN : row0 + i * RSTEP;
-            const int col = CSTEP ? (i * CSTEP + tid) % BN : col0;
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < WK; ++w) t += smem[w * CF::GROUP_LDS + row * RED_LD + col];
-            v[i] = t;
-        }
-        float rv[EPT], ra[EPT], rb[EPT];
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int row = CSTEP ? (i * CSTEP + tid) / BN : row0 + i * RSTEP;
-            const int col = CSTEP ? (i * CSTEP + tid) % BN : col0;
-            const int m = min(m0 + row, M - 1), co = min(n0 + col, p.Cout - 1);
-            rv[i] = p.res ? p.res[(unsigned)(m * p.ldr + co)] : 0.f;
-            ra[i] = 1.f;
-            rb[i] = 0.f;
+        for (int i = 0; i < EPV; ++i) {
+            const int m = min(m0 + min(row0 + i * RSTEP, BM - 1), M - 1);
+            rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ra[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
+            rb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.res) rv[i] = ld4(p.res + (unsigned)(m * p.ldr + cc));
             if (p.resA) {
-                const int n = m / HoWo;
-                ra[i] = p.resA[(unsigned)(n * p.Cout + co)];
-                rb[i] = p.resB[(unsigned)(n * p.Cout + co)];
+                const int n = fast_div(m, HoWo, rHoWo);
+                ra[i] = ld4(p.resA + (unsigned)(n * p.Cout + cc));
+                rb[i] = ld4(p.resB + (unsigned)(n * p.Cout + cc));
             }
         }
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int row = CSTEP ? (i * CSTEP + tid) / BN : row0 + i * RSTEP;
-            const int col = CSTEP ? (i * CSTEP + tid) % BN : col0;
-            const int m = m0 + row, co = n0 + col;
-            const int cc = min(co, p.Cout - 1);
-            float t = v[i] + (p.bias ? p.bias[cc] : 0.f) + (p.bias2 ? p.bias2[cc] : 0.f);
+        for (int i = 0; i < EPV; ++i) {
+            const int row = min(row0 + i * RSTEP, BM - 1);
+            f32x4 t = bsum;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+                const float* r = smem + w * CF::GROUP_LDS + row * RED_LD + c4;
+                t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
+            }
             if (p.res) t += rv[i] * ra[i] + rb[i];
-            if (m < M && co < p.Cout) p.out[(size_t)m * p.ldo + co] = t;
+            const int m = m0 + row;
+            if (m < M && cok && row0 + i * RSTEP < BM) st4(p.out + ((size_t)m * p.ldo + co), t);
         }
+        STAMP(3);
     } else {
         // frame layout out[(n*Cout + co)*HoWo + pix]: consecutive threads take consecutive pixels
         for (int e = tid; e < BM * BN; e += CF::NTHREADS) {
@@ -338,27 +407,35 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     }
 }
 
-template <int WM, int WN, int WK, int NT, int PRO>
+template <int WM, int WN, int WK, int NT, int KCH, int PRO>
 int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M) {
-    using CF = Cfg<WM, WN, WK, NT>;
+    using CF = Cfg<WM, WN, WK, NT, KCH>;
     static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, PRO>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::LDS_BYTES) != hipSuccess)
             return LFVDM_E_LAUNCH;
         attr_set = true;
     }
     const dim3 grid((unsigned)((M + CF::BM - 1) / CF::BM), (unsigned)((a->Cout + CF::BN - 1) / CF::BN));
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, PRO>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
 
+template <int WM, int WN, int WK, int NT, int KCH>
+int launch_kc(const lfvdm_conv_args* a, hipStream_t s, long M) {
+    if (!a->coefA) return launch_pro<WM, WN, WK, NT, KCH, 0>(a, s, M);
+    if (a->act == LFVDM_ACT_SILU) return launch_pro<WM, WN, WK, NT, KCH, 2>(a, s, M);
+    return launch_pro<WM, WN, WK, NT, KCH, 1>(a, s, M);
+}
+
 template <int WM, int WN, int WK, int NT>
-int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, long M) {
-    if (!a->coefA) return launch_pro<WM, WN, WK, NT, 0>(a, s, M);
-    if (a->act == LFVDM_ACT_SILU) return launch_pro<WM, WN, WK, NT, 2>(a, s, M);
-    return launch_pro<WM, WN, WK, NT, 1>(a, s, M);
+int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, long M, int kch) {
+    if constexpr (WM * WN >= 4 && NT == 1) {   // 64-channel chunks need a 256-thread k-group (register budget)
+        if (kch == 64) return launch_kc<WM, WN, WK, NT, 64>(a, s, M);
+    }
+    return launch_kc<WM, WN, WK, NT, 32>(a, s, M);
 }
 
 // Tile configurations: {WM, WN, WK, NT, waves/SIMD allowed by the VGPR allocation}.
@@ -377,10 +454,10 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 // Modelled makespan (cycles) of one launch: 256 CUs x 4 SIMDs, 64 cycles per 32x32x2 MFMA, one barrier
 // per 32-channel chunk, loads prefetched two chunks ahead.
-double model_cycles(const TileCfg& c, int Cout, long M, int NK) {
+double model_cycles(const TileCfg& c, int Cout, long M, int NK, int kch) {
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
     const int waves = c.WM * c.WN * c.WK;
-    const double lds = (double)c.WK * 2.0 * (BM + BN) * LDR * 4.0;
+    const double lds = (double)c.WK * 2.0 * (BM + BN) * (kch + 4) * 4.0;
     int resident = (int)(160.0 * 1024.0 / lds);
     const int by_vgpr = (c.vgpr_waves * 4) / waves;
     if (by_vgpr < resident) resident = by_vgpr;
@@ -392,23 +469,35 @@ double model_cycles(const TileCfg& c, int Cout, long M, int NK) {
     if (per_cu > resident) per_cu = resident;
     const double simd_waves = (double)per_cu * ((waves + 3) / 4);
     const double chunks = (double)((NK + c.WK - 1) / c.WK);
-    const double mfma = 16.0 * c.NT * 64.0;
+    const double mfma = 16.0 * c.NT * 64.0 * (kch / 32);
     double per_iter = mfma * simd_waves;
     const double floor_iter = 1000.0 + 0.3 * mfma;   // barrier + staging + exposed latency of a lone wave
     if (per_iter < floor_iter) per_iter = floor_iter;
     return (double)rounds * (chunks * per_iter + 3500.0 + 900.0 + 250.0 * c.WK);
 }
 
-int pick_cfg(int Cout, long M, int NK) {
-    int best = 0;
+// Joint choice of tile configuration and K chunk width (64-channel chunks only when every channel
+// count involved is a multiple of 64 and the k-group has 256 threads).
+struct Pick { int id, kch, NK; };
+Pick pick_cfg(const lfvdm_conv_args* a, long M) {
+    const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
+    const bool can64 = !getenv("LFVDM_CONV_KC32") && Cin % 64 == 0 && a->C0 % 64 == 0 && C2 % 64 == 0 && a->s2C0 % 64 == 0;
+    static const int forced = getenv("LFVDM_CONV_CFG") ? atoi(getenv("LFVDM_CONV_CFG")) : -1;  // tuning aid
+    Pick best = {0, 32, a->ksize * a->ksize * (Cin / 32) + C2 / 32};
     double best_t = 1e30;
     for (int i = 0; i < kNumCfgs; ++i) {
         const TileCfg c = kCfgs[i];
-        if (c.WK > NK) continue;
-        const int BN = 32 * c.NT * c.WN;
-        if (Cout <= 32 && BN > 32) continue;
-        const double est = model_cycles(c, Cout, M, NK);
-        if (est < best_t) { best_t = est; best = i; }
+        if (forced >= 0 && i != forced) continue;
+        const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
+        if (a->Cout <= 32 && BN > 32) continue;
+        for (int kch = 32; kch <= 64; kch += 32) {
+            if (kch == 64 && (!can64 || c.WM * c.WN < 4 || c.NT > 1)) continue;
+            const int NK = a->ksize * a->ksize * (Cin / kch) + C2 / kch;
+            if (c.WK > NK) continue;
+            if ((double)c.WK * 2.0 * (BM + BN) * (kch + 4) * 4.0 > 160.0 * 1024.0) continue;   // LDS budget
+            const double est = model_cycles(c, a->Cout, M, NK, kch);
+            if (est < best_t) { best_t = est; best = {i, kch, NK}; }
+        }
     }
     return best;
 }
@@ -426,6 +515,7 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     if (a->C1 > 0 && !a->src1) return LFVDM_E_SHAPE;
     if (C2 > 0 && (!a->W2 || !a->s2src0 || (a->s2C1 > 0 && !a->s2src1))) return LFVDM_E_SHAPE;
     if ((a->coefA == nullptr) != (a->coefB == nullptr)) return LFVDM_E_SHAPE;
+    if (a->out_mode == LFVDM_OUT_ROWS && (a->Cout % 4 || a->ldo % 4 || (a->res && a->ldr % 4))) return LFVDM_E_SHAPE;
     {   // output size must agree with the conv arithmetic the kernel assumes
         const int Hin = a->up ? 2 * a->Hs : a->Hs, Win = a->up ? 2 * a->Ws : a->Ws;
         const int pad = a->ksize == 3 ? 1 : 0;
@@ -437,18 +527,17 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     if ((long)a->N * a->Hs * a->Ws * (a->C0 > a->C1 ? a->C0 : a->C1) >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     if (M * (long)(C2 > a->Cout ? C2 : a->Cout) >= (1L << 31) || (long)a->N * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     if ((long)a->Cout * a->ksize * a->ksize * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
-    const int NK = a->ksize * a->ksize * (Cin / 32) + C2 / 32;
-    static const int forced = getenv("LFVDM_CONV_CFG") ? atoi(getenv("LFVDM_CONV_CFG")) : -1;  // tuning aid
-    const int id = (forced >= 0 && forced < kNumCfgs && kCfgs[forced].WK <= NK) ? forced : pick_cfg(a->Cout, M, NK);
-    switch (id) {
-        case 0: return launch_cfg<2, 2, 1, 1>(a, s, M);
-        case 1: return launch_cfg<2, 2, 1, 2>(a, s, M);
-        case 2: return launch_cfg<1, 2, 2, 1>(a, s, M);
-        case 3: return launch_cfg<1, 2, 4, 1>(a, s, M);
-        case 4: return launch_cfg<1, 1, 8, 1>(a, s, M);
-        case 5: return launch_cfg<2, 2, 2, 1>(a, s, M);
-        case 6: return launch_cfg<1, 1, 4, 1>(a, s, M);
-        case 7: return launch_cfg<2, 2, 2, 2>(a, s, M);
+    const Pick pk = pick_cfg(a, M);
+    const int kch = pk.kch;
+    switch (pk.id) {
+        case 0: return launch_cfg<2, 2, 1, 1>(a, s, M, kch);
+        case 1: return launch_cfg<2, 2, 1, 2>(a, s, M, kch);
+        case 2: return launch_cfg<1, 2, 2, 1>(a, s, M, kch);
+        case 3: return launch_cfg<1, 2, 4, 1>(a, s, M, kch);
+        case 4: return launch_cfg<1, 1, 8, 1>(a, s, M, kch);
+        case 5: return launch_cfg<2, 2, 2, 1>(a, s, M, kch);
+        case 6: return launch_cfg<1, 1, 4, 1>(a, s, M, kch);
+        case 7: return launch_cfg<2, 2, 2, 2>(a, s, M, kch);
     }
     return LFVDM_E_UNSUPPORTED;
 }
@@ -468,10 +557,11 @@ extern "C" int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* n
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
     if (Cin <= 0 || Cin % 32 || C2 % 32) return LFVDM_E_SHAPE;
     const long M = (long)a->N * a->Ho * a->Wo;
-    const int id = pick_cfg(a->Cout, M, a->ksize * a->ksize * (Cin / 32) + C2 / 32);
+    const Pick pk = pick_cfg(a, M);
+    const int id = pk.id, kch = pk.kch;
     // encoded as (WM*1000 + WN*100 + WK*10 + NT, waves) so that callers can print the template instance
     *nt = kCfgs[id].WM * 1000 + kCfgs[id].WN * 100 + kCfgs[id].WK * 10 + kCfgs[id].NT;
-    *nwaves = kCfgs[id].WM * kCfgs[id].WN * kCfgs[id].WK;
+    *nwaves = kCfgs[id].WM * kCfgs[id].WN * kCfgs[id].WK + 1000 * kch;
     return LFVDM_OK;
 }
 
