@@ -60,7 +60,8 @@ typedef struct lfvdm_conv_args {
     int32_t C0, C1;
     int32_t N;        /* samples (B*T) */
     int32_t Hs, Ws;   /* spatial size of the stored source */
-    int32_t up;       /* 1: source is nearest-upsampled x2 on the fly */
+    int32_t up;       /* 1: source is nearest-upsampled x2 on the fly; 2: zero-insertion x2 (the data
+                       * gradient of a stride-2 conv is this conv on the transposed-flipped weights) */
     int32_t stride;   /* 1 or 2 */
     int32_t ksize;    /* 3 (pad 1) or 1 (pad 0) */
     int32_t Ho, Wo;   /* output spatial size */
@@ -96,6 +97,21 @@ int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* nwaves);
 int lfvdm_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int ksize, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Backward of the convolution / linear (autograd of nn.Conv2d / nn.Linear in the reference,
+ * train_util.py:328 `loss.backward()`).
+ *   data gradient   : lfvdm_conv_igemm on dout with the weights packed by lfvdm_pack_conv_weight_t
+ *                     (Wt[ci][tap][co] = W[co][ci][flip(tap)]); stride-2 convs use up = 2.
+ *   weight gradient : lfvdm_conv_wgrad.  `a` describes the FORWARD operand (src*, C*, N, Hs, Ws, up,
+ *                     stride, ksize, Ho, Wo, coefA/B, act); a->res = dout rows [M][ldr]; a->out = packed
+ *                     gradient [Cout][k*k][Cin], ACCUMULATED with float atomics (zero it first);
+ *                     a->bias = bias gradient [Cout] (accumulated) or NULL.
+ *   lfvdm_unpack_conv_grad: packed [Cout][k*k][Cin] -> OIHW gradient (accumulate = 1: +=).
+ * ------------------------------------------------------------------------------------- */
+int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream);
+int lfvdm_pack_conv_weight_t(const float* w_oihw, float* w_packed_t, int Cout, int Cin, int ksize, void* stream);
+int lfvdm_unpack_conv_grad(const float* g_packed, float* g_oihw, int Cout, int Cin, int ksize, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Model prologue: input compositing + indicator channel + 3x3 input conv in one kernel
  * (unet.py:441-450 and input_blocks.0, unet.py:310-316).
  *   x, x0: (B,T,C,H,W) frame layout; obs: (B*T) floats; w: OIHW [Cout][C+1][3][3]
@@ -114,6 +130,24 @@ int lfvdm_conv_in(const float* x, const float* x0, const float* obs, const float
 int lfvdm_gn_coef(const float* src0, const float* src1, int C0, int C1, int N, int P,
                   const float* gamma, const float* beta, const float* film, int film_div, int film_ld,
                   float eps, float* coefA, float* coefB, void* stream);
+
+/* Same, additionally writing (mean, rstd) per (sample, group) to stats[N][32][2] for the backward. */
+int lfvdm_gn_coef_stats(const float* src0, const float* src1, int C0, int C1, int N, int P,
+                        const float* gamma, const float* beta, const float* film, int film_div, int film_ld,
+                        float eps, float* coefA, float* coefB, float* stats, void* stream);
+
+/* GroupNorm(+FiLM)(+SiLU) backward (autograd of nn.GroupNorm / SiLU in the reference's loss.backward()).
+ * da [N*P][C0+C1] is the gradient w.r.t. act(x*A+B) (the conv data gradient); coefA/coefB/stats come from
+ * lfvdm_gn_coef_stats.  _stats writes sums[N][C][2] = (sum_p dz, sum_p dz*xhat); _apply writes dx, split over
+ * the two concat sources (out1 may be NULL when C1 == 0), overwriting (acc = 0) or accumulating (acc = 1). */
+int lfvdm_gn_bwd_stats(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                       const float* coefA, const float* coefB, const float* stats, int act, float* sums, void* stream);
+int lfvdm_gn_bwd_apply(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                       const float* coefA, const float* coefB, const float* stats, const float* sums, int act,
+                       float* out0, float* out1, int acc0, int acc1, void* stream);
+/* Temporal GroupNorm backward: dx from dy; dgamma/dbeta [C] are ACCUMULATED with float atomics. */
+int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* dgamma,
+                          float* dbeta, int B, int T, int P, int C, int accumulate, void* stream);
 
 /* Temporal GroupNorm of rpe.py:135-137: statistics over (C/32 channels x T frames) for each
  * (b, pixel); writes the normalised tensor (it is also the residual of rpe.py:172).

@@ -109,7 +109,8 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
     const float* src = sel(main_seg, sel(second, p.src1, p.src0), sel(second, p.s2src1, p.s2src0));
     const int Csrc = sel(main_seg, sel(second, p.C1, p.C0), sel(second, p.s2C1, p.s2C0));
     const int cl = second ? cc - c0 : cc;
-    const int up = sel(main_seg, p.up, 0);
+    const int upmode = sel(main_seg, p.up, 0);      // 0 none, 1 nearest x2, 2 zero-insertion x2 (transposed conv)
+    const int up = upmode ? 1 : 0;
     const int stride = sel(main_seg, p.stride, 1);
     const int Hst = sel(main_seg, p.Hs, p.Ho);      // stored source extent
     const int Wst = sel(main_seg, p.Ws, p.Wo);
@@ -153,7 +154,8 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
             const RowInfo& q = ri[j];
             const int iy = q.oy * stride + dy;
             const int ix = q.ox * stride + dx;
-            const bool inb = live && q.valid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+            bool inb = live && q.valid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+            if (upmode == 2) inb = inb && (((iy | ix) & 1) == 0);   // only the even grid carries data
             am |= (inb ? 1u : 0u) << j;
             const int sy = min(max(iy, 0), Hin - 1) >> 1;
             const int sx = min(max(ix, 0), Win - 1) >> 1;
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // wave index as a SCALAR: everything derived from it (k-group, K slice, chunk parameters, segment
+    // branches) then lives in SGPRs / scalar branches instead of per-lane VGPR arithmetic under exec masks
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave / (WM * WN);
     const int wmn = wave - wk * (WM * WN);
     const int wm = wmn / WN, wn = wmn - wm * WN;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     RowInfo ri[CF::AE];
     {
         const float rHoWo = 1.0f / (float)HoWo, rWo = 1.0f / (float)p.Wo;
-        const int Hin = p.Hs << p.up, Win = p.Ws << p.up;
+        const int Hin = p.up ? 2 * p.Hs : p.Hs, Win = p.up ? 2 * p.Ws : p.Ws;
 #pragma unroll
         for (int j = 0; j < CF::AE; ++j) {
             const int m = m0 + ((gt + j * CF::GT) >> CF::RSH);

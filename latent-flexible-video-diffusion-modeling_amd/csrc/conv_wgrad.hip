@@ -1,0 +1,225 @@
+// Weight / bias gradients of the implicit-GEMM convolution (and of nn.Linear) on fp32 MFMA, plus the
+// transposed-flipped weight packing that turns the data gradient into a forward conv_igemm launch.
+//
+//   dWp[co][tap*Cin + ci] += sum_m dout[m][co] * f(src)[m, tap, ci]        (packed [Cout][tap][Cin])
+//   db[co]                += sum_m dout[m][co]
+// f is the same fused prologue as in the forward (GroupNorm/FiLM affine + SiLU, zero padding), so the
+// normalised activation is never materialised for the backward either.
+//
+// Decomposition: the reduction dimension is M (output pixels).  One WAVE owns a 32(co) x 32(k) tile of
+// dWp for a slice of M and walks it in 32-row chunks with wave-private LDS staging (no barriers); partial
+// tiles of different M slices are combined with float atomics into the (zero-initialised) packed gradient
+// (atomic traffic: Cout*K*msplit*4 B per launch, far below the ~1.3 TB/s atomic rate).
+// MFMA mapping: D[co][k] += A[co][m] * B[m][k]; A lane (i=co, h) reads dout[m = 8g+4h+e][co] and B lane
+// (j=k, h) reads a[m = 8g+4h+e][k] as conflict-free column reads of the row-major LDS tiles.
+#include "common.cuh"
+
+namespace {
+
+constexpr int WLD = 36;  // padded LDS row (floats)
+
+struct WRow {
+    int n, oy, ox, m;
+    bool valid;
+};
+
+__device__ __forceinline__ int fdiv(int a, int d, float rd) {
+    int q = (int)((float)a * rd);
+    const int r = a - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
+template <class T>
+__device__ __forceinline__ T selv(bool c, T a, T b) {
+    return c ? a : b;
+}
+
+// args reuse lfvdm_conv_args: src*/C*/N/Hs/Ws/up/stride/ksize/Ho/Wo/coefA/coefB/act describe the forward
+// operand; `res` = dout rows [M][ldr] (ldr >= Cout); `out` = packed dW [Cout][taps*Cin] (accumulated);
+// `bias` (non-const use) = db [Cout] or NULL.
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const lfvdm_conv_args p_in, int msplit) {
+    const lfvdm_conv_args p = p_in;
+    __shared__ __attribute__((aligned(16))) float smem[4][2 * 32 * WLD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* Ds = smem[wave];            // dout tile [32 m][32 co]
+    float* As = Ds + 32 * WLD;         // a tile    [32 m][32 k]
+
+    const int Cin = p.C0 + p.C1;
+    const int taps = p.ksize * p.ksize;
+    const int cpt = Cin / 32;
+    const int NKT = taps * cpt;                        // k tiles
+    const int NCT = (p.Cout + 31) / 32;                // co tiles
+    const int HoWo = p.Ho * p.Wo;
+    const int M = p.N * HoWo;
+    const int nchunks = (M + 31) / 32;
+
+    // wave task = (k tile, co tile, m slice)
+    const long task = (long)blockIdx.x * 4 + wave;
+    const long ntasks = (long)NKT * NCT * msplit;
+    if (task >= ntasks) return;
+    const int ms = (int)(task % msplit);
+    const int ct = (int)((task / msplit) % NCT);
+    const int kt = (int)(task / ((long)msplit * NCT));
+    const int tap = kt / cpt;
+    const int cc = (kt - tap * cpt) * 32;
+    const int dy = p.ksize == 3 ? tap / 3 - 1 : 0;
+    const int dx = p.ksize == 3 ? tap - (tap / 3) * 3 - 1 : 0;
+    const bool second = cc >= p.C0;
+    const float* src = selv(second, p.src1, p.src0);
+    const int Csrc = selv(second, p.C1, p.C0);
+    const int cl = second ? cc - p.C0 : cc;
+    const int Hin = p.up ? 2 * p.Hs : p.Hs, Win = p.up ? 2 * p.Ws : p.Ws;
+    const int c_beg = (int)(((long)nchunks * ms) / msplit), c_end = (int)(((long)nchunks * (ms + 1)) / msplit);
+    const int co0 = ct * 32;
+
+    const int col = (lane & 7) * 4;
+    const int rsub = lane >> 3;
+    const float rHoWo = 1.0f / (float)HoWo, rWo = 1.0f / (float)p.Wo;
+    const float* dout = p.res;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int st_off = rsub * WLD + col;
+
+    for (int c = c_beg; c < c_end; ++c) {
+        const int m0 = c * 32;
+        f32x4 dv[4], av[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + r * 8 + rsub;
+            const bool valid = m < M;
+            const int mm = valid ? m : 0;
+            const int n = fdiv(mm, HoWo, rHoWo);
+            const int rem = mm - n * HoWo;
+            const int oy = fdiv(rem, p.Wo, rWo);
+            const int ox = rem - oy * p.Wo;
+            // dout tile (zero for rows past M and filters past Cout)
+            f32x4 d = zero;
+            if (valid && co0 + col < p.Cout) d = ld4(dout + (size_t)mm * p.ldr + co0 + col);
+            dv[r] = d;
+            // forward operand tile
+            const int iy = oy * p.stride + dy, ix = ox * p.stride + dx;
+            const bool inb = valid && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+            f32x4 v = zero;
+            if (inb) {
+                const int sy = p.up ? (iy >> 1) : iy, sx = p.up ? (ix >> 1) : ix;
+                v = ld4(src + ((size_t)(n * p.Hs + sy) * p.Ws + sx) * Csrc + cl + col);
+                if (p.coefA) v = v * ld4(p.coefA + (size_t)n * Cin + cc + col) + ld4(p.coefB + (size_t)n * Cin + cc + col);
+                if (p.act == LFVDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            }
+            av[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bsum += dv[r];
+            st4(Ds + r * 8 * WLD + st_off, dv[r]);
+            st4(As + r * 8 * WLD + st_off, av[r]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mrow = 8 * g + 4 * (lane >> 5) + e;
+                const float a = Ds[mrow * WLD + (lane & 31)];
+                const float b = As[mrow * WLD + (lane & 31)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        wave_lds_fence();
+    }
+    // ---- accumulate the partial tile: D lane l holds column k = l&31, rows co = (r&3)+8*(r>>2)+4*(l>>5)
+    const int Ktot = taps * Cin;
+    float* dW = p.out;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < p.Cout) atomicAdd(dW + (size_t)co * Ktot + (size_t)tap * Cin + cc + (lane & 31), acc[r]);
+    }
+    if (kt == 0 && p.bias != nullptr) {
+        // bias gradient: column sums of this wave's dout rows (lanes with equal col differ in bits 3..5)
+        float* db = const_cast<float*>(p.bias);
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            bsum.x += __shfl_xor(bsum.x, o, 64); bsum.y += __shfl_xor(bsum.y, o, 64);
+            bsum.z += __shfl_xor(bsum.z, o, 64); bsum.w += __shfl_xor(bsum.w, o, 64);
+        }
+        if (lane < 8 && co0 + col < p.Cout) {
+            atomicAdd(db + co0 + col + 0, bsum.x); atomicAdd(db + co0 + col + 1, bsum.y);
+            atomicAdd(db + co0 + col + 2, bsum.z); atomicAdd(db + co0 + col + 3, bsum.w);
+        }
+    }
+}
+
+// OIHW -> [Cin][k*k][Cout] with the taps flipped: Wt[ci][t][co] = W[co][ci][k*k-1-t]
+__global__ void pack_conv_weight_t_kernel(const float* __restrict__ w, float* __restrict__ o, int Cout, int Cin, int taps) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        const size_t t2 = i / Cout;
+        const int t = (int)(t2 % taps);
+        const int ci = (int)(t2 / taps);
+        o[i] = w[((size_t)co * Cin + ci) * taps + (taps - 1 - t)];
+    }
+}
+
+// packed gradient [Cout][taps][Cin] -> += into the OIHW parameter gradient [Cout][Cin][taps]
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ gp, float* __restrict__ g, int Cout, int Cin, int taps,
+                                        int accumulate) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % taps);
+        const size_t t2 = i / taps;
+        const int ci = (int)(t2 % Cin);
+        const int co = (int)(t2 / Cin);
+        const float v = gp[((size_t)co * taps + t) * Cin + ci];
+        g[i] = accumulate ? g[i] + v : v;
+    }
+}
+
+}  // namespace
+
+// dW (packed) += dout^T * f(src); db += colsum(dout).  See the kernel comment for the meaning of the fields.
+extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
+    const int Cin = a->C0 + a->C1;
+    if (a->N <= 0 || a->Cout <= 0 || Cin <= 0 || Cin % 32 || a->C0 % 32) return LFVDM_E_SHAPE;
+    if (a->ksize != 1 && a->ksize != 3) return LFVDM_E_SHAPE;
+    if (!a->res || !a->out || a->ldr < a->Cout || a->ldr % 4 || a->Cout % 4) return LFVDM_E_SHAPE;
+    if (a->C1 > 0 && !a->src1) return LFVDM_E_SHAPE;
+    if ((a->coefA == nullptr) != (a->coefB == nullptr)) return LFVDM_E_SHAPE;
+    const long M = (long)a->N * a->Ho * a->Wo;
+    const int nchunks = (int)((M + 31) / 32);
+    const long tiles = (long)a->ksize * a->ksize * (Cin / 32) * ((a->Cout + 31) / 32);
+    long msplit = (4096 + tiles - 1) / tiles;          // aim at ~4k wave tasks
+    if (msplit > nchunks) msplit = nchunks;
+    if (msplit < 1) msplit = 1;
+    const long ntasks = tiles * msplit;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a,
+                       (int)msplit);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_pack_conv_weight_t(const float* w, float* o, int Cout, int Cin, int ksize, void* stream) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return LFVDM_E_SHAPE;
+    const size_t total = (size_t)Cout * Cin * ksize * ksize;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_weight_t_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, o, Cout, Cin, ksize * ksize);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_unpack_conv_grad(const float* gp, float* g, int Cout, int Cin, int ksize, int accumulate, void* stream) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return LFVDM_E_SHAPE;
+    const size_t total = (size_t)Cout * Cin * ksize * ksize;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gp, g, Cout, Cin,
+                       ksize * ksize, accumulate);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}

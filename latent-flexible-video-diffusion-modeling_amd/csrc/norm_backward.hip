@@ -1,0 +1,273 @@
+// GroupNorm(+FiLM)(+SiLU) backward for the fused "statistics -> affine in the conv operand" scheme, and the
+// temporal GroupNorm backward.  HBM/L2-bound reductions; wave = 64.
+//
+// Forward (norm_embed.hip):  z = x*A + B,  a = act(z),  A = rstd*g',  B = b' - mean*A,  g' = gamma*(1+scale).
+// Given da (gradient w.r.t. a, from the conv data gradient):
+//   dz      = da * act'(z)
+//   s1[n,c] = sum_p dz,          s2[n,c] = sum_p dz * xhat          (xhat = (x-mean)*rstd)
+//   S1[n,g] = sum_{c in g} g'_c s1[n,c],   S2[n,g] = sum_{c in g} g'_c s2[n,c]
+//   dx      = rstd * (g'_c dz - (S1 + xhat*S2) / (cg*P))
+// and the parameter / FiLM gradients are tiny contractions of s1, s2 done by the caller.
+#include "common.cuh"
+
+namespace {
+
+constexpr int GB_GPW = 8;
+constexpr int GB_THREADS = 256;
+
+__device__ __forceinline__ f32x4 ldcat(const float* s0, const float* s1, int C0, int C1, size_t pos, int c) {
+    return c < C0 ? ld4(s0 + pos * C0 + c) : ld4(s1 + pos * C1 + (c - C0));
+}
+
+__device__ __forceinline__ float dsilu(float z) {
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+// pass 1: per-(n, c) sums s1, s2 -> sums[n][c][2]
+__global__ __launch_bounds__(GB_THREADS) void gn_bwd_stats_kernel(
+    const float* __restrict__ da, const float* __restrict__ s0, const float* __restrict__ s1p, int C0, int C1, int P,
+    const float* __restrict__ coefA, const float* __restrict__ coefB, const float* __restrict__ stats, int act,
+    float* __restrict__ sums) {
+    const int C = C0 + C1;
+    const int cg = C / 32;
+    const int CW = GB_GPW * cg;
+    const int Q = CW / 4;
+    const int n = blockIdx.x;
+    const int cbase = blockIdx.y * CW;
+    const int PL = GB_THREADS / Q;
+    const int tid = threadIdx.x;
+    const bool active = tid < PL * Q;
+    const int q = active ? tid % Q : 0;
+    const int pl = active ? tid / Q : 0;
+    const int c = cbase + q * 4;
+    __shared__ float part[2][GB_THREADS * 4];
+
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const f32x4 A = ld4(coefA + (size_t)n * C + c), B = ld4(coefB + (size_t)n * C + c);
+        f32x4 mu, rs;
+        const float* st = stats + (size_t)n * 64;
+        mu.x = st[2 * ((c + 0) / cg)]; rs.x = st[2 * ((c + 0) / cg) + 1];
+        mu.y = st[2 * ((c + 1) / cg)]; rs.y = st[2 * ((c + 1) / cg) + 1];
+        mu.z = st[2 * ((c + 2) / cg)]; rs.z = st[2 * ((c + 2) / cg) + 1];
+        mu.w = st[2 * ((c + 3) / cg)]; rs.w = st[2 * ((c + 3) / cg) + 1];
+        const size_t pos0 = (size_t)n * P;
+        for (int p = pl; p < P; p += PL) {
+            const f32x4 x = ldcat(s0, s1p, C0, C1, pos0 + p, c);
+            f32x4 dz = ld4(da + (pos0 + p) * C + c);
+            if (act == LFVDM_ACT_SILU) {
+                const f32x4 z = x * A + B;
+                dz.x *= dsilu(z.x); dz.y *= dsilu(z.y); dz.z *= dsilu(z.z); dz.w *= dsilu(z.w);
+            }
+            a1 += dz;
+            a2 += dz * ((x - mu) * rs);
+        }
+        st4(part[0] + (pl * Q + q) * 4, a1);
+        st4(part[1] + (pl * Q + q) * 4, a2);
+    }
+    __syncthreads();
+    for (int cc = tid; cc < CW; cc += GB_THREADS) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int i = 0; i < PL; ++i) { t1 += part[0][i * CW + cc]; t2 += part[1][i * CW + cc]; }
+        sums[((size_t)n * C + cbase + cc) * 2 + 0] = t1;
+        sums[((size_t)n * C + cbase + cc) * 2 + 1] = t2;
+    }
+}
+
+// pass 2: dx (split over the two concat destinations, overwrite or accumulate)
+__global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
+    const float* __restrict__ da, const float* __restrict__ s0, const float* __restrict__ s1p, int C0, int C1, int P,
+    const float* __restrict__ coefA, const float* __restrict__ coefB, const float* __restrict__ stats,
+    const float* __restrict__ sums, int act, float* __restrict__ out0, float* __restrict__ out1, int acc0, int acc1) {
+    const int C = C0 + C1;
+    const int cg = C / 32;
+    const int CW = GB_GPW * cg;
+    const int Q = CW / 4;
+    const int n = blockIdx.x;
+    const int cbase = blockIdx.y * CW;
+    const int PL = GB_THREADS / Q;
+    const int tid = threadIdx.x;
+    __shared__ float gS1[GB_GPW], gS2[GB_GPW];
+    if (tid < GB_GPW) {
+        const int g = blockIdx.y * GB_GPW + tid;
+        const float rstd = stats[((size_t)n * 32 + g) * 2 + 1];
+        float S1 = 0.f, S2 = 0.f;
+        for (int i = 0; i < cg; ++i) {
+            const int ch = g * cg + i;
+            const float gp = coefA[(size_t)n * C + ch] / rstd;   // g' = A / rstd (rstd > 0)
+            S1 += gp * sums[((size_t)n * C + ch) * 2 + 0];
+            S2 += gp * sums[((size_t)n * C + ch) * 2 + 1];
+        }
+        const float inv = 1.0f / (float)(cg * P);
+        gS1[tid] = S1 * inv;
+        gS2[tid] = S2 * inv;
+    }
+    __syncthreads();
+    if (tid >= PL * Q) return;
+    const int q = tid % Q, pl = tid / Q;
+    const int c = cbase + q * 4;
+    const f32x4 A = ld4(coefA + (size_t)n * C + c), B = ld4(coefB + (size_t)n * C + c);
+    f32x4 mu, rs, S1, S2;
+    const float* st = stats + (size_t)n * 64;
+#define LFVDM_G(k, f)                                                             \
+    { const int g = (c + k) / cg; mu.f = st[2 * g]; rs.f = st[2 * g + 1];         \
+      S1.f = gS1[g - blockIdx.y * GB_GPW]; S2.f = gS2[g - blockIdx.y * GB_GPW]; }
+    LFVDM_G(0, x) LFVDM_G(1, y) LFVDM_G(2, z) LFVDM_G(3, w)
+#undef LFVDM_G
+    const size_t pos0 = (size_t)n * P;
+    const bool first = c < C0;
+    float* out = first ? out0 : out1;
+    const int Cd = first ? C0 : C1;
+    const int cd = first ? c : c - C0;
+    const int acc = first ? acc0 : acc1;
+    for (int p = pl; p < P; p += PL) {
+        const f32x4 x = ldcat(s0, s1p, C0, C1, pos0 + p, c);
+        f32x4 dz = ld4(da + (pos0 + p) * C + c);
+        if (act == LFVDM_ACT_SILU) {
+            const f32x4 z = x * A + B;
+            dz.x *= dsilu(z.x); dz.y *= dsilu(z.y); dz.z *= dsilu(z.z); dz.w *= dsilu(z.w);
+        }
+        const f32x4 xh = (x - mu) * rs;
+        f32x4 dx = A * dz - rs * (S1 + xh * S2);     // rstd*g'*dz == A*dz
+        float* o = out + (pos0 + p) * Cd + cd;
+        if (acc) dx += ld4(o);
+        st4(o, dx);
+    }
+}
+
+// temporal GroupNorm backward (rpe.py:135-137): sample = (b, pixel), elements [T][C/32-group]; one wave per sample.
+// y = (x-mean)*rstd*gamma + beta.  Writes dx and accumulates dgamma/dbeta with atomics.
+constexpr int GTB_MAXC = 512;
+__global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ gamma, float eps,
+                                                              float* __restrict__ dx, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int B, int T, int P, int C,
+                                                              int accumulate) {
+    __shared__ float ch_all[4][3][GTB_MAXC];
+    __shared__ float gst_all[4][4][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long sample = (long)blockIdx.x * 4 + wave;
+    if (sample >= (long)B * P) return;
+    float* chx = ch_all[wave][0];   // per-channel sums (reused per pass)
+    float* chd = ch_all[wave][1];
+    float* chdx = ch_all[wave][2];
+    float* gmean = gst_all[wave][0];
+    float* grstd = gst_all[wave][1];
+    float* gS1 = gst_all[wave][2];
+    float* gS2 = gst_all[wave][3];
+    const int b = (int)(sample / P), p = (int)(sample % P);
+    const int cg = C / 32;
+    const int Q = C / 4;
+    const size_t base = ((size_t)b * T * P + p) * C;
+    const size_t tstride = (size_t)P * C;
+    const int TL = (Q <= 64 && 64 % Q == 0) ? 64 / Q : 1;
+    const int QL = 64 / TL;
+    const int ql = lane % QL, tl = lane / QL;
+
+    // statistics (two passes) exactly as in the forward
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int q = ql; q < Q; q += QL) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f};
+            if (pass) { mu.x = gmean[(q * 4) / cg]; mu.y = gmean[(q * 4 + 1) / cg]; mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg]; }
+            for (int t = tl; t < T; t += TL) {
+                f32x4 v = ld4(x + base + t * tstride + q * 4);
+                if (pass) { v = v - mu; s += v * v; } else { s += v; }
+            }
+            for (int o = QL; o < 64; o <<= 1) {
+                s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+            }
+            if (tl == 0) st4(chx + q * 4, s);
+        }
+        wave_lds_fence();
+        if (lane < 32) {
+            float t = 0.f;
+            for (int i = 0; i < cg; ++i) t += chx[lane * cg + i];
+            const float inv = 1.0f / (float)(cg * T);
+            if (pass == 0) gmean[lane] = t * inv; else grstd[lane] = 1.0f / sqrtf(t * inv + eps);
+        }
+        wave_lds_fence();
+    }
+    // per-channel sums of dy and dy*xhat
+    for (int q = ql; q < Q; q += QL) {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, mu, rs;
+        mu.x = gmean[(q * 4) / cg]; mu.y = gmean[(q * 4 + 1) / cg]; mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg];
+        rs.x = grstd[(q * 4) / cg]; rs.y = grstd[(q * 4 + 1) / cg]; rs.z = grstd[(q * 4 + 2) / cg]; rs.w = grstd[(q * 4 + 3) / cg];
+        for (int t = tl; t < T; t += TL) {
+            const f32x4 xv = ld4(x + base + t * tstride + q * 4);
+            const f32x4 d = ld4(dy + base + t * tstride + q * 4);
+            s1 += d;
+            s2 += d * ((xv - mu) * rs);
+        }
+        for (int o = QL; o < 64; o <<= 1) {
+            s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+            s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+        }
+        if (tl == 0) { st4(chd + q * 4, s1); st4(chdx + q * 4, s2); }
+    }
+    wave_lds_fence();
+    if (lane < 32) {
+        float S1 = 0.f, S2 = 0.f;
+        for (int i = 0; i < cg; ++i) { const int ch = lane * cg + i; S1 += gamma[ch] * chd[ch]; S2 += gamma[ch] * chdx[ch]; }
+        const float inv = 1.0f / (float)(cg * T);
+        gS1[lane] = S1 * inv; gS2[lane] = S2 * inv;
+    }
+    // parameter gradients: one atomic per (sample, channel)
+    for (int ch = lane; ch < C; ch += 64) {
+        atomicAdd(dgamma + ch, chdx[ch]);
+        atomicAdd(dbeta + ch, chd[ch]);
+    }
+    wave_lds_fence();
+    const int E = T * Q;
+    for (int e = lane; e < E; e += 64) {
+        const int t = e / Q, q = e - t * Q;
+        const f32x4 xv = ld4(x + base + t * tstride + q * 4);
+        const f32x4 d = ld4(dy + base + t * tstride + q * 4);
+        const f32x4 ga = ld4(gamma + q * 4);
+        f32x4 o;
+#define LFVDM_T(k, f)                                                                                   \
+    { const int g = (q * 4 + k) / cg; const float xh = (xv.f - gmean[g]) * grstd[g];                    \
+      o.f = grstd[g] * (ga.f * d.f - (gS1[g] + xh * gS2[g])); }
+        LFVDM_T(0, x) LFVDM_T(1, y) LFVDM_T(2, z) LFVDM_T(3, w)
+#undef LFVDM_T
+        float* dst = dx + base + t * tstride + q * 4;
+        if (accumulate) o += ld4(dst);
+        st4(dst, o);
+    }
+}
+
+}  // namespace
+
+extern "C" int lfvdm_gn_bwd_stats(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                                  const float* coefA, const float* coefB, const float* stats, int act, float* sums,
+                                  void* stream) {
+    const int C = C0 + C1;
+    if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
+                       C0, C1, P, coefA, coefB, stats, act, sums);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_bwd_apply(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                                  const float* coefA, const float* coefB, const float* stats, const float* sums, int act,
+                                  float* out0, float* out1, int acc0, int acc1, void* stream) {
+    const int C = C0 + C1;
+    if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
+    if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
+                       C0, C1, P, coefA, coefB, stats, sums, act, out0, out1, acc0, acc1);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const float* gamma, float eps, float* dx,
+                                     float* dgamma, float* dbeta, int B, int T, int P, int C, int accumulate, void* stream) {
+    if (B <= 0 || T <= 0 || P <= 0 || C % 32 || C > GTB_MAXC) return LFVDM_E_SHAPE;
+    const long samples = (long)B * P;
+    hipLaunchKernelGGL(gn_temporal_bwd_kernel, dim3((unsigned)((samples + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, dy,
+                       gamma, eps, dx, dgamma, dbeta, B, T, P, C, accumulate);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}

@@ -20,7 +20,7 @@ __device__ __forceinline__ f32x4 ld_cat(const float* s0, const float* s1, int C0
 __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
     const float* __restrict__ s0, const float* __restrict__ s1, int C0, int C1, int P,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
-    int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB) {
+    int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats) {
     const int C = C0 + C1;
     const int cg = C / 32;
     const int CW = GN_GPW * cg;       // channels handled here
@@ -68,6 +68,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
             else grstd[tid] = 1.0f / sqrtf(t * inv + eps);
         }
         __syncthreads();
+    }
+    if (stats && tid < GN_GPW) {   // (mean, rstd) per (sample, group) for the backward pass
+        stats[((size_t)n * 32 + blockIdx.y * GN_GPW + tid) * 2 + 0] = gmean[tid];
+        stats[((size_t)n * 32 + blockIdx.y * GN_GPW + tid) * 2 + 1] = grstd[tid];
     }
     for (int cc = tid; cc < CW; cc += GN_THREADS) {
         const int ch = cbase + cc;
@@ -253,17 +257,24 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const lfvdm_rowdot_job* __r
 
 }  // namespace
 
-extern "C" int lfvdm_gn_coef(const float* src0, const float* src1, int C0, int C1, int N, int P, const float* gamma,
-                             const float* beta, const float* film, int film_div, int film_ld, float eps, float* coefA,
-                             float* coefB, void* stream) {
+extern "C" int lfvdm_gn_coef_stats(const float* src0, const float* src1, int C0, int C1, int N, int P, const float* gamma,
+                                   const float* beta, const float* film, int film_div, int film_ld, float eps,
+                                   float* coefA, float* coefB, float* stats, void* stream) {
     const int C = C0 + C1;
     if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
     if (C1 > 0 && !src1) return LFVDM_E_SHAPE;
     if (film && film_div <= 0) return LFVDM_E_SHAPE;
     hipLaunchKernelGGL(gn_coef_kernel, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0, C1,
-                       P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB);
+                       P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_coef(const float* src0, const float* src1, int C0, int C1, int N, int P, const float* gamma,
+                             const float* beta, const float* film, int film_div, int film_ld, float eps, float* coefA,
+                             float* coefB, void* stream) {
+    return lfvdm_gn_coef_stats(src0, src1, C0, C1, N, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, nullptr,
+                               stream);
 }
 
 extern "C" int lfvdm_gn_temporal(const float* x, const float* gamma, const float* beta, float eps, float* y, int B, int T,

@@ -1,0 +1,465 @@
+"""Training path of ``UNetVideoModel``: differentiable blocks on the gfx950 kernels.
+
+Every block below is a ``torch.autograd.Function`` whose forward AND backward run the hand-written
+HIP kernels for the heavy work of the reference's ``loss.backward()`` (train_util.py:328):
+
+  * 3x3 / 1x1 convolutions and the qkv / proj_out linears: forward ``lfvdm_conv_igemm``, data gradient
+    ``lfvdm_conv_igemm`` on transposed-flipped weights (``lfvdm_pack_conv_weight_t``; stride-2 convs use
+    the zero-insertion gather), weight/bias gradient ``lfvdm_conv_wgrad`` (fp32 MFMA, the fused
+    GroupNorm/FiLM/SiLU operand is recomputed on the fly, never stored);
+  * GroupNorm(+FiLM)(+SiLU): ``lfvdm_gn_coef_stats`` forward, ``lfvdm_gn_bwd_stats/apply`` backward;
+    temporal GroupNorm ``lfvdm_gn_temporal(_bwd)``; attention cores forward ``lfvdm_attn_*``.
+
+Round-1 interim (documented in DESIGN.md): the small-M pieces (time-embedding MLP, FiLM projections, RPE
+networks: < 2 % of the FLOPs) and the backward of the two attention CORES run on library batched GEMMs
+(rocBLAS through torch.matmul/einsum) plus elementwise softmax-backward ops; all on the GPU, no CPU path.
+"""
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native as nat
+from .nn import timestep_freqs
+
+_EPS = 1e-5
+
+
+def _new(*shape, like):
+    return th.empty(*shape, device=like.device, dtype=th.float32)
+
+
+# ----------------------------------------------------------------------------- packed weights
+def _pack(w):
+    """OIHW -> [Cout][taps][Cin] (forward operand layout)."""
+    Cout, Cin, k, _ = w.shape
+    out = _new(Cout, k * k, Cin, like=w)
+    nat.pack_conv_weight(w.contiguous(), out)
+    return out
+
+
+def _pack_t(w4):
+    """OIHW (or [O][I] as [O][I][1][1]) -> [Cin][taps][Cout], taps flipped (data-gradient operand)."""
+    Cout, Cin, k, _ = w4.shape
+    out = _new(Cin, k * k, Cout, like=w4)
+    nat.pack_conv_weight_t(w4.contiguous(), out)
+    return out
+
+
+def _wgrad_into(grad_w_shape, like, **kw):
+    """Run lfvdm_conv_wgrad into a zeroed packed buffer and return (dW in the parameter layout, db)."""
+    Cout, Cin = grad_w_shape[0], grad_w_shape[1]
+    k = grad_w_shape[2] if len(grad_w_shape) == 4 else 1
+    kw.pop("ksize", None)
+    gp = th.zeros(Cout, k * k, Cin, device=like.device, dtype=th.float32)
+    db = th.zeros(Cout, device=like.device, dtype=th.float32)
+    nat.conv_wgrad(out=gp, bias=db, Cout=Cout, ksize=k, **kw)
+    if k == 1:
+        return gp.view(grad_w_shape), db
+    g = _new(*grad_w_shape, like=like)
+    nat.unpack_conv_grad(gp, g, accumulate=False)
+    return g, db
+
+
+# ----------------------------------------------------------------------------- plain conv (in / down / up)
+class ConvFn(th.autograd.Function):
+    """3x3 conv on channels-last rows [N*H*W][Cin] with optional stride 2 / nearest-2x upsample
+    (Downsample / Upsample of reference unet.py:60-114)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, N, H, W, stride, up):
+        Cout, Cin = w.shape[0], w.shape[1]
+        Hin, Win = (2 * H, 2 * W) if up else (H, W)
+        Ho, Wo = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
+        out = _new(N * Ho * Wo, Cout, like=x)
+        nat.conv_igemm(src0=x, C0=Cin, N=N, Hs=H, Ws=W, up=int(up), stride=stride, Ho=Ho, Wo=Wo, W=_pack(w), bias=b,
+                       Cout=Cout, out=out, ldo=Cout)
+        ctx.save_for_backward(x, w)
+        ctx.geom = (N, H, W, stride, up, Ho, Wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        N, H, W, stride, up, Ho, Wo = ctx.geom
+        Cout, Cin = w.shape[0], w.shape[1]
+        dout = dout.contiguous()
+        dw, db = _wgrad_into(tuple(w.shape), x, src0=x, C0=Cin, N=N, Hs=H, Ws=W, up=int(up), stride=stride, Ho=Ho, Wo=Wo,
+                             res=dout, ldr=Cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = _pack_t(w)
+            if stride == 2:   # transposed conv: zero-insertion gather of dout on the (2Ho x 2Wo) grid
+                assert 2 * Ho == H and 2 * Wo == W, "stride-2 data gradient needs even sizes"
+                dx = _new(N * H * W, Cin, like=x)
+                nat.conv_igemm(src0=dout, C0=Cout, N=N, Hs=Ho, Ws=Wo, up=2, Ho=H, Wo=W, W=wt, Cout=Cin, out=dx, ldo=Cin)
+            else:
+                Hin, Win = (2 * H, 2 * W) if up else (H, W)
+                dfull = _new(N * Hin * Win, Cin, like=x)
+                nat.conv_igemm(src0=dout, C0=Cout, N=N, Hs=Ho, Ws=Wo, Ho=Hin, Wo=Win, W=wt, Cout=Cin, out=dfull, ldo=Cin)
+                if up:        # adjoint of nearest-2x: sum each 2x2 block
+                    dx = dfull.view(N, H, 2, W, 2, Cin).sum(dim=(2, 4)).reshape(N * H * W, Cin).contiguous()
+                else:
+                    dx = dfull
+        return dx, dw, db, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- linear on rows
+class LinearFn(th.autograd.Function):
+    """y = x W^T + b (+ res) on rows [M][K] (nn.Linear qkv / proj_out, rpe.py:139,171)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res):
+        M, K = x.shape
+        O = w.shape[0]
+        y = _new(M, O, like=x)
+        kw = dict(src0=x, C0=K, N=M, Hs=1, Ws=1, Ho=1, Wo=1, ksize=1, W=w, bias=b, Cout=O, out=y, ldo=O)
+        if res is not None:
+            kw.update(res=res, ldr=O)
+        nat.conv_igemm(**kw)
+        ctx.save_for_backward(x, w)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        M, K = x.shape
+        O = w.shape[0]
+        dy = dy.contiguous()
+        dw, db = _wgrad_into((O, K), x, src0=x, C0=K, N=M, Hs=1, Ws=1, Ho=1, Wo=1, res=dy, ldr=O)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _new(M, K, like=x)
+            nat.conv_igemm(src0=dy, C0=O, N=M, Hs=1, Ws=1, Ho=1, Wo=1, ksize=1, W=_pack_t(w.view(O, K, 1, 1)), Cout=K,
+                           out=dx, ldo=K)
+        return dx, dw, db, (dy if ctx.has_res else None)
+
+
+# ----------------------------------------------------------------------------- GroupNorm helpers
+def _gn_forward(a, b, C0, C1, N, P, gamma, beta, film, T):
+    C = C0 + C1
+    cA, cB, stats = _new(N, C, like=a), _new(N, C, like=a), _new(N, 32, 2, like=a)
+    nat.check(nat.lib().lfvdm_gn_coef_stats(
+        nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(gamma), nat.ptr(beta), nat.ptr(film), T if film is not None else 1,
+        (2 * C) if film is not None else 0, _EPS, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats), nat.stream()), "lfvdm_gn_coef_stats")
+    return cA, cB, stats
+
+
+def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, T, want_dx=(True, True)):
+    """Returns (dx_a, dx_b, dgamma, dbeta, dfilm).  da: [N*P][C] gradient w.r.t. act(GN(x))."""
+    C = C0 + C1
+    sums = _new(N, C, 2, like=da)
+    L = nat.lib()
+    nat.check(L.lfvdm_gn_bwd_stats(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
+                                   act, nat.ptr(sums), nat.stream()), "lfvdm_gn_bwd_stats")
+    dxa = _new(N * P, C0, like=da)
+    dxb = _new(N * P, C1, like=da) if C1 else None
+    nat.check(L.lfvdm_gn_bwd_apply(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
+                                   nat.ptr(sums), act, nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.stream()), "lfvdm_gn_bwd_apply")
+    s1, s2 = sums[..., 0], sums[..., 1]              # [N][C]: sum dz, sum dz*xhat
+    if film is not None:
+        B = N // T
+        sc1 = 1.0 + film[:, :C].repeat_interleave(T, dim=0)   # (1 + scale) per (n, c)
+        dgamma = (s2 * sc1).sum(0)
+        dbeta = (s1 * sc1).sum(0)
+        dscale = (s2 * gamma + s1 * beta).view(B, T, C).sum(1)
+        dshift = s1.view(B, T, C).sum(1)
+        dfilm = th.cat([dscale, dshift], dim=1)
+    else:
+        dgamma, dbeta, dfilm = s2.sum(0), s1.sum(0), None
+    return dxa, dxb, dgamma, dbeta, dfilm
+
+
+# ----------------------------------------------------------------------------- ResBlock
+class ResBlockFn(th.autograd.Function):
+    """reference unet.py:194-207 with use_scale_shift_norm=True, on a virtual concat input (a | b)."""
+
+    @staticmethod
+    def forward(ctx, a, b, film, g1, be1, w1, b1, g2, be2, w2, b2, ws, bs, N, H, W, T):
+        C0 = a.shape[1]
+        C1 = b.shape[1] if b is not None else 0
+        Cin, Cout, P = C0 + C1, w1.shape[0], H * W
+        cA1, cB1, st1 = _gn_forward(a, b, C0, C1, N, P, g1, be1, None, T)
+        h1 = _new(N * P, Cout, like=a)
+        nat.conv_igemm(src0=a, src1=b, C0=C0, C1=C1, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=cA1, coefB=cB1, act=nat.ACT_SILU,
+                       W=_pack(w1), bias=b1, Cout=Cout, out=h1, ldo=Cout)
+        cA2, cB2, st2 = _gn_forward(h1, None, Cout, 0, N, P, g2, be2, film, T)
+        out = _new(N * P, Cout, like=a)
+        kw = dict(src0=h1, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=cA2, coefB=cB2, act=nat.ACT_SILU, W=_pack(w2),
+                  bias=b2, Cout=Cout, out=out, ldo=Cout)
+        if ws is None:
+            kw.update(res=a, ldr=Cout)
+        else:
+            kw.update(s2src0=a, s2src1=b, s2C0=C0, s2C1=C1, W2=ws.view(Cout, Cin), bias2=bs)
+        nat.conv_igemm(**kw)
+        ctx.save_for_backward(a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2)
+        ctx.geom = (N, H, W, T, C0, C1, Cout)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2 = ctx.saved_tensors
+        N, H, W, T, C0, C1, Cout = ctx.geom
+        Cin, P = C0 + C1, H * W
+        dout = dout.contiguous()
+        geo = dict(N=N, Hs=H, Ws=W, Ho=H, Wo=W)
+        # conv2: weight grad on the fused operand act(GN2(h1)), data grad -> da2
+        dw2, db2 = _wgrad_into(tuple(w2.shape), a, src0=h1, C0=Cout, coefA=cA2, coefB=cB2, act=nat.ACT_SILU, res=dout,
+                               ldr=Cout, **geo)
+        da2 = _new(N * P, Cout, like=a)
+        nat.conv_igemm(src0=dout, C0=Cout, W=_pack_t(w2), Cout=Cout, out=da2, ldo=Cout, **geo)
+        dh1, _, dg2, dbe2, dfilm = _gn_backward(da2, h1, None, Cout, 0, N, P, cA2, cB2, st2, nat.ACT_SILU, g2, be2, film, T)
+        # conv1
+        dw1, db1 = _wgrad_into(tuple(w1.shape), a, src0=a, src1=b, C0=C0, C1=C1, coefA=cA1, coefB=cB1, act=nat.ACT_SILU,
+                               res=dh1, ldr=Cout, **geo)
+        da1 = _new(N * P, Cin, like=a)
+        nat.conv_igemm(src0=dh1, C0=Cout, W=_pack_t(w1), Cout=Cin, out=da1, ldo=Cin, **geo)
+        dxa, dxb, dg1, dbe1, _ = _gn_backward(da1, a, b, C0, C1, N, P, cA1, cB1, st1, nat.ACT_SILU, g1, be1, None, T)
+        # skip path
+        dws = dbs = None
+        if ws is None:
+            dxa = dxa + dout
+        else:
+            dws, dbs = _wgrad_into((Cout, Cin, 1, 1), a, src0=a, src1=b, C0=C0, C1=C1, ksize=1, res=dout, ldr=Cout, **geo)
+            dsk = _new(N * P, Cin, like=a)
+            nat.conv_igemm(src0=dout, C0=Cout, ksize=1, W=_pack_t(ws), Cout=Cin, out=dsk, ldo=Cin, **geo)
+            dxa = dxa + dsk[:, :C0]
+            if dxb is not None:
+                dxb = dxb + dsk[:, C0:]
+        return (dxa, dxb, dfilm, dg1, dbe1, dw1, db1, dg2, dbe2, dw2, db2, dws, dbs, None, None, None, None)
+
+
+# ----------------------------------------------------------------------------- output head
+class HeadFn(th.autograd.Function):
+    """out = conv3x3(SiLU(GN(h))) written in the (B,T,C,H,W) frame layout (reference unet.py:399-403,462-464)."""
+
+    @staticmethod
+    def forward(ctx, h, g, be, w, b, N, H, W):
+        C, Cout, P = h.shape[1], w.shape[0], H * W
+        cA, cB, st = _gn_forward(h, None, C, 0, N, P, g, be, None, 1)
+        out = _new(N, Cout, H, W, like=h)
+        nat.conv_igemm(src0=h, C0=C, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=cA, coefB=cB, act=nat.ACT_SILU, W=_pack(w), bias=b,
+                       Cout=Cout, out=out, ldo=Cout, out_mode=nat.OUT_NCHW)
+        ctx.save_for_backward(h, g, be, w, cA, cB, st)
+        ctx.geom = (N, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, g, be, w, cA, cB, st = ctx.saved_tensors
+        N, H, W = ctx.geom
+        C, Cout, P = h.shape[1], w.shape[0], H * W
+        # rows [M][32]: the data-gradient GEMM reduces over Cout, padded to one 32-channel chunk
+        CP = (Cout + 31) // 32 * 32
+        drows = th.zeros(N * P, CP, device=h.device, dtype=th.float32)
+        drows[:, :Cout] = dout.permute(0, 2, 3, 1).reshape(N * P, Cout)
+        geo = dict(N=N, Hs=H, Ws=W, Ho=H, Wo=W)
+        gp = th.zeros(CP, 9, C, device=h.device, dtype=th.float32)
+        dbp = th.zeros(CP, device=h.device, dtype=th.float32)
+        nat.conv_wgrad(src0=h, C0=C, coefA=cA, coefB=cB, act=nat.ACT_SILU, res=drows, ldr=CP, out=gp, bias=dbp, Cout=CP, **geo)
+        dw = gp[:Cout].view(Cout, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+        wt = th.zeros(C, 9, CP, device=h.device, dtype=th.float32)      # Wt[ci][t][co] = W[co][ci][8-t]
+        wt[:, :, :Cout] = w.flip(2, 3).reshape(Cout, C, 9).permute(1, 2, 0)
+        da = _new(N * P, C, like=h)
+        nat.conv_igemm(src0=drows, C0=CP, W=wt, Cout=C, out=da, ldo=C, **geo)
+        dh, _, dg, dbe, _ = _gn_backward(da, h, None, C, 0, N, P, cA, cB, st, nat.ACT_SILU, g, be, None, 1)
+        return dh, dg, dbe, dw, dbp[:Cout].clone(), None, None, None
+
+
+# ----------------------------------------------------------------------------- attention
+def _temporal_core_torch(qkv, Rq, Rk, Rv, mask, B, T, P, C, heads):
+    """Differentiable restatement of rpe.py:143-169 on device (used for the core's backward only)."""
+    Fh = C // heads
+    scale = Fh ** -0.5
+    x = qkv.view(B, T, P, 3, heads, Fh).permute(3, 0, 2, 4, 1, 5)   # 3, B, P, H, T, F
+    q, k, v = x[0] * scale, x[1], x[2]
+    logits = q @ k.transpose(-1, -2)
+    logits = logits + th.einsum("bdhtf,btshf->bdhts", q, Rk.view(B, T, T, heads, Fh))
+    logits = logits + th.einsum("bdhtf,btshf->bdhts", k * scale, Rq.view(B, T, T, heads, Fh)).transpose(-1, -2)
+    if mask is not None:
+        m = mask.view(B, T)
+        same = m[:, None, :] * m[:, :, None] + (1 - m[:, None, :]) * (1 - m[:, :, None])
+        logits = logits.masked_fill((same == 0).view(B, 1, 1, T, T), float("-inf"))
+    attn = th.softmax(logits, dim=-1)
+    out = attn @ v + th.einsum("bdhts,btshf->bdhtf", attn, Rv.view(B, T, T, heads, Fh))
+    return out.permute(0, 3, 1, 2, 4).reshape(B * T * P, C)          # rows (b,t,p), channels (h,f)
+
+
+class TemporalAttnFn(th.autograd.Function):
+    """x -> GN_t(x) + proj(attn_rpe(qkv(GN_t(x))))   (reference rpe.py:133-174, temporal instance)."""
+
+    @staticmethod
+    def forward(ctx, x, gn_w, gn_b, wqkv, bqkv, wproj, bproj, Rq, Rk, Rv, mask, B, T, P, heads):
+        C = x.shape[1]
+        M = B * T * P
+        xn = th.empty_like(x)
+        nat.gn_temporal(x, gn_w, gn_b, _EPS, xn, B, T, P, C)
+        qkv = _new(M, 3 * C, like=x)
+        nat.conv_igemm(src0=xn, C0=C, N=M, Hs=1, Ws=1, Ho=1, Wo=1, ksize=1, W=wqkv, bias=bqkv, Cout=3 * C, out=qkv, ldo=3 * C)
+        o = _new(M, C, like=x)
+        nat.attn_temporal(qkv, Rq, Rk, Rv, mask, o, None, B, T, P, C, heads)
+        y = _new(M, C, like=x)
+        nat.conv_igemm(src0=o, C0=C, N=M, Hs=1, Ws=1, Ho=1, Wo=1, ksize=1, W=wproj, bias=bproj, Cout=C, res=xn, ldr=C, out=y,
+                       ldo=C)
+        ctx.save_for_backward(x, gn_w, wqkv, wproj, Rq, Rk, Rv, mask, xn, qkv, o)
+        ctx.geom = (B, T, P, heads)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gn_w, wqkv, wproj, Rq, Rk, Rv, mask, xn, qkv, o = ctx.saved_tensors
+        B, T, P, heads = ctx.geom
+        C = x.shape[1]
+        M = B * T * P
+        dy = dy.contiguous()
+        one = dict(N=M, Hs=1, Ws=1, Ho=1, Wo=1)
+        dwp, dbp = _wgrad_into((C, C), x, src0=o, C0=C, res=dy, ldr=C, **one)
+        do = _new(M, C, like=x)
+        nat.conv_igemm(src0=dy, C0=C, ksize=1, W=_pack_t(wproj.view(C, C, 1, 1)), Cout=C, out=do, ldo=C, **one)
+        # attention core backward (interim: recompute on batched library GEMMs)
+        with th.enable_grad():
+            qkv_ = qkv.detach().requires_grad_(True)
+            Rs = [r.detach().requires_grad_(True) for r in (Rq, Rk, Rv)]
+            o_ = _temporal_core_torch(qkv_, Rs[0], Rs[1], Rs[2], mask, B, T, P, C, heads)
+            dqkv, dRq, dRk, dRv = th.autograd.grad(o_, [qkv_] + Rs, do)
+        dqkv = dqkv.contiguous()
+        dwq, dbq = _wgrad_into((3 * C, C), x, src0=xn, C0=C, res=dqkv, ldr=3 * C, **one)
+        dxn = _new(M, C, like=x)
+        nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
+                       ldo=C, **one)
+        dx = th.empty_like(x)
+        dg, db = th.zeros(C, device=x.device), th.zeros(C, device=x.device)
+        nat.check(nat.lib().lfvdm_gn_temporal_bwd(nat.ptr(x), nat.ptr(dxn), nat.ptr(gn_w), _EPS, nat.ptr(dx), nat.ptr(dg),
+                                                  nat.ptr(db), B, T, P, C, 0, nat.stream()), "lfvdm_gn_temporal_bwd")
+        return dx, dg, db, dwq, dbq, dwp, dbp, dRq, dRk, dRv, None, None, None, None, None
+
+
+class SpatialAttnFn(th.autograd.Function):
+    """x -> GN_s(x) + proj(attn(qkv(GN_s(x)))) over the H*W tokens of each frame (rpe.py:133-174, spatial)."""
+
+    @staticmethod
+    def forward(ctx, x, gn_w, gn_b, wqkv, bqkv, wproj, bproj, N, P, heads):
+        C = x.shape[1]
+        M = N * P
+        cA, cB, st = _gn_forward(x, None, C, 0, N, P, gn_w, gn_b, None, 1)
+        qkv = _new(M, 3 * C, like=x)
+        nat.conv_igemm(src0=x, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=cA, coefB=cB, W=wqkv, bias=bqkv, Cout=3 * C,
+                       out=qkv, ldo=3 * C)
+        o = _new(M, C, like=x)
+        nat.attn_spatial(qkv, o, None, N, P, C, heads)
+        y = _new(M, C, like=x)
+        nat.conv_igemm(src0=o, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=wproj, bias=bproj, Cout=C, res=x, ldr=C, resA=cA,
+                       resB=cB, out=y, ldo=C)
+        ctx.save_for_backward(x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o)
+        ctx.geom = (N, P, heads)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o = ctx.saved_tensors
+        N, P, heads = ctx.geom
+        C = x.shape[1]
+        M, Fh = N * P, C // heads
+        dy = dy.contiguous()
+        geo = dict(N=N, Hs=P, Ws=1, Ho=P, Wo=1)
+        dwp, dbp = _wgrad_into((C, C), x, src0=o, C0=C, ksize=1, res=dy, ldr=C, **geo)
+        do = _new(M, C, like=x)
+        nat.conv_igemm(src0=dy, C0=C, ksize=1, W=_pack_t(wproj.view(C, C, 1, 1)), Cout=C, out=do, ldo=C, **geo)
+        # core backward (interim): S, P recomputed with batched library GEMMs
+        q, k, v = (t.permute(0, 2, 1, 3) for t in qkv.view(N, P, 3, heads, Fh).unbind(2))   # N, H, P, F
+        scale = Fh ** -0.5
+        dO = do.view(N, P, heads, Fh).permute(0, 2, 1, 3)
+        attn = th.softmax((q * scale) @ k.transpose(-1, -2), dim=-1)
+        dv = attn.transpose(-1, -2) @ dO
+        dP = dO @ v.transpose(-1, -2)
+        dS = attn * (dP - (attn * dP).sum(-1, keepdim=True))
+        dq = (dS @ k) * scale
+        dk = dS.transpose(-1, -2) @ (q * scale)
+        dqkv = th.stack([dq, dk, dv], dim=0).permute(1, 3, 0, 2, 4).reshape(M, 3 * C).contiguous()
+        dwq, dbq = _wgrad_into((3 * C, C), x, src0=x, C0=C, ksize=1, coefA=cA, coefB=cB, res=dqkv, ldr=3 * C, **geo)
+        dxn = _new(M, C, like=x)   # gradient w.r.t. the normalised tensor: qkv path + residual
+        nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
+                       ldo=C, **geo)
+        dx, _, dg, db, _ = _gn_backward(dxn, x, None, C, 0, N, P, cA, cB, st, nat.ACT_NONE, gn_w, gn_b, None, 1)
+        return dx, dg, db, dwq, dbq, dwp, dbp, None, None, None
+
+
+# ----------------------------------------------------------------------------- whole network
+def _rpe_R(net, temb_b, rel, B, T):
+    """RPENet (rpe.py:20-31) on device; tiny, stays on library ops in the training path."""
+    relf = rel.to(th.float32)
+    feats = th.stack([th.log1p(relf.clamp(min=0)), th.log1p((-relf).clamp(min=0)), (rel == 0).to(th.float32)], dim=-1)
+    hid = net.embed_diffusion_time(temb_b).view(B, 1, 1, -1) + net.embed_distances(feats)
+    return net.out(F.silu(hid)).contiguous()       # B, T, T, C
+
+
+class UNetFunction:
+    """Differentiable forward of the whole U-Net in training mode (same math as ``_engine.Plan``)."""
+
+    @staticmethod
+    def run(engine, x, x0, timesteps, frame_indices, obs_mask, latent_mask, return_attn_weights):
+        from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
+        m = engine.model
+        if return_attn_weights:
+            raise NotImplementedError("attention maps are only produced in no-grad (sampling/logging) mode")
+        B, T, Cx, H, W = x.shape
+        N = B * T
+        ch = m.model_channels
+        obs = obs_mask.reshape(B, T, 1, 1, 1).to(th.float32)
+        mask = (obs_mask.reshape(B, T) + latent_mask.reshape(B, T)).clamp(max=1).to(th.float32).contiguous()
+        # --- embeddings (per batch element: rows of the reference's (B*T, 4ch) emb are equal within b)
+        freqs = timestep_freqs(ch).to(x.device)
+        args = timesteps.to(th.float32)[:, None] * freqs[None]
+        temb = th.cat([th.cos(args), th.sin(args)], dim=-1)
+        emb = m.time_embed[2](F.silu(m.time_embed[0](temb)))            # (B, 4ch)
+        semb = F.silu(emb)
+        rel = frame_indices.unsqueeze(-1) - frame_indices.unsqueeze(-2)
+        # --- input compositing + first conv (reference unet.py:441-450): 5 -> 32 zero-padded channels
+        comp = th.cat([x * (1 - obs) + x0 * obs, th.ones_like(x[:, :, :1]) * obs], dim=2)
+        rows = th.zeros(N * H * W, 32, device=x.device, dtype=th.float32)
+        rows[:, :Cx + 1] = comp.reshape(N, Cx + 1, H, W).permute(0, 2, 3, 1).reshape(N * H * W, Cx + 1)
+        conv0 = m.input_blocks[0][0]
+        w0 = F.pad(conv0.weight, (0, 0, 0, 0, 0, 32 - (Cx + 1)))
+        h = ConvFn.apply(rows, w0, conv0.bias, N, H, W, 1, False)
+        cur = (h, H, W)
+        hs = [cur]
+
+        def stage(blk, cur, skip=None):
+            h, Hc, Wc = cur
+            b = skip
+            for layer in blk:
+                if isinstance(layer, ResBlock):
+                    film = layer.emb_layers[1](semb)
+                    sk = layer.skip_connection
+                    ws, bs = (None, None) if isinstance(sk, nn.Identity) else (sk.weight, sk.bias)
+                    h = ResBlockFn.apply(h, b, film, layer.in_layers[0].weight, layer.in_layers[0].bias,
+                                         layer.in_layers[2].weight, layer.in_layers[2].bias, layer.out_layers[0].weight,
+                                         layer.out_layers[0].bias, layer.out_layers[3].weight, layer.out_layers[3].bias,
+                                         ws, bs, N, Hc, Wc, T)
+                    b = None
+                elif isinstance(layer, FactorizedAttentionBlock):
+                    ta, sa = layer.temporal_attention, layer.spatial_attention
+                    R = [_rpe_R(r.rpe_net, emb, rel, B, T) for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v)]
+                    h = TemporalAttnFn.apply(h, ta.norm.weight, ta.norm.bias, ta.qkv.weight, ta.qkv.bias, ta.proj_out.weight,
+                                             ta.proj_out.bias, R[0], R[1], R[2], mask, B, T, Hc * Wc, layer.num_heads)
+                    h = SpatialAttnFn.apply(h, sa.norm.weight, sa.norm.bias, sa.qkv.weight, sa.qkv.bias, sa.proj_out.weight,
+                                            sa.proj_out.bias, N, Hc * Wc, layer.num_heads)
+                elif isinstance(layer, Downsample):
+                    h = ConvFn.apply(h, layer.op.weight, layer.op.bias, N, Hc, Wc, 2, False)
+                    Hc, Wc = Hc // 2, Wc // 2
+                elif isinstance(layer, Upsample):
+                    h = ConvFn.apply(h, layer.conv.weight, layer.conv.bias, N, Hc, Wc, 1, True)
+                    Hc, Wc = 2 * Hc, 2 * Wc
+                else:
+                    raise NotImplementedError(type(layer))
+            return (h, Hc, Wc)
+
+        for blk in list(m.input_blocks)[1:]:
+            cur = stage(blk, cur)
+            hs.append(cur)
+        cur = stage(m.middle_block, cur)
+        for blk in m.output_blocks:
+            cur = stage(blk, cur, skip=hs.pop()[0])
+        h, Hc, Wc = cur
+        out = HeadFn.apply(h, m.out[0].weight, m.out[0].bias, m.out[2].weight, m.out[2].bias, N, Hc, Wc)
+        return out.view(B, T, m.out_channels, H, W), None

@@ -50,8 +50,15 @@ _SIGS = {
     "lfvdm_conv_igemm": ([C.POINTER(ConvArgs), c_fp], c_i),
     "lfvdm_conv_igemm_config": ([C.POINTER(ConvArgs), C.POINTER(c_i), C.POINTER(c_i)], c_i),
     "lfvdm_pack_conv_weight": ([c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_conv_wgrad": ([C.POINTER(ConvArgs), c_fp], c_i),
+    "lfvdm_pack_conv_weight_t": ([c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_unpack_conv_grad": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_conv_in": ([c_fp] * 6 + [c_i] * 5 + [c_fp], c_i),
     "lfvdm_gn_coef": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp], c_i),
+    "lfvdm_gn_coef_stats": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp, c_fp], c_i),
+    "lfvdm_gn_bwd_stats": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp], c_i),
+    "lfvdm_gn_bwd_apply": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp], c_i),
+    "lfvdm_gn_temporal_bwd": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_temporal": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rowdot": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_nets": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
@@ -122,6 +129,37 @@ def conv_igemm(**kw):
     a.res = ptr(kw.get("res")); a.ldr = kw.get("ldr", kw["Cout"]); a.resA = ptr(kw.get("resA")); a.resB = ptr(kw.get("resB"))
     a.out = ptr(kw["out"]); a.ldo = kw["ldo"]; a.out_mode = kw.get("out_mode", OUT_ROWS)
     check(lib().lfvdm_conv_igemm(C.byref(a), stream()), "lfvdm_conv_igemm")
+
+
+def fill_conv_args(**kw):
+    """ConvArgs from keyword tensors/ints (same keys as conv_igemm)."""
+    a = ConvArgs()
+    g = kw.get
+    a.src0 = ptr(kw["src0"]); a.src1 = ptr(g("src1")); a.C0 = kw["C0"]; a.C1 = g("C1", 0)
+    a.N = kw["N"]; a.Hs = kw["Hs"]; a.Ws = kw["Ws"]; a.up = g("up", 0); a.stride = g("stride", 1)
+    a.ksize = g("ksize", 3); a.Ho = kw["Ho"]; a.Wo = kw["Wo"]
+    a.coefA = ptr(g("coefA")); a.coefB = ptr(g("coefB")); a.act = g("act", ACT_NONE)
+    a.W = ptr(g("W")); a.bias = ptr(g("bias")); a.Cout = kw["Cout"]
+    a.s2src0 = ptr(g("s2src0")); a.s2src1 = ptr(g("s2src1")); a.s2C0 = g("s2C0", 0); a.s2C1 = g("s2C1", 0)
+    a.W2 = ptr(g("W2")); a.bias2 = ptr(g("bias2"))
+    a.res = ptr(g("res")); a.ldr = g("ldr", kw["Cout"]); a.resA = ptr(g("resA")); a.resB = ptr(g("resB"))
+    a.out = ptr(kw["out"]); a.ldo = g("ldo", kw["Cout"]); a.out_mode = g("out_mode", OUT_ROWS)
+    return a
+
+
+def conv_wgrad(**kw):
+    """Weight/bias gradient launch; kw as conv_igemm plus res=dout rows, out=packed dW, bias=db."""
+    check(lib().lfvdm_conv_wgrad(C.byref(fill_conv_args(**kw)), stream()), "lfvdm_conv_wgrad")
+
+
+def pack_conv_weight_t(w, out):
+    Cout, Cin, k = w.shape[0], w.shape[1], (w.shape[2] if w.dim() == 4 else 1)
+    check(lib().lfvdm_pack_conv_weight_t(ptr(w), ptr(out), Cout, Cin, k, stream()), "lfvdm_pack_conv_weight_t")
+
+
+def unpack_conv_grad(gp, g, accumulate):
+    Cout, Cin, k = g.shape[0], g.shape[1], (g.shape[2] if g.dim() == 4 else 1)
+    check(lib().lfvdm_unpack_conv_grad(ptr(gp), ptr(g), Cout, Cin, k, int(bool(accumulate)), stream()), "lfvdm_unpack_conv_grad")
 
 
 def conv_igemm_struct(a):
