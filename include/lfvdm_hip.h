@@ -226,6 +226,27 @@ int lfvdm_p_sample(const float* x, const float* eps, const float* noise, const i
 int lfvdm_masked_mse(const float* a, const float* b, const float* mask, float* out, int B, int T,
                      int frame_inner, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Fused AdamW + EMA + gradient-norm over one flat fp32 arena (train_util.py:346-357, nn.py:55-65).
+ * torch.optim.AdamW semantics (decoupled weight decay, bias correction); ema <- rate*ema + (1-rate)*p.
+ * ------------------------------------------------------------------------------------- */
+typedef struct lfvdm_adamw_args {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    float* ema[4];
+    float ema_rate[4];
+    int32_t n_ema;
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay;
+    float bias_corr1, bias_corr2_sqrt; /* 1 - beta1^t, sqrt(1 - beta2^t) */
+    float grad_scale;                  /* applied to g first (1/world_size after a SUM all-reduce) */
+    float* grad_sqsum;                 /* optional: += sum (grad_scale*g)^2 */
+} lfvdm_adamw_args;
+
+int lfvdm_adamw_ema(const lfvdm_adamw_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

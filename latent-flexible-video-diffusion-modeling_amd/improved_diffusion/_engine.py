@@ -299,7 +299,9 @@ class Plan:
 
     # ------------------------------------------------------------------ run
     def weight_signature(self):
-        return tuple(w._version for w, _ in self.packs)
+        # parameter versions catch torch-side in-place updates (optimizers, load_state_dict); the engine
+        # epoch is bumped explicitly by code that rewrites parameters through raw pointers (fused AdamW)
+        return (self.engine.epoch,) + tuple(w._version for w, _ in self.packs)
 
     def refresh_weights(self):
         """(Re)pack the OIHW conv weights into the [Cout][tap][Cin] layout the kernels read."""
@@ -337,6 +339,7 @@ class Engine:
         nat.lib()  # fail loudly if the native library is missing
         self.model = model
         self.plans = {}
+        self.epoch = 0
         for p in model.parameters():
             if p.dtype != th.float32:
                 raise RuntimeError("the native path is fp32 (use_fp16 is off in the reference defaults)")
@@ -353,8 +356,8 @@ class Engine:
         return pl
 
     def invalidate(self):
-        for pl in self.plans.values():
-            pl._sig = None
+        """Parameters were rewritten behind torch's back: repack the conv weights on next use."""
+        self.epoch += 1
 
     def forward(self, x, x0, timesteps, frame_indices, obs_mask, latent_mask, return_attn_weights=False):
         B, T, Cx, H, W = x.shape

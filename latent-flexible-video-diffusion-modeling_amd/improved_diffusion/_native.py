@@ -34,6 +34,13 @@ class ConvArgs(C.Structure):
     ]
 
 
+class AdamWArgs(C.Structure):
+    _fields_ = [("p", c_fp), ("g", c_fp), ("m", c_fp), ("v", c_fp), ("ema", c_fp * 4), ("ema_rate", C.c_float * 4),
+                ("n_ema", C.c_int32), ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("weight_decay", C.c_float), ("bias_corr1", C.c_float), ("bias_corr2_sqrt", C.c_float),
+                ("grad_scale", C.c_float), ("grad_sqsum", c_fp)]
+
+
 class RowdotJob(C.Structure):
     _fields_ = [("W", c_fp), ("b", c_fp), ("inp", c_fp), ("out", c_fp), ("K", C.c_int32), ("O", C.c_int32),
                 ("M", C.c_int32), ("ldin", C.c_int32), ("ldout", C.c_int32), ("in_mode", C.c_int32),
@@ -64,6 +71,7 @@ _SIGS = {
     "lfvdm_rpe_nets": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_attn_spatial": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_attn_temporal": ([c_fp] * 7 + [c_i] * 5 + [c_fp], c_i),
+    "lfvdm_adamw_ema": ([C.POINTER(AdamWArgs), c_fp], c_i),
     "lfvdm_q_sample": ([c_fp] * 6 + [c_i, c_i, c_fp], c_i),
     "lfvdm_p_sample": ([c_fp] * 9 + [c_i] + [c_fp] * 3 + [c_i, c_i, c_fp], c_i),
     "lfvdm_masked_mse": ([c_fp] * 4 + [c_i, c_i, c_i, c_fp], c_i),

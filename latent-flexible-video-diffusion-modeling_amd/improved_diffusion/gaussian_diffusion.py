@@ -301,7 +301,7 @@ class GaussianDiffusion:
     def _graph_sampler(self, unet, shape, clip_denoised):
         key = (id(unet), shape, bool(clip_denoised))
         s = self._samplers.get(key)
-        if s is None or s.unet is not unet:
+        if s is None or s.unet is not unet or s.engine is not unet.native_engine():
             s = GraphSampler(self, unet, shape, clip_denoised)
             self._samplers = {key: s}  # keep one (graphs pin device memory)
         return s
@@ -378,7 +378,8 @@ class GraphSampler:
         from ._engine import Plan
         # a private plan: the sampler's state lives in its static buffers, so it must not be shared
         # with eager model() calls on the same shape
-        self.plan = Plan(unet.native_engine(), B, T, H, W, False)
+        self.engine = unet.native_engine()
+        self.plan = Plan(self.engine, B, T, H, W, False)
         self.plan.refresh_weights()
         dev = self.plan.dev
         self.tb = diffusion.tables(dev)

@@ -1,0 +1,493 @@
+"""Training loop with the reference's interface (train_util.py) on the MI355X-native path.
+
+Differences from the reference, all below the public surface:
+  * parameters, gradients, Adam moments and EMA copies each live in ONE flat fp32 arena
+    (``ParamArena``); ``model.parameters()`` are views into it, so checkpoints/state-dicts are unchanged;
+  * data parallelism = one process per GPU, ONE RCCL all-reduce of the gradient arena per optimizer
+    step (after the last micro-batch; the reference gets the same effect from DDP + ``no_sync``,
+    train_util.py:116-125,309-313), preceded by one broadcast of the parameter arena from rank 0;
+  * ``optimize_normal`` is one fused HIP launch: AdamW + every EMA rate + the gradient norm
+    (reference: per-tensor optimizer ops, 2 launches per tensor per EMA rate, 390 ``.item()`` syncs);
+  * loss logging does one device->host copy per step instead of one per key and batch element.
+"""
+import copy
+import functools
+import glob
+import math
+import os
+from pathlib import Path
+from time import time
+
+import numpy as np
+import torch as th
+import torch.distributed as dist
+
+from . import dist_util
+from . import _native as nat
+from .logger import logger
+from .fp16_util import zero_grad  # noqa: F401  (reference API)
+from .nn import update_ema  # noqa: F401  (reference API)
+from .resample import LossAwareSampler, UniformSampler
+from .rng_util import rng_decorator, RNG
+
+try:
+    import wandb
+except ImportError:  # optional
+    wandb = None
+
+INITIAL_LOG_LOSS_SCALE = 20.0
+
+
+class ParamArena:
+    """Flat fp32 storage for a list of parameters: ``p.data`` and ``p.grad`` become views of two
+    contiguous buffers (named_parameters order), which gives one collective per step, one fused
+    optimizer launch and a memset for zero_grad."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        dev = self.params[0].device
+        self.sizes = [p.numel() for p in self.params]
+        # 16-byte aligned slots so that every parameter view stays float4-addressable for the kernels
+        self.offsets, off = [], 0
+        for n in self.sizes:
+            self.offsets.append(off)
+            off += (n + 3) // 4 * 4
+        self.numel = off
+        self.p = th.zeros(off, device=dev, dtype=th.float32)
+        self.g = th.zeros(off, device=dev, dtype=th.float32)
+        with th.no_grad():
+            for p, o, n in zip(self.params, self.offsets, self.sizes):
+                self.p[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.p[o:o + n].view(p.shape)
+                p.grad = self.g[o:o + n].view(p.shape)
+
+    def views(self, flat):
+        return [flat[o:o + n].view(p.shape) for p, o, n in zip(self.params, self.offsets, self.sizes)]
+
+    def zero_grad(self):
+        self.g.zero_()
+        for p, o, n in zip(self.params, self.offsets, self.sizes):
+            if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:
+                p.grad = self.g[o:o + n].view(p.shape)
+
+
+class TrainLoop:
+    def __init__(self, *, model, diffusion, data, batch_size, microbatch, lr, ema_rate, log_interval, save_interval,
+                 resume_checkpoint, use_fp16, diffusion_space_kwargs, fp16_scale_growth, schedule_sampler, weight_decay,
+                 lr_anneal_steps, sample_interval, pad_with_random_frames, max_frames, enc_dec_chunk_size, args):
+        if use_fp16:
+            raise NotImplementedError("use_fp16 is off in the reference defaults; the native path is fp32")
+        self.args = args
+        self.model = model
+        self.diffusion = diffusion
+        self.data = data
+        self.batch_size = batch_size
+        self.microbatch = microbatch if microbatch > 0 else batch_size
+        self.lr = lr
+        self.ema_rate = [ema_rate] if isinstance(ema_rate, float) else [float(x) for x in ema_rate.split(",")]
+        self.log_interval = log_interval
+        self.save_interval = save_interval
+        self.resume_checkpoint = resume_checkpoint
+        self.use_fp16 = use_fp16
+        self.fp16_scale_growth = fp16_scale_growth
+        self.diffusion_space_kwargs = diffusion_space_kwargs
+        self.schedule_sampler = schedule_sampler or UniformSampler(diffusion)
+        self.weight_decay = weight_decay
+        self.lr_anneal_steps = lr_anneal_steps
+        self.sample_interval = sample_interval
+        self.pad_with_random_frames = pad_with_random_frames
+        self.enc_dec_chunk_size = enc_dec_chunk_size
+        with RNG(0):
+            vis_batch = next(self.data)[0][:2]
+            self.vis_batch = self.encode(vis_batch).to(vis_batch.device)
+        self.max_frames = max_frames
+
+        self.step = 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.global_batch = self.batch_size * self.world
+        self.lg_loss_scale = INITIAL_LOG_LOSS_SCALE
+        self.sync_cuda = th.cuda.is_available()
+
+        self._load_and_sync_parameters()
+        self.model_params = list(self.model.parameters())
+        self.master_params = self.model_params
+        self.arena = ParamArena(self.model_params)
+        if hasattr(self.model, "_engine"):
+            self.model._engine = None          # parameter storage moved: drop cached device pointers
+        dev = self.arena.p.device
+        self.exp_avg = th.zeros_like(self.arena.p)
+        self.exp_avg_sq = th.zeros_like(self.arena.p)
+        self.opt_step = 0
+        self.betas, self.adam_eps = (0.9, 0.999), 1e-8
+        self.opt = _ArenaAdamW(self)          # state_dict()/load_state_dict() in torch.optim.AdamW format
+        if getattr(self.args, "resume_id", "") != "":
+            self._load_optimizer_state()
+            ema_lists = [self._load_ema_parameters(rate) for rate in self.ema_rate]
+        else:
+            ema_lists = [None for _ in self.ema_rate]
+        self.ema_flat = []
+        for lst in ema_lists:
+            flat = self.arena.p.clone()
+            if lst is not None:
+                for v, src in zip(self.arena.views(flat), lst):
+                    v.copy_(src)
+            self.ema_flat.append(flat)
+        self.ema_params = [self.arena.views(f) for f in self.ema_flat]
+        self.grad_sqsum = th.zeros(1, device=dev)
+
+        self.use_ddp = self.world > 1
+        self.ddp_model = self.model            # gradient averaging is done on the arena (see optimize_normal)
+        if self.use_ddp:
+            dist.broadcast(self.arena.p, 0)    # same initial replica everywhere (DDP does this at construction)
+            for f in self.ema_flat:
+                dist.broadcast(f, 0)
+        if self.rank == 0:
+            logger.logkv("num_parameters", sum(p.numel() for p in model.parameters()), distributed=False)
+
+    # ------------------------------------------------------------------ checkpoints (resume)
+    def _load_and_sync_parameters(self):
+        ckpt = find_resume_checkpoint(self.args) or self.resume_checkpoint
+        if ckpt:
+            self.step = parse_resume_step_from_filename(ckpt)
+            print(f"loading model from checkpoint: {ckpt}...")
+            self.model.load_state_dict(dist_util.load_state_dict(ckpt, map_location=dist_util.dev())["state_dict"])
+
+    def _load_ema_parameters(self, rate):
+        main = find_resume_checkpoint(self.args) or self.resume_checkpoint
+        ema_ckpt = find_ema_checkpoint(main, self.step, rate)
+        if ema_ckpt:
+            print(f"loading EMA from checkpoint: {ema_ckpt}...")
+            sd = dist_util.load_state_dict(ema_ckpt, map_location=dist_util.dev())["state_dict"]
+            return self._state_dict_to_master_params(sd)
+        return None
+
+    def _load_optimizer_state(self):
+        main = find_resume_checkpoint(self.args) or self.resume_checkpoint
+        if not main:
+            return
+        path = os.path.join(os.path.dirname(main), f"opt{self.step:06}.pt")
+        if os.path.exists(path):
+            print(f"loading optimizer state from checkpoint: {path}")
+            self.opt.load_state_dict(dist_util.load_state_dict(path, map_location=dist_util.dev()))
+
+    # ------------------------------------------------------------------ training-batch construction (host)
+    def sample_some_indices(self, max_indices, T):
+        """A random arithmetic-ish progression of <= max_indices frame indices in [0, T)
+        (reference train_util.py:180-191; same sequence of random draws)."""
+        while True:
+            s = th.randint(low=1, high=max_indices + 1, size=())
+            max_scale = T / (s - 0.999)
+            scale = np.exp(np.random.rand() * np.log(max_scale))
+            pos = th.rand(()) * (T - scale * (s - 1))
+            indices = [int(pos + i * scale) for i in range(s)]
+            if all(0 <= i < T for i in indices):
+                return indices
+            print("warning: sampled invalid indices", indices, "trying again")
+
+    def sample_all_masks(self, batch1, batch2=None, gather=True, set_masks={'obs': (), 'latent': ()}):
+        """Random observed/latent frame masks with at most ``max_frames`` frames flagged per video
+        (reference train_util.py:193-222)."""
+        N = self.max_frames
+        B, T, *_ = batch1.shape
+        masks = {k: th.zeros_like(batch1[:, :, :1, :1, :1]) for k in ('obs', 'latent')}
+        for obs_row, latent_row in zip(masks['obs'], masks['latent']):
+            latent_row[self.sample_some_indices(max_indices=N, T=T)] = 1.
+            while True:
+                mask = obs_row if th.rand(()) < 0.5 else latent_row
+                indices = th.tensor(self.sample_some_indices(max_indices=N, T=T))
+                taken = (obs_row[indices] + latent_row[indices]).view(-1)
+                indices = indices[taken == 0]
+                if len(indices) > N - sum(obs_row) - sum(latent_row):
+                    break
+                mask[indices] = 1.
+        if len(set_masks['obs']) > 0:
+            for k in masks:
+                n_set = min(len(set_masks[k]), len(masks[k]))
+                masks[k][:n_set] = set_masks[k][:n_set]
+        any_mask = (masks['obs'] + masks['latent']).to(th.float32).clip(max=1).to(masks['obs'].dtype)
+        if not gather:
+            return batch1, masks['obs'], masks['latent']
+        batch, (obs_mask, latent_mask), frame_indices = self.prepare_training_batch(
+            any_mask, batch1, batch2, (masks['obs'], masks['latent']))
+        return batch, frame_indices, obs_mask, latent_mask
+
+    def prepare_training_batch(self, mask, batch1, batch2, tensors):
+        """Gather the flagged frames of batch1 (sorted), pad to ``max_frames`` with random frames of
+        batch2 and gather ``tensors`` the same way (reference train_util.py:224-241)."""
+        B, T, *_ = mask.shape
+        mask = mask.view(B, T)
+        eff_T = self.max_frames if self.pad_with_random_frames else int(mask.sum(dim=1).max())
+        indices = th.zeros_like(mask[:, :eff_T], dtype=th.int64)
+        new_batch = th.zeros_like(batch1[:, :eff_T])
+        new_tensors = [th.zeros_like(t[:, :eff_T]) for t in tensors]
+        for b in range(B):
+            n = int(mask[b].sum())
+            indices[b, :n] = mask[b].nonzero().flatten()
+            indices[b, n:] = th.randint_like(indices[b, n:], high=T) if self.pad_with_random_frames else 0
+            new_batch[b, :n] = batch1[b][mask[b] == 1]
+            new_batch[b, n:] = (batch1 if batch2 is None else batch2)[b][indices[b, n:]]
+            for nt, t in zip(new_tensors, tensors):
+                nt[b, :n] = t[b][mask[b] == 1]
+                nt[b, n:] = t[b][indices[b, n:]]
+        return new_batch, new_tensors, indices
+
+    # ------------------------------------------------------------------ loop
+    def run_loop(self):
+        last_sample_time = None
+        while not self.lr_anneal_steps or self.step < self.lr_anneal_steps:
+            self.run_step()
+            if self.step % self.log_interval == 0:
+                logger.dumpkvs()
+            if self.step % self.save_interval == 0:
+                self.save()
+            if os.environ.get("DIFFUSION_TRAINING_TEST", "") and self.step > 0:
+                return
+            if self.sample_interval is not None and self.step != 0 and (self.step % self.sample_interval == 0 or self.step == 5):
+                if last_sample_time is not None:
+                    logger.logkv('timing/time_between_samples', time() - last_sample_time)
+                self.log_samples()
+                last_sample_time = time()
+            self.step += 1
+        if (self.step - 1) % self.save_interval != 0:
+            self.save()
+
+    def run_step(self):
+        t0 = time()
+        self.forward_backward()
+        self.optimize_normal()
+        self.log_step()
+        logger.logkv("timing/step_time", time() - t0)
+
+    def forward_backward(self):
+        self.arena.zero_grad()
+        batch1 = next(self.data)[0]
+        batch2 = next(self.data)[0] if self.pad_with_random_frames else None
+        for i in range(0, batch1.shape[0], self.microbatch):
+            micro1 = batch1[i:i + self.microbatch]
+            micro2 = batch2[i:i + self.microbatch] if batch2 is not None else None
+            micro, frame_indices, obs_mask, latent_mask = self.sample_all_masks(micro1, micro2)
+            micro = self.encode(micro)
+            dev = dist_util.dev()
+            micro, frame_indices = micro.to(dev), frame_indices.to(dev)
+            obs_mask, latent_mask = obs_mask.to(dev), latent_mask.to(dev)
+            t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
+            losses = self.diffusion.training_losses(
+                self.ddp_model, micro, t,
+                model_kwargs={'frame_indices': frame_indices, 'obs_mask': obs_mask, 'latent_mask': latent_mask, 'x0': micro},
+                latent_mask=(1 - obs_mask) if self.pad_with_random_frames else latent_mask, eval_mask=latent_mask)
+            if isinstance(self.schedule_sampler, LossAwareSampler):
+                self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
+            loss = (losses["loss"] * weights).mean()
+            log_loss_dict(self.diffusion, t, {k: v * weights for k, v in losses.items()})
+            loss.backward()      # gradients accumulate in the arena across micro-batches
+
+    def optimize_normal(self):
+        """All-reduce (once) + fused AdamW/EMA/grad-norm (reference train_util.py:346-357)."""
+        if self.use_ddp:
+            dist.all_reduce(self.arena.g, op=dist.ReduceOp.SUM)   # RCCL; averaged by grad_scale below
+        self._anneal_lr()
+        self.opt_step += 1
+        self.grad_sqsum.zero_()
+        a = nat.AdamWArgs()
+        a.p, a.g, a.m, a.v = self.arena.p.data_ptr(), self.arena.g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        for i, (flat, rate) in enumerate(zip(self.ema_flat, self.ema_rate)):
+            a.ema[i] = flat.data_ptr()
+            a.ema_rate[i] = rate
+        a.n_ema, a.n = len(self.ema_flat), self.arena.numel
+        a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = self.cur_lr(), self.betas[0], self.betas[1], self.adam_eps, self.weight_decay
+        a.bias_corr1 = 1.0 - self.betas[0] ** self.opt_step
+        a.bias_corr2_sqrt = math.sqrt(1.0 - self.betas[1] ** self.opt_step)
+        a.grad_scale = 1.0 / self.world
+        a.grad_sqsum = self.grad_sqsum.data_ptr()
+        import ctypes
+        nat.check(nat.lib().lfvdm_adamw_ema(ctypes.byref(a), nat.stream()), "lfvdm_adamw_ema")
+        self._invalidate_engine()
+        if self.step % self.log_interval == 0:   # the only host sync of the optimizer phase
+            logger.logkv_mean("grad_norm", float(np.sqrt(self.grad_sqsum.item())))
+
+    def _invalidate_engine(self):
+        eng = getattr(self.model, "_engine", None)
+        if eng is not None:
+            eng.invalidate()
+
+    def cur_lr(self):
+        if not self.lr_anneal_steps:
+            return self.lr
+        return self.lr * (1 - self.step / self.lr_anneal_steps)
+
+    def _anneal_lr(self):
+        self.opt.param_groups[0]["lr"] = self.cur_lr()
+
+    def log_step(self):
+        logger.logkv("step", self.step)
+        logger.logkv("samples", (self.step + 1) * self.global_batch)
+
+    # ------------------------------------------------------------------ save
+    def save(self):
+        if self.rank == 0:
+            Path(get_blob_logdir(self.args)).mkdir(parents=True, exist_ok=True)
+
+            def save_checkpoint(rate, params):
+                print(f"saving model {rate}...")
+                name = f"model{self.step:06d}.pt" if not rate else f"ema_{rate}_{self.step:06d}.pt"
+                th.save({"state_dict": self._master_params_to_state_dict(params), "config": self.args.__dict__,
+                         "step": self.step}, os.path.join(get_blob_logdir(self.args), name))
+
+            save_checkpoint(0, self.master_params)
+            for rate, params in zip(self.ema_rate, self.ema_params):
+                save_checkpoint(rate, params)
+            th.save(self.opt.state_dict(), os.path.join(get_blob_logdir(self.args), f"opt{self.step:06d}.pt"))
+        if dist.is_initialized():
+            dist.barrier()
+
+    def _master_params_to_state_dict(self, master_params):
+        sd = self.model.state_dict()
+        for i, (name, _v) in enumerate(self.model.named_parameters()):
+            assert name in sd
+            sd[name] = master_params[i].detach().clone()
+        return sd
+
+    def _state_dict_to_master_params(self, state_dict):
+        return [state_dict[name] for name, _ in self.model.named_parameters()]
+
+    def encode(self, video):
+        return self.diffusion.encode(video, chunk_size=self.enc_dec_chunk_size)
+
+    def decode(self, video):
+        return self.diffusion.decode(video, chunk_size=self.enc_dec_chunk_size)
+
+    @rng_decorator(seed=0)
+    def log_samples(self):
+        """Rank-0 sampling with the first EMA parameter set (reference train_util.py:428-475)."""
+        if self.rank == 0:
+            sample_start = time()
+            self.model.eval()
+            with th.no_grad():
+                backup = self.arena.p.clone()
+                self.arena.p.copy_(self.ema_flat[0])
+            self._invalidate_engine()
+            print("sampling...")
+            obs_mask = th.zeros_like(self.vis_batch[:, :, :1, :1, :1])
+            latent_mask = obs_mask.clone()
+            n_obs = self.max_frames // 3
+            obs_mask[0, :n_obs] = 1.
+            latent_mask[0, n_obs:self.max_frames] = 1.
+            if self.batch_size > 1 and len(self.vis_batch) > 1:
+                spacing = len(self.vis_batch[0]) // self.max_frames
+                obs_mask[1, :n_obs * spacing:spacing] = 1.
+                latent_mask[1, n_obs * spacing:self.max_frames * spacing:spacing] = 1.
+            batch, frame_indices, obs_mask, latent_mask = self.sample_all_masks(
+                self.vis_batch, None, gather=True, set_masks={'obs': obs_mask, 'latent': latent_mask})
+            dev = dist_util.dev()
+            samples, attn = self.diffusion.p_sample_loop(
+                self.model, batch.shape, clip_denoised=True,
+                model_kwargs={'frame_indices': frame_indices.to(dev), 'x0': batch.to(dev), 'obs_mask': obs_mask.to(dev),
+                              'latent_mask': latent_mask.to(dev)},
+                latent_mask=latent_mask, return_attn_weights=False, return_decoded=False)
+            samples = samples.cpu() * latent_mask + batch * obs_mask
+            try:
+                samples = self.decode(samples).float()
+                _mark_as_observed(samples[:, :n_obs])
+                vids = ((samples + 1) * 127.5).clamp(0, 255).to(th.uint8).cpu().numpy()
+                if wandb is not None and wandb.run is not None:
+                    for i, video in enumerate(vids):
+                        logger.logkv(f'video-{i}', wandb.Video(video), distributed=False)
+            except NotImplementedError:
+                pass   # latent space without the VAE: keep the latents, nothing to render
+            logger.logkv("timing/sampling_time", time() - sample_start, distributed=False)
+            self.model.train()
+            with th.no_grad():
+                self.arena.p.copy_(backup)
+            self._invalidate_engine()
+            print("finished sampling")
+        if dist.is_initialized():
+            dist.barrier()
+
+
+class _ArenaAdamW:
+    """torch.optim.AdamW-compatible view of the arena optimizer state (for checkpoints and lr access)."""
+
+    def __init__(self, loop):
+        self.loop = loop
+        self.param_groups = [dict(lr=loop.lr, betas=loop.betas, eps=loop.adam_eps, weight_decay=loop.weight_decay,
+                                  amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                                  fused=None, params=list(range(len(loop.model_params))))]
+
+    def state_dict(self):
+        L = self.loop
+        m, v = L.arena.views(L.exp_avg), L.arena.views(L.exp_avg_sq)
+        state = {i: {"step": th.tensor(float(L.opt_step)), "exp_avg": m[i].clone(), "exp_avg_sq": v[i].clone()}
+                 for i in range(len(L.model_params))} if L.opt_step > 0 else {}
+        return {"state": state, "param_groups": [dict(self.param_groups[0])]}
+
+    def load_state_dict(self, sd):
+        L = self.loop
+        m, v = L.arena.views(L.exp_avg), L.arena.views(L.exp_avg_sq)
+        for i, st in sd.get("state", {}).items():
+            m[int(i)].copy_(st["exp_avg"])
+            v[int(i)].copy_(st["exp_avg_sq"])
+            L.opt_step = int(float(st["step"]))
+
+
+def _mark_as_observed(images, color=[1., -1., -1.]):
+    for i, c in enumerate(color):
+        if i >= images.shape[-3]:
+            break
+        images[..., i, :, 1:2] = c
+        images[..., i, 1:2, :] = c
+        images[..., i, :, -2:-1] = c
+        images[..., i, -2:-1, :] = c
+
+
+def parse_resume_step_from_filename(filename):
+    """path/to/modelNNNNNN.pt -> NNNNNN (0 if it does not parse)."""
+    parts = filename.split("model")
+    if len(parts) < 2:
+        return 0
+    try:
+        return int(parts[-1].split(".")[0])
+    except ValueError:
+        return 0
+
+
+def get_blob_logdir(args):
+    root_dir = "checkpoints"
+    assert os.path.exists(root_dir), "Must create directory 'checkpoints'"
+    if len(getattr(args, "resume_id", "")) > 0:
+        run_id = args.resume_id
+    elif wandb is not None and wandb.run is not None:
+        run_id = wandb.run.id
+    else:
+        run_id = os.environ.get("LFVDM_RUN_ID", "local")
+    return os.path.join(root_dir, run_id)
+
+
+def find_resume_checkpoint(args):
+    if not getattr(args, "resume_id", ""):
+        return None
+    ckpts = glob.glob(os.path.join(get_blob_logdir(args), "model*.pt"))
+    if not ckpts:
+        return None
+    by_step = {int(Path(f).stem.replace('model', '')): f for f in ckpts}
+    return by_step[max(by_step)]
+
+
+def find_ema_checkpoint(main_checkpoint, step, rate):
+    if main_checkpoint is None:
+        return None
+    path = os.path.join(os.path.dirname(main_checkpoint), f"ema_{rate}_{step:06d}.pt")
+    return path if os.path.exists(path) else None
+
+
+def log_loss_dict(diffusion, ts, losses):
+    """Mean and per-timestep-quartile means of every loss term (reference train_util.py:530-536), with a
+    single device->host transfer."""
+    keys = list(losses.keys())
+    stacked = th.stack([losses[k].detach().float() for k in keys]).cpu().numpy()
+    ts_np = ts.cpu().numpy()
+    for key, values in zip(keys, stacked):
+        logger.logkv_mean(key, float(values.mean()))
+        for sub_t, sub_loss in zip(ts_np, values):
+            quartile = int(4 * sub_t / diffusion.num_timesteps)
+            logger.logkv_mean(f"{key}_q{quartile}", float(sub_loss))
