@@ -137,6 +137,58 @@ def cpu_baseline_sample(model, diffusion, inputs, B, T, budget_s=12.0):
                 sample=f"{n - 2} p_sample steps of the same workload (oracle/unet_oracle.py + diffusion_oracle.py, torch CPU fp32)")
 
 
+def synthetic_video_stream(B, T_video, seed):
+    g = th.Generator().manual_seed(seed)
+    while True:
+        yield (th.randn(B, T_video, 4, 16, 16, generator=g).clamp(-1, 1), {})
+
+
+def bench_train(rank, world, dev, steps, warmup):
+    """DDP-style training at BASELINE.json configs[2]: latent U-Net num_channels=128, max_frames=20, batch 2 per
+    GPU (global 2*N), one optimizer step = mask sampling + q_sample + U-Net forward/backward + ONE RCCL all-reduce
+    of the gradient arena + fused AdamW/EMA (reference TrainLoop.run_step, train_util.py:267-275)."""
+    import argparse as ap
+    from improved_diffusion.train_util import TrainLoop
+    model, diffusion = make_model_and_diffusion(128, dev)
+    model.train()
+    loop = TrainLoop(model=model, diffusion=diffusion, data=synthetic_video_stream(2, 40, 4321 + rank), batch_size=2,
+                     microbatch=-1, lr=1e-4, ema_rate="0.9999", log_interval=10 ** 9, save_interval=10 ** 9,
+                     resume_checkpoint="", use_fp16=False, diffusion_space_kwargs={}, fp16_scale_growth=1e-3,
+                     schedule_sampler=None, weight_decay=0.0, lr_anneal_steps=0, sample_interval=None,
+                     pad_with_random_frames=True, max_frames=20, enc_dec_chunk_size=20, args=ap.Namespace(resume_id=""))
+    th.manual_seed(99 + rank)
+    np.random.seed(99 + rank)
+    for _ in range(warmup):
+        loop.run_step()
+        loop.step += 1
+    th.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loop.run_step()
+        loop.step += 1
+    th.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    th.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = th.tensor([el], device=dev, dtype=th.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    from improved_diffusion.logger import logger
+    loss = float(logger.name2val.get("loss", float("nan")))
+    logger.dumpkvs()
+    P = sum(p.numel() for p in model.parameters())
+    return {"optimizer_steps_per_s": round(steps / el, 3), "ms_per_step": round(1000.0 * el / steps, 2), "steps": steps,
+            "global_batch": 2 * world, "videos_per_s": round(2 * world * steps / el, 2), "params": P,
+            "allreduce_bytes_per_step": 4 * P if world > 1 else 0, "last_loss": loss,
+            "workload": "train: U-Net num_channels=128 num_res_blocks=1 max_frames=20 batch 2/GPU, AdamW+EMA, "
+                        "one RCCL all-reduce of the fp32 gradient arena per step (BASELINE.json configs[2])"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +196,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed optimizer steps of the training leg (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -186,6 +239,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     finite = bool(th.isfinite(sampler.plan.x_in).all().item())
+    train = None
+    if args.train_steps > 0:
+        del sampler
+        diffusion._samplers.clear()
+        th.cuda.empty_cache()
+        train = bench_train(rank, world, dev, args.train_steps, 2)
+        sampler = diffusion._graph_sampler(model, shape, True)   # for the kernel breakdown below
+        sampler.begin(th.randn(*shape, device=dev), inputs)
 
     out = {
         "metric": "denoising steps/sec (train+sample) on 20-frame 4x16x16 latents", "value": round(world * args.steps / el, 2),
@@ -197,6 +258,8 @@ def main():
                    "batch": B, "frames": T, "latent": "4x16x16", "parallelism": f"replicas x{world} (no collective)",
                    "frames_steps_per_s": round(world * args.steps * B * T / el, 1), "finite": finite},
     }
+    if train is not None:
+        out["train"] = train
     if rank == 0:
         if not args.no_breakdown:
             groups = kernel_breakdown(sampler.plan)

@@ -177,7 +177,7 @@ class TrainLoop:
         (reference train_util.py:180-191; same sequence of random draws)."""
         while True:
             s = th.randint(low=1, high=max_indices + 1, size=())
-            max_scale = T / (s - 0.999)
+            max_scale = T / (float(s) - 0.999)
             scale = np.exp(np.random.rand() * np.log(max_scale))
             pos = th.rand(()) * (T - scale * (s - 1))
             indices = [int(pos + i * scale) for i in range(s)]
