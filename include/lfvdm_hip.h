@@ -86,12 +86,22 @@ typedef struct lfvdm_conv_args {
     float* out;
     int32_t ldo;      /* row stride for LFVDM_OUT_ROWS */
     int32_t out_mode; /* LFVDM_OUT_* */
+    int32_t tune;     /* 0: built-in makespan model picks tile shape / K-chunk (never split-K); otherwise a
+                       * code returned by lfvdm_conv_igemm_candidates (set by an autotuner for a fixed shape) */
+    /* optional workspace enabling deterministic split-K over workgroups for small-M layers: slabs of partial
+     * tiles + one arrival ticket per output tile (the launcher zeroes the tickets with a memset node) */
+    float* splitk_ws;
+    int32_t* splitk_cnt;
+    int64_t splitk_ws_floats;
+    int64_t splitk_cnt_ints;
 } lfvdm_conv_args;
 
 int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream);
 /* template instance (NT = 32-column tiles per wave, nwaves = K-split waves per workgroup) that
  * lfvdm_conv_igemm picks for these arguments; profiling aid, launches nothing. */
 int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* nwaves);
+/* legal `tune` codes for these arguments (tile configuration x K-chunk width x split-K factor) */
+int lfvdm_conv_igemm_candidates(const lfvdm_conv_args* a, int* codes, int max_codes);
 
 /* OIHW [Cout][Cin][k][k] -> [Cout][k*k][Cin] (k in {1,3}); state-dict layout stays OIHW. */
 int lfvdm_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int ksize, void* stream);

@@ -78,8 +78,11 @@ template <int AE, int WE>
 struct ChunkRegs {
     f32x4 a[AE];
     f32x4 w[WE];
-    f32x4 ca[AE], cb[AE];   // GroupNorm/FiLM coefficients: loaded WITH the first chunk of a channel chunk so
-                            // that they sit in front of younger prefetches in the in-order vmcnt queue
+    // GroupNorm/FiLM coefficients: loaded WITH the first chunk of a channel chunk so that they sit in front
+    // of younger prefetches in the in-order vmcnt queue.  Only when the thread stages <= 2 A rows (register
+    // budget); otherwise they are fetched when the chunk is written to LDS (once per 9 taps).
+    static constexpr bool COEF_PREFETCH = AE <= 2;
+    f32x4 ca[COEF_PREFETCH ? AE : 1], cb[COEF_PREFETCH ? AE : 1];
     unsigned amask;
     int coef_cc;            // >= 0: first chunk of a channel chunk -> (re)load the GroupNorm/FiLM coefficients
     bool main_seg;
@@ -121,11 +124,11 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
 
     R.main_seg = main_seg;
     R.coef_cc = (p.coefA && main_seg && live && (tap == 0 || kc == kfirst)) ? cc : -1;
-    if (R.coef_cc >= 0) {   // wave-uniform
+    if (ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH && R.coef_cc >= 0) {   // wave-uniform
 #pragma unroll
         for (int j = 0; j < CF::AE; ++j) {
-            R.ca[j] = ld4(p.coefA + (unsigned)(ri[j].n * Cin + cc + col));
-            R.cb[j] = ld4(p.coefB + (unsigned)(ri[j].n * Cin + cc + col));
+            R.ca[j < (ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH ? CF::AE : 1) ? j : 0] = ld4(p.coefA + (unsigned)(ri[j].n * Cin + cc + col));
+            R.cb[j < (ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH ? CF::AE : 1) ? j : 0] = ld4(p.coefB + (unsigned)(ri[j].n * Cin + cc + col));
         }
     }
     unsigned am = 0;
@@ -170,13 +173,21 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
 // PRO: 0 = raw operand, 1 = affine (GroupNorm coefficients), 2 = affine + SiLU
 template <class CF, int PRO>
 __device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs<CF::AE, CF::WE>& R,
-                                             f32x4 (&ca)[CF::AE], f32x4 (&cb)[CF::AE], unsigned wmask, float* As,
-                                             float* Ws, int gt) {
+                                             f32x4 (&ca)[CF::AE], f32x4 (&cb)[CF::AE], unsigned wmask,
+                                             const RowInfo (&ri)[CF::AE], int Cin, float* As, float* Ws, int gt) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const int col = (gt & (CF::QPR - 1)) * 4;
     if (PRO > 0 && R.coef_cc >= 0) {   // once per channel chunk (the 9 taps share it)
+        if constexpr (ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH) {
 #pragma unroll
-        for (int j = 0; j < CF::AE; ++j) { ca[j] = R.ca[j]; cb[j] = R.cb[j]; }
+            for (int j = 0; j < CF::AE; ++j) { ca[j] = R.ca[j]; cb[j] = R.cb[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CF::AE; ++j) {
+                ca[j] = ld4(p.coefA + (unsigned)(ri[j].n * Cin + R.coef_cc + col));
+                cb[j] = ld4(p.coefB + (unsigned)(ri[j].n * Cin + R.coef_cc + col));
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < CF::WE; ++j)
@@ -228,11 +239,16 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     STAMP(0);
     float* gbase = smem + wk * CF::GROUP_LDS;
 
-    // contiguous K slice of this k-group; every group runs `iters` iterations (same barrier count),
-    // a group that owns fewer chunks replays its last chunk with everything masked to zero
-    const int kbeg = (int)(((long)NK * wk) / WK);
-    const int kend = (int)(((long)NK * (wk + 1)) / WK);
-    const int iters = ((NK + WK - 1) / WK + 1) & ~1;   // even: the loop is unrolled by two
+    // K is first split over gridDim.z workgroups (small-M layers: more workgroups than output tiles; the
+    // partial tiles are combined with float atomics into the zero-initialised output), then over the
+    // k-groups of the workgroup.  Every group runs `iters` iterations (same barrier count); a group that
+    // owns fewer chunks replays its last chunk with everything masked to zero.
+    const int KZ = gridDim.z, kz = blockIdx.z;
+    const int zbeg = (int)(((long)NK * kz) / KZ), zend = (int)(((long)NK * (kz + 1)) / KZ);
+    const int NKz = zend - zbeg;
+    const int kbeg = zbeg + (int)(((long)NKz * wk) / WK);
+    const int kend = zbeg + (int)(((long)NKz * (wk + 1)) / WK);
+    const int iters = (((NK + KZ - 1) / KZ + WK - 1) / WK + 1) & ~1;   // even: the loop is unrolled by two
 
     RowInfo ri[CF::AE];
     {
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     f32x4 ca[CF::AE], cb[CF::AE];
 #pragma unroll
     for (int j = 0; j < CF::AE; ++j) { ca[j] = (f32x4){1.f, 1.f, 1.f, 1.f}; cb[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const int klast = kend - 1;
+    const int klast = max(kend - 1, 0);
     issue_chunk<CF>(p, min(kbeg, klast), kbeg < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R0);
     issue_chunk<CF>(p, min(kbeg + 1, klast), kbeg + 1 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R1);
 
@@ -294,16 +310,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     const int fra = (32 * wm + (lane & 31)) * LDR + (lane >> 5) * 4;                    // A fragment offset
     const int frw = (BM + 32 * NT * wn + (lane & 31)) * LDR + (lane >> 5) * 4;          // W fragment offset
 
-#define LFVDM_PHASE(KC_, ST_, R_)                                                                              \
+#define LFVDM_FINISH(ST_, R_) finish_chunk<CF, PRO>(p, R_, ca, cb, wmask, ri, Cin, (ST_), (ST_) + BM * LDR, gt)
+#define LFVDM_ISSUE(KC_, R_) \
+    issue_chunk<CF>(p, min((KC_) + 2, klast), (KC_) + 2 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R_)
+#define LFVDM_MFMA(ST_)                                                                                        \
     do {                                                                                                       \
-        float* st_ = (ST_);                                                                                    \
-        STAMP(4 + 4 * ((KC_) - kbeg));                                                                         \
-        finish_chunk<CF, PRO>(p, R_, ca, cb, wmask, st_, st_ + BM * LDR, gt);                                  \
-        STAMP(5 + 4 * ((KC_) - kbeg));                                                                         \
-        __syncthreads();                                                                                       \
-        STAMP(6 + 4 * ((KC_) - kbeg));                                                                         \
-        issue_chunk<CF>(p, min((KC_) + 2, klast), (KC_) + 2 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R_);  \
-        STAMP(7 + 4 * ((KC_) - kbeg));                                                                         \
+        const float* st_ = (ST_);                                                                              \
         _Pragma("unroll") for (int g = 0; g < KC / 8; ++g) {                                                   \
             const f32x4 a4 = ld4(st_ + fra + g * 8);                                                           \
             f32x4 b4[NT];                                                                                      \
@@ -313,11 +325,42 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[t][e], acc[t], 0, 0, 0);           \
         }                                                                                                      \
     } while (0)
-    for (int it = 0; it < iters; it += 2) {
-        LFVDM_PHASE(kbeg + it, gbase, R0);
-        LFVDM_PHASE(kbeg + it + 1, gbase + CF::STAGE, R1);
+    // Two barriers per chunk.  In an 8-wave workgroup every SIMD holds one wave of the first half (waves
+    // 0-3) and one of the second half (4-7); the halves run the loop half a period apart ("ping-pong"):
+    // while one half issues its 16*NT*(KC/32) MFMAs the other half does its VALU/LDS staging work, so the
+    // matrix pipe and the vector pipe of a SIMD overlap instead of alternating.  A k-group always lies
+    // inside one half, and its LDS write (finish) and read (MFMA) phases are separated by a barrier.
+    const bool late_half = (CF::NTHREADS == 512) && wave >= 4;
+    if (!late_half) {
+        for (int it = 0; it < iters; it += 2) {
+            LFVDM_FINISH(gbase, R0);
+            __syncthreads();
+            LFVDM_ISSUE(kbeg + it, R0);
+            LFVDM_MFMA(gbase);
+            __syncthreads();
+            LFVDM_FINISH(gbase + CF::STAGE, R1);
+            __syncthreads();
+            LFVDM_ISSUE(kbeg + it + 1, R1);
+            LFVDM_MFMA(gbase + CF::STAGE);
+            __syncthreads();
+        }
+    } else {
+        for (int it = 0; it < iters; it += 2) {
+            __syncthreads();
+            LFVDM_FINISH(gbase, R0);
+            LFVDM_ISSUE(kbeg + it, R0);
+            __syncthreads();
+            LFVDM_MFMA(gbase);
+            __syncthreads();
+            LFVDM_FINISH(gbase + CF::STAGE, R1);
+            LFVDM_ISSUE(kbeg + it + 1, R1);
+            __syncthreads();
+            LFVDM_MFMA(gbase + CF::STAGE);
+        }
     }
-#undef LFVDM_PHASE
+#undef LFVDM_FINISH
+#undef LFVDM_ISSUE
+#undef LFVDM_MFMA
     STAMP(2);
     __syncthreads();   // all fragment reads done before the stages are reused for the reduction
 
@@ -331,6 +374,58 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             red[row * RED_LD + 32 * NT * wn + t * 32 + (lane & 31)] = acc[t][r];
         }
     __syncthreads();
+
+    // ---- split-K over workgroups (KZ > 1): every slice stores its partial tile to a slab of the
+    // workspace; the slice that arrives LAST at the tile's counter sums all slabs in FIXED order (slice
+    // 0..KZ-1), so the result is bitwise reproducible whatever the arrival order.  Cross-workgroup
+    // visibility follows the agent-scope release/acquire recipe of the CDNA guide (G16): stores ->
+    // every wave s_waitcnt vmcnt(0) -> barrier -> lane 0: release fence + drained ticket atomic;
+    // last arriver: acquire fence -> barrier -> plain loads.
+    bool do_epilogue = true;
+    if (KZ > 1) {
+        constexpr int QNs = BN / 4;
+        const size_t tile_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        float* slab = p.splitk_ws + (tile_id * KZ + kz) * (size_t)(BM * BN);
+        for (int e = tid; e < BM * QNs; e += CF::NTHREADS) {
+            const int row = e / QNs, c4 = (e - row * QNs) * 4;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+                const float* r = smem + w * CF::GROUP_LDS + row * RED_LD + c4;
+                t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
+            }
+            st4(slab + row * BN + c4, t);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int s_last;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (ticket == KZ - 1) ? 1 : 0;
+            if (s_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        do_epilogue = s_last != 0;
+        if (do_epilogue) {
+            // ordered sum of the KZ slabs back into the LDS tile of group 0 (the epilogue below reads it)
+            const float* base = p.splitk_ws + tile_id * KZ * (size_t)(BM * BN);
+            for (int e = tid; e < BM * QNs; e += CF::NTHREADS) {
+                const int row = e / QNs, c4 = (e - row * QNs) * 4;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                for (int z = 0; z < KZ; ++z) t += ld4(base + (size_t)z * (BM * BN) + row * BN + c4);
+                float* r = smem + row * RED_LD + c4;
+                r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+            }
+            __syncthreads();
+        }
+    }
+    if (!do_epilogue) return;
+    const int WKE = (KZ > 1) ? 1 : WK;    // after a split-K combine the full sum sits in group 0's tile
 
     // ---- epilogue: a thread owns 4 consecutive output columns of EPV rows: bias is read once as a
     // float4, all residual loads are issued back to back, stores are 16-byte.
@@ -367,8 +462,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         for (int i = 0; i < EPV; ++i) {
             const int row = min(row0 + i * RSTEP, BM - 1);
             f32x4 t = bsum;
-#pragma unroll
-            for (int w = 0; w < WK; ++w) {
+            for (int w = 0; w < WKE; ++w) {
                 const float* r = smem + w * CF::GROUP_LDS + row * RED_LD + c4;
                 t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
             }
@@ -412,7 +506,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 }
 
 template <int WM, int WN, int WK, int NT, int KCH, int PRO>
-int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M) {
+int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
     using CF = Cfg<WM, WN, WK, NT, KCH>;
     static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent
     if (!attr_set) {
@@ -421,25 +515,28 @@ int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M) {
             return LFVDM_E_LAUNCH;
         attr_set = true;
     }
-    const dim3 grid((unsigned)((M + CF::BM - 1) / CF::BM), (unsigned)((a->Cout + CF::BN - 1) / CF::BN));
+    const dim3 grid((unsigned)((M + CF::BM - 1) / CF::BM), (unsigned)((a->Cout + CF::BN - 1) / CF::BN), (unsigned)kz);
+    if (kz > 1) {   // arrival tickets of the split-K tiles start from zero (stream-ordered memset node)
+        if (hipMemsetAsync(a->splitk_cnt, 0, (size_t)grid.x * grid.y * sizeof(int), s) != hipSuccess) return LFVDM_E_LAUNCH;
+    }
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
 
 template <int WM, int WN, int WK, int NT, int KCH>
-int launch_kc(const lfvdm_conv_args* a, hipStream_t s, long M) {
-    if (!a->coefA) return launch_pro<WM, WN, WK, NT, KCH, 0>(a, s, M);
-    if (a->act == LFVDM_ACT_SILU) return launch_pro<WM, WN, WK, NT, KCH, 2>(a, s, M);
-    return launch_pro<WM, WN, WK, NT, KCH, 1>(a, s, M);
+int launch_kc(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
+    if (!a->coefA) return launch_pro<WM, WN, WK, NT, KCH, 0>(a, s, M, kz);
+    if (a->act == LFVDM_ACT_SILU) return launch_pro<WM, WN, WK, NT, KCH, 2>(a, s, M, kz);
+    return launch_pro<WM, WN, WK, NT, KCH, 1>(a, s, M, kz);
 }
 
 template <int WM, int WN, int WK, int NT>
-int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, long M, int kch) {
+int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, long M, int kch, int kz) {
     if constexpr (WM * WN >= 4 && NT == 1) {   // 64-channel chunks need a 256-thread k-group (register budget)
-        if (kch == 64) return launch_kc<WM, WN, WK, NT, 64>(a, s, M);
+        if (kch == 64) return launch_kc<WM, WN, WK, NT, 64>(a, s, M, kz);
     }
-    return launch_kc<WM, WN, WK, NT, 32>(a, s, M);
+    return launch_kc<WM, WN, WK, NT, 32>(a, s, M, kz);
 }
 
 // Tile configurations: {WM, WN, WK, NT, waves/SIMD allowed by the VGPR allocation}.
@@ -458,7 +555,7 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 // Modelled makespan (cycles) of one launch: 256 CUs x 4 SIMDs, 64 cycles per 32x32x2 MFMA, one barrier
 // per 32-channel chunk, loads prefetched two chunks ahead.
-double model_cycles(const TileCfg& c, int Cout, long M, int NK, int kch) {
+double model_cycles(const TileCfg& c, int Cout, long M, int NK, int kch, int kz) {
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
     const int waves = c.WM * c.WN * c.WK;
     const double lds = (double)c.WK * 2.0 * (BM + BN) * (kch + 4) * 4.0;
@@ -466,32 +563,69 @@ double model_cycles(const TileCfg& c, int Cout, long M, int NK, int kch) {
     const int by_vgpr = (c.vgpr_waves * 4) / waves;
     if (by_vgpr < resident) resident = by_vgpr;
     if (resident < 1) resident = 1;
-    const long wgs = ((M + BM - 1) / BM) * ((Cout + BN - 1) / BN);
+    const long wgs = ((M + BM - 1) / BM) * ((Cout + BN - 1) / BN) * kz;
     const long slots = 256L * resident;
     const long rounds = (wgs + slots - 1) / slots;
     long per_cu = (wgs + 255) / 256;
     if (per_cu > resident) per_cu = resident;
     const double simd_waves = (double)per_cu * ((waves + 3) / 4);
-    const double chunks = (double)((NK + c.WK - 1) / c.WK);
+    const double chunks = (double)(((NK + kz - 1) / kz + c.WK - 1) / c.WK);
     const double mfma = 16.0 * c.NT * 64.0 * (kch / 32);
     double per_iter = mfma * simd_waves;
     const double floor_iter = 1000.0 + 0.3 * mfma;   // barrier + staging + exposed latency of a lone wave
     if (per_iter < floor_iter) per_iter = floor_iter;
-    return (double)rounds * (chunks * per_iter + 3500.0 + 900.0 + 250.0 * c.WK);
+    return (double)rounds * (chunks * per_iter + 3500.0 + 900.0 + 250.0 * c.WK) + (kz > 1 ? 2500.0 : 0.0);
 }
 
 // Joint choice of tile configuration and K chunk width (64-channel chunks only when every channel
 // count involved is a multiple of 64 and the k-group has 256 threads).
-struct Pick { int id, kch, NK; };
+struct Pick { int id, kch, NK, kz; };
+
+// tune code (lfvdm_conv_args::tune): 0 = heuristic, else 1 + id + 16*(kch == 64) + 32*log2(kz)
+inline int encode_tune(int id, int kch, int kz) {
+    int l = 0;
+    while ((1 << l) < kz) ++l;
+    return 1 + id + 16 * (kch == 64 ? 1 : 0) + 32 * l;
+}
+// is (id, kch, kz) a legal configuration for these arguments?
+bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz) {
+    const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
+    if (id < 0 || id >= kNumCfgs || id == 7 || (kch != 32 && kch != 64) || kz < 1 || kz > 8) return false;
+    const TileCfg c = kCfgs[id];
+    const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
+    if (a->Cout <= 32 && BN > 32) return false;
+    const bool can64 = Cin % 64 == 0 && a->C0 % 64 == 0 && C2 % 64 == 0 && a->s2C0 % 64 == 0;
+    if (kch == 64 && (!can64 || c.WM * c.WN < 4 || c.NT > 1)) return false;
+    const int NK = a->ksize * a->ksize * (Cin / kch) + C2 / kch;
+    if (c.WK > NK) return false;
+    if ((double)c.WK * 2.0 * (BM + BN) * (kch + 4) * 4.0 > 160.0 * 1024.0) return false;
+    // split-K over workgroups needs the caller's workspace (slabs + tile tickets) and the rows layout
+    if (kz > 1) {
+        if (!a->splitk_ws || !a->splitk_cnt || a->out_mode != LFVDM_OUT_ROWS || NK < kz * c.WK) return false;
+        const long M = (long)a->N * a->Ho * a->Wo;
+        const long tiles = ((M + BM - 1) / BM) * ((a->Cout + BN - 1) / BN);
+        if (tiles * kz * (long)(BM * BN) > a->splitk_ws_floats || tiles > a->splitk_cnt_ints) return false;
+    }
+    return true;
+}
+
 Pick pick_cfg(const lfvdm_conv_args* a, long M) {
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
+    if (a->tune > 0) {   // explicit choice (autotuner); fall through to the model if it is not legal here
+        const int t = a->tune - 1;
+        const int id = t & 15, kch = (t & 16) ? 64 : 32, kz = 1 << (t >> 5);
+        if (cfg_valid(a, id, kch, kz)) return {id, kch, a->ksize * a->ksize * (Cin / kch) + C2 / kch, kz};
+    }
     const bool can64 = !getenv("LFVDM_CONV_KC32") && Cin % 64 == 0 && a->C0 % 64 == 0 && C2 % 64 == 0 && a->s2C0 % 64 == 0;
     static const int forced = getenv("LFVDM_CONV_CFG") ? atoi(getenv("LFVDM_CONV_CFG")) : -1;  // tuning aid
-    Pick best = {0, 32, a->ksize * a->ksize * (Cin / 32) + C2 / 32};
+    static const int forced_kz = getenv("LFVDM_CONV_KZ") ? atoi(getenv("LFVDM_CONV_KZ")) : -1;
+    const bool can_split = false;   // the built-in model never splits K over workgroups (see cfg_valid)
+    Pick best = {0, 32, a->ksize * a->ksize * (Cin / 32) + C2 / 32, 1};
     double best_t = 1e30;
     for (int i = 0; i < kNumCfgs; ++i) {
         const TileCfg c = kCfgs[i];
         if (forced >= 0 && i != forced) continue;
+        if (i == 7) continue;   // 64x128 with two k-groups exceeds the register budget (spills): not offered
         const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
         if (a->Cout <= 32 && BN > 32) continue;
         for (int kch = 32; kch <= 64; kch += 32) {
@@ -499,8 +633,12 @@ Pick pick_cfg(const lfvdm_conv_args* a, long M) {
             const int NK = a->ksize * a->ksize * (Cin / kch) + C2 / kch;
             if (c.WK > NK) continue;
             if ((double)c.WK * 2.0 * (BM + BN) * (kch + 4) * 4.0 > 160.0 * 1024.0) continue;   // LDS budget
-            const double est = model_cycles(c, a->Cout, M, NK, kch);
-            if (est < best_t) { best_t = est; best = {i, kch, NK}; }
+            for (int kz = 1; kz <= 8; kz *= 2) {
+                if (kz > 1 && (!can_split || NK < 2 * kz * c.WK)) continue;
+                if (forced_kz > 0 && kz != forced_kz && !(kz == 1 && (!can_split || NK < 2 * forced_kz * c.WK))) continue;
+                const double est = model_cycles(c, a->Cout, M, NK, kch, kz);
+                if (est < best_t) { best_t = est; best = {i, kch, NK, kz}; }
+            }
         }
     }
     return best;
@@ -532,16 +670,16 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     if (M * (long)(C2 > a->Cout ? C2 : a->Cout) >= (1L << 31) || (long)a->N * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     if ((long)a->Cout * a->ksize * a->ksize * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     const Pick pk = pick_cfg(a, M);
-    const int kch = pk.kch;
+    const int kch = pk.kch, kz = pk.kz;
     switch (pk.id) {
-        case 0: return launch_cfg<2, 2, 1, 1>(a, s, M, kch);
-        case 1: return launch_cfg<2, 2, 1, 2>(a, s, M, kch);
-        case 2: return launch_cfg<1, 2, 2, 1>(a, s, M, kch);
-        case 3: return launch_cfg<1, 2, 4, 1>(a, s, M, kch);
-        case 4: return launch_cfg<1, 1, 8, 1>(a, s, M, kch);
-        case 5: return launch_cfg<2, 2, 2, 1>(a, s, M, kch);
-        case 6: return launch_cfg<1, 1, 4, 1>(a, s, M, kch);
-        case 7: return launch_cfg<2, 2, 2, 2>(a, s, M, kch);
+        case 0: return launch_cfg<2, 2, 1, 1>(a, s, M, kch, kz);
+        case 1: return launch_cfg<2, 2, 1, 2>(a, s, M, kch, kz);
+        case 2: return launch_cfg<1, 2, 2, 1>(a, s, M, kch, kz);
+        case 3: return launch_cfg<1, 2, 4, 1>(a, s, M, kch, kz);
+        case 4: return launch_cfg<1, 1, 8, 1>(a, s, M, kch, kz);
+        case 5: return launch_cfg<2, 2, 2, 1>(a, s, M, kch, kz);
+        case 6: return launch_cfg<1, 1, 4, 1>(a, s, M, kch, kz);
+        case 7: return launch_cfg<2, 2, 2, 2>(a, s, M, kch, kz);
     }
     return LFVDM_E_UNSUPPORTED;
 }
@@ -557,6 +695,16 @@ extern "C" int lfvdm_pack_conv_weight(const float* w, float* o, int Cout, int Ci
 
 // Which template instance lfvdm_conv_igemm would launch for these arguments (profiling aid: lets
 // bench.py attribute per-launch HIP-event timings to the kernel symbol rocprofv3 reports).
+// All legal tune codes for these arguments (for an autotuner); returns how many were written.
+extern "C" int lfvdm_conv_igemm_candidates(const lfvdm_conv_args* a, int* codes, int max_codes) {
+    int n = 0;
+    for (int id = 0; id < kNumCfgs; ++id)
+        for (int kch = 32; kch <= 64; kch += 32)
+            for (int kz = 1; kz <= 8; kz *= 2)
+                if (cfg_valid(a, id, kch, kz) && n < max_codes) codes[n++] = encode_tune(id, kch, kz);
+    return n;
+}
+
 extern "C" int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* nwaves) {
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
     if (Cin <= 0 || Cin % 32 || C2 % 32) return LFVDM_E_SHAPE;

@@ -76,6 +76,12 @@ class Plan:
         a.resA = _p(g("resA")) if g("resA") is not None else None
         a.resB = _p(g("resB")) if g("resB") is not None else None
         a.out = _p(kw["out"]); a.ldo = kw["ldo"]; a.out_mode = g("out_mode", nat.OUT_ROWS)
+        # shared split-K workspace (launches are stream-ordered, so one buffer serves every conv of the plan)
+        if getattr(self, "splitk_ws", None) is None:
+            self.splitk_ws = self.buf(2 * 1024 * 1024)                      # 8 MiB of slabs
+            self.splitk_cnt = self.buf(4096, dtype=th.int32)
+        a.splitk_ws, a.splitk_cnt = _p(self.splitk_ws), _p(self.splitk_cnt)
+        a.splitk_ws_floats, a.splitk_cnt_ints = self.splitk_ws.numel(), self.splitk_cnt.numel()
         self.keep.append(a)
         self.add(nat.lib().lfvdm_conv_igemm, C.byref(a))
 
@@ -296,6 +302,41 @@ class Plan:
         self.add_conv(src0=x, C0=Cc, N=N, Hs=H, Ws=W, up=0 if down else 1, stride=2 if down else 1, Ho=Ho, Wo=Wo,
                       W=self.packed(conv.weight), bias=conv.bias, Cout=Cc, out=out, ldo=Cc)
         return dict(parts=[(out, Cc)], H=Ho, W=Wo)
+
+    # ------------------------------------------------------------------ autotune
+    def autotune(self, rounds=3, reps=6):
+        """Time every legal (tile shape, K-chunk, split-K) variant of each implicit-GEMM launch of this plan
+        on the device and pin the fastest in the launch arguments.  Shapes are static per plan, so this
+        runs once (about half a second); the built-in makespan model is only the starting point."""
+        L = nat.lib()
+        s = nat.stream()
+        codes = (C.c_int * 64)()
+        ev0, ev1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        tuned = 0
+        for fn, args in self.steps:
+            if fn is not L.lfvdm_conv_igemm:
+                continue
+            a = args[0]._obj
+            n = L.lfvdm_conv_igemm_candidates(C.byref(a), codes, 64)
+            best, best_t = 0, float("inf")
+            for code in [0] + [codes[i] for i in range(n)]:
+                a.tune = code
+                if fn(C.byref(a), s) != 0:
+                    continue
+                t_min = float("inf")
+                for _ in range(rounds):
+                    ev0.record()
+                    for _ in range(reps):
+                        fn(C.byref(a), s)
+                    ev1.record()
+                    ev1.synchronize()
+                    t_min = min(t_min, ev0.elapsed_time(ev1))
+                if t_min < best_t * 0.98:      # prefer earlier (simpler) candidates on ties
+                    best, best_t = code, t_min
+            a.tune = best
+            tuned += 1
+        self.tuned = True
+        return tuned
 
     # ------------------------------------------------------------------ run
     def weight_signature(self):

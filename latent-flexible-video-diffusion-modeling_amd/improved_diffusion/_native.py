@@ -30,7 +30,8 @@ class ConvArgs(C.Structure):
         ("W", c_fp), ("bias", c_fp), ("Cout", C.c_int32),
         ("s2src0", c_fp), ("s2src1", c_fp), ("s2C0", C.c_int32), ("s2C1", C.c_int32), ("W2", c_fp), ("bias2", c_fp),
         ("res", c_fp), ("ldr", C.c_int32), ("resA", c_fp), ("resB", c_fp),
-        ("out", c_fp), ("ldo", C.c_int32), ("out_mode", C.c_int32),
+        ("out", c_fp), ("ldo", C.c_int32), ("out_mode", C.c_int32), ("tune", C.c_int32),
+        ("splitk_ws", c_fp), ("splitk_cnt", c_fp), ("splitk_ws_floats", C.c_int64), ("splitk_cnt_ints", C.c_int64),
     ]
 
 
@@ -56,6 +57,7 @@ _SIGS = {
     "lfvdm_abi_version": ([], c_i),
     "lfvdm_conv_igemm": ([C.POINTER(ConvArgs), c_fp], c_i),
     "lfvdm_conv_igemm_config": ([C.POINTER(ConvArgs), C.POINTER(c_i), C.POINTER(c_i)], c_i),
+    "lfvdm_conv_igemm_candidates": ([C.POINTER(ConvArgs), C.POINTER(c_i), c_i], c_i),
     "lfvdm_pack_conv_weight": ([c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_conv_wgrad": ([C.POINTER(ConvArgs), c_fp], c_i),
     "lfvdm_pack_conv_weight_t": ([c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),

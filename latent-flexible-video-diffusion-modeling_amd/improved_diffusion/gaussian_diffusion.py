@@ -409,6 +409,12 @@ class GraphSampler:
             pl.set_inputs(img, model_kwargs["x0"], th.zeros(B, device=pl.dev), model_kwargs["frame_indices"],
                           model_kwargs["obs_mask"], model_kwargs["latent_mask"])
             if self.graph is None:
+                import os
+                if os.environ.get("LFVDM_AUTOTUNE", "1") != "0" and not getattr(pl, "tuned", False):
+                    saved0 = pl.x_in.clone()
+                    pl.launch()               # realistic operand contents for the timing runs
+                    pl.autotune()
+                    pl.x_in.copy_(saved0)
                 # warm-up on a side stream (sets kernel attributes, fills caches), then capture
                 saved = pl.x_in.clone()
                 self.t_buf.fill_(self.diffusion.num_timesteps - 1)

@@ -326,3 +326,31 @@ def test_diffusion_ops(nat):
     mo = torch.empty(B, device="cuda")
     nat.masked_mse(x.cuda(), eps.cuda(), mask.cuda(), mo, B, T, Cc * H * H)
     close(mo, do.masked_mean_flat((x - eps) ** 2, mask.view(B, T, 1, 1, 1)), 1e-6, rtol=1e-5)
+
+
+def test_conv_splitk_is_exact_and_deterministic(nat):
+    """Every legal (tile shape, K-chunk, split-K) variant of one small-M launch gives the same conv, and the
+    split-K variants (ordered last-arriver reduction) are bitwise reproducible run to run."""
+    import ctypes as C
+    N, Cin, Cout, H = 40, 128, 128, 2
+    x, w, b = rnd("sk/x", N, Cin, H, H), rnd("sk/w", Cout, Cin, 3, 3, scale=0.05), rnd("sk/b", Cout)
+    res = rnd("sk/r", N * H * H, Cout)
+    ref = F.conv2d(x, w, b, padding=1) + res.view(N, H, H, Cout).permute(0, 3, 1, 2)
+    out = torch.empty(N * H * H, Cout, device="cuda")
+    ws = torch.empty(1 << 20, device="cuda")
+    cnt = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    keep = dict(src0=cl(x), W=packed(nat, w), bias=b.cuda(), res=res.cuda())   # the struct holds raw pointers
+    a = nat.fill_conv_args(C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, Cout=Cout, ldr=Cout, out=out, ldo=Cout, **keep)
+    a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+    codes = (C.c_int * 64)()
+    n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 64)
+    split = [codes[i] for i in range(n) if (codes[i] - 1) >> 5 > 0]
+    assert n >= 8 and len(split) >= 3, "split-K candidates expected for a small-M layer"
+    for code in [codes[i] for i in range(n)]:
+        a.tune = code
+        out.zero_()
+        nat.conv_igemm_struct(a)
+        close(from_cl(out, N, H, H, Cout), ref, 5e-5)
+        first = out.clone()
+        nat.conv_igemm_struct(a)
+        assert torch.equal(out, first), f"tune code {code} is not reproducible"
