@@ -179,6 +179,7 @@ def bench_train(rank, world, dev, steps, warmup):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     from improved_diffusion.logger import logger
+    loop._flush_loss_log()
     loss = float(logger.name2val.get("loss", float("nan")))
     logger.dumpkvs()
     P = sum(p.numel() for p in model.parameters())
@@ -244,7 +245,7 @@ def main():
         del sampler
         diffusion._samplers.clear()
         th.cuda.empty_cache()
-        train = bench_train(rank, world, dev, args.train_steps, 2)
+        train = bench_train(rank, world, dev, args.train_steps, 4)   # 2 eager + capture + 1 replay before timing
         sampler = diffusion._graph_sampler(model, shape, True)   # for the kernel breakdown below
         sampler.begin(th.randn(*shape, device=dev), inputs)
 

@@ -113,8 +113,9 @@ int lfvdm_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int C
  *                     (Wt[ci][tap][co] = W[co][ci][flip(tap)]); stride-2 convs use up = 2.
  *   weight gradient : lfvdm_conv_wgrad.  `a` describes the FORWARD operand (src*, C*, N, Hs, Ws, up,
  *                     stride, ksize, Ho, Wo, coefA/B, act); a->res = dout rows [M][ldr]; a->out = packed
- *                     gradient [Cout][k*k][Cin], ACCUMULATED with float atomics (zero it first);
- *                     a->bias = bias gradient [Cout] (accumulated) or NULL.
+ *                     gradient [Cout][k*k][Cin] (a->out_mode = 0) or the OIHW parameter gradient itself
+ *                     (a->out_mode = 1), ACCUMULATED with float atomics; a->bias = bias gradient [Cout]
+ *                     (accumulated) or NULL.
  *   lfvdm_unpack_conv_grad: packed [Cout][k*k][Cin] -> OIHW gradient (accumulate = 1: +=).
  * ------------------------------------------------------------------------------------- */
 int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream);

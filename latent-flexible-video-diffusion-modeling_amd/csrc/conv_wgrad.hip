@@ -136,10 +136,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const lfvdm_conv_args p
     // ---- accumulate the partial tile: D lane l holds column k = l&31, rows co = (r&3)+8*(r>>2)+4*(l>>5)
     const int Ktot = taps * Cin;
     float* dW = p.out;
+    const bool oihw = p.out_mode == 1;   // accumulate straight into the OIHW parameter gradient
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co < p.Cout) atomicAdd(dW + (size_t)co * Ktot + (size_t)tap * Cin + cc + (lane & 31), acc[r]);
+        if (co < p.Cout) {
+            const int ci = cc + (lane & 31);
+            float* dst = oihw ? dW + ((size_t)co * Cin + ci) * taps + tap : dW + (size_t)co * Ktot + (size_t)tap * Cin + ci;
+            atomicAdd(dst, acc[r]);
+        }
     }
     if (kt == 0 && p.bias != nullptr) {
         // bias gradient: column sums of this wave's dout rows (lanes with equal col differ in bits 3..5)

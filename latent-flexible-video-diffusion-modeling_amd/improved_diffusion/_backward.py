@@ -45,6 +45,22 @@ def _pack_t(w4):
     return out
 
 
+def _grad_of(p):
+    """The parameter's gradient buffer (the arena view set up by TrainLoop, or a fresh zero tensor)."""
+    if p.grad is None:
+        p.grad = th.zeros_like(p)
+    return p.grad
+
+
+def _wgrad_accumulate(w, b, **kw):
+    """Weight/bias gradient accumulated DIRECTLY into ``w.grad`` / ``b.grad`` by the wgrad kernel (OIHW
+    addressing for 3x3): no temporary, no zero fill, no unpack, and no AccumulateGrad add per parameter."""
+    kw.pop("ksize", None)
+    k = w.shape[2] if w.dim() == 4 else 1
+    nat.conv_wgrad(out=_grad_of(w), bias=_grad_of(b) if b is not None else None, Cout=w.shape[0], ksize=k,
+                   out_mode=1 if k == 3 else 0, **kw)
+
+
 def _wgrad_into(grad_w_shape, like, **kw):
     """Run lfvdm_conv_wgrad into a zeroed packed buffer and return (dW in the parameter layout, db)."""
     Cout, Cin = grad_w_shape[0], grad_w_shape[1]
@@ -74,6 +90,7 @@ class ConvFn(th.autograd.Function):
         nat.conv_igemm(src0=x, C0=Cin, N=N, Hs=H, Ws=W, up=int(up), stride=stride, Ho=Ho, Wo=Wo, W=_pack(w), bias=b,
                        Cout=Cout, out=out, ldo=Cout)
         ctx.save_for_backward(x, w)
+        ctx.params = (w, b) if (w.is_leaf and b.is_leaf) else None   # leaf parameters: accumulate in place
         ctx.geom = (N, H, W, stride, up, Ho, Wo)
         return out
 
@@ -83,8 +100,12 @@ class ConvFn(th.autograd.Function):
         N, H, W, stride, up, Ho, Wo = ctx.geom
         Cout, Cin = w.shape[0], w.shape[1]
         dout = dout.contiguous()
-        dw, db = _wgrad_into(tuple(w.shape), x, src0=x, C0=Cin, N=N, Hs=H, Ws=W, up=int(up), stride=stride, Ho=Ho, Wo=Wo,
-                             res=dout, ldr=Cout)
+        wkw = dict(src0=x, C0=Cin, N=N, Hs=H, Ws=W, up=int(up), stride=stride, Ho=Ho, Wo=Wo, res=dout, ldr=Cout)
+        if ctx.params is not None:
+            _wgrad_accumulate(ctx.params[0], ctx.params[1], **wkw)
+            dw = db = None
+        else:
+            dw, db = _wgrad_into(tuple(w.shape), x, **wkw)
         dx = None
         if ctx.needs_input_grad[0]:
             wt = _pack_t(w)
@@ -193,6 +214,7 @@ class ResBlockFn(th.autograd.Function):
             kw.update(s2src0=a, s2src1=b, s2C0=C0, s2C1=C1, W2=ws.view(Cout, Cin), bias2=bs)
         nat.conv_igemm(**kw)
         ctx.save_for_backward(a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2)
+        ctx.params = (w1, b1, w2, b2, ws, bs)
         ctx.geom = (N, H, W, T, C0, C1, Cout)
         return out
 
@@ -203,15 +225,17 @@ class ResBlockFn(th.autograd.Function):
         Cin, P = C0 + C1, H * W
         dout = dout.contiguous()
         geo = dict(N=N, Hs=H, Ws=W, Ho=H, Wo=W)
-        # conv2: weight grad on the fused operand act(GN2(h1)), data grad -> da2
-        dw2, db2 = _wgrad_into(tuple(w2.shape), a, src0=h1, C0=Cout, coefA=cA2, coefB=cB2, act=nat.ACT_SILU, res=dout,
-                               ldr=Cout, **geo)
+        pw1, pb1, pw2, pb2, pws, pbs = ctx.params
+        # conv2: weight grad on the fused operand act(GN2(h1)) (accumulated in place), data grad -> da2
+        _wgrad_accumulate(pw2, pb2, src0=h1, C0=Cout, coefA=cA2, coefB=cB2, act=nat.ACT_SILU, res=dout, ldr=Cout, **geo)
+        dw2 = db2 = None
         da2 = _new(N * P, Cout, like=a)
         nat.conv_igemm(src0=dout, C0=Cout, W=_pack_t(w2), Cout=Cout, out=da2, ldo=Cout, **geo)
         dh1, _, dg2, dbe2, dfilm = _gn_backward(da2, h1, None, Cout, 0, N, P, cA2, cB2, st2, nat.ACT_SILU, g2, be2, film, T)
         # conv1
-        dw1, db1 = _wgrad_into(tuple(w1.shape), a, src0=a, src1=b, C0=C0, C1=C1, coefA=cA1, coefB=cB1, act=nat.ACT_SILU,
-                               res=dh1, ldr=Cout, **geo)
+        _wgrad_accumulate(pw1, pb1, src0=a, src1=b, C0=C0, C1=C1, coefA=cA1, coefB=cB1, act=nat.ACT_SILU, res=dh1,
+                          ldr=Cout, **geo)
+        dw1 = db1 = None
         da1 = _new(N * P, Cin, like=a)
         nat.conv_igemm(src0=dh1, C0=Cout, W=_pack_t(w1), Cout=Cin, out=da1, ldo=Cin, **geo)
         dxa, dxb, dg1, dbe1, _ = _gn_backward(da1, a, b, C0, C1, N, P, cA1, cB1, st1, nat.ACT_SILU, g1, be1, None, T)
@@ -220,7 +244,7 @@ class ResBlockFn(th.autograd.Function):
         if ws is None:
             dxa = dxa + dout
         else:
-            dws, dbs = _wgrad_into((Cout, Cin, 1, 1), a, src0=a, src1=b, C0=C0, C1=C1, ksize=1, res=dout, ldr=Cout, **geo)
+            _wgrad_accumulate(pws, pbs, src0=a, src1=b, C0=C0, C1=C1, ksize=1, res=dout, ldr=Cout, **geo)
             dsk = _new(N * P, Cin, like=a)
             nat.conv_igemm(src0=dout, C0=Cout, ksize=1, W=_pack_t(ws), Cout=Cin, out=dsk, ldo=Cin, **geo)
             dxa = dxa + dsk[:, :C0]
@@ -302,6 +326,7 @@ class TemporalAttnFn(th.autograd.Function):
         nat.conv_igemm(src0=o, C0=C, N=M, Hs=1, Ws=1, Ho=1, Wo=1, ksize=1, W=wproj, bias=bproj, Cout=C, res=xn, ldr=C, out=y,
                        ldo=C)
         ctx.save_for_backward(x, gn_w, wqkv, wproj, Rq, Rk, Rv, mask, xn, qkv, o)
+        ctx.params = (wqkv, bqkv, wproj, bproj)
         ctx.geom = (B, T, P, heads)
         return y
 
@@ -313,7 +338,9 @@ class TemporalAttnFn(th.autograd.Function):
         M = B * T * P
         dy = dy.contiguous()
         one = dict(N=M, Hs=1, Ws=1, Ho=1, Wo=1)
-        dwp, dbp = _wgrad_into((C, C), x, src0=o, C0=C, res=dy, ldr=C, **one)
+        pwq, pbq, pwp, pbp = ctx.params
+        _wgrad_accumulate(pwp, pbp, src0=o, C0=C, res=dy, ldr=C, **one)
+        dwp = dbp = dwq = dbq = None
         do = _new(M, C, like=x)
         nat.conv_igemm(src0=dy, C0=C, ksize=1, W=_pack_t(wproj.view(C, C, 1, 1)), Cout=C, out=do, ldo=C, **one)
         # attention core backward (interim: recompute on batched library GEMMs)
@@ -323,7 +350,7 @@ class TemporalAttnFn(th.autograd.Function):
             o_ = _temporal_core_torch(qkv_, Rs[0], Rs[1], Rs[2], mask, B, T, P, C, heads)
             dqkv, dRq, dRk, dRv = th.autograd.grad(o_, [qkv_] + Rs, do)
         dqkv = dqkv.contiguous()
-        dwq, dbq = _wgrad_into((3 * C, C), x, src0=xn, C0=C, res=dqkv, ldr=3 * C, **one)
+        _wgrad_accumulate(pwq, pbq, src0=xn, C0=C, res=dqkv, ldr=3 * C, **one)
         dxn = _new(M, C, like=x)
         nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
                        ldo=C, **one)
@@ -351,6 +378,7 @@ class SpatialAttnFn(th.autograd.Function):
         nat.conv_igemm(src0=o, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=wproj, bias=bproj, Cout=C, res=x, ldr=C, resA=cA,
                        resB=cB, out=y, ldo=C)
         ctx.save_for_backward(x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o)
+        ctx.params = (wqkv, bqkv, wproj, bproj)
         ctx.geom = (N, P, heads)
         return y
 
@@ -362,7 +390,9 @@ class SpatialAttnFn(th.autograd.Function):
         M, Fh = N * P, C // heads
         dy = dy.contiguous()
         geo = dict(N=N, Hs=P, Ws=1, Ho=P, Wo=1)
-        dwp, dbp = _wgrad_into((C, C), x, src0=o, C0=C, ksize=1, res=dy, ldr=C, **geo)
+        pwq, pbq, pwp, pbp = ctx.params
+        _wgrad_accumulate(pwp, pbp, src0=o, C0=C, ksize=1, res=dy, ldr=C, **geo)
+        dwp = dbp = dwq = dbq = None
         do = _new(M, C, like=x)
         nat.conv_igemm(src0=dy, C0=C, ksize=1, W=_pack_t(wproj.view(C, C, 1, 1)), Cout=C, out=do, ldo=C, **geo)
         # core backward (interim): S, P recomputed with batched library GEMMs
@@ -376,7 +406,7 @@ class SpatialAttnFn(th.autograd.Function):
         dq = (dS @ k) * scale
         dk = dS.transpose(-1, -2) @ (q * scale)
         dqkv = th.stack([dq, dk, dv], dim=0).permute(1, 3, 0, 2, 4).reshape(M, 3 * C).contiguous()
-        dwq, dbq = _wgrad_into((3 * C, C), x, src0=x, C0=C, ksize=1, coefA=cA, coefB=cB, res=dqkv, ldr=3 * C, **geo)
+        _wgrad_accumulate(pwq, pbq, src0=x, C0=C, ksize=1, coefA=cA, coefB=cB, res=dqkv, ldr=3 * C, **geo)
         dxn = _new(M, C, like=x)   # gradient w.r.t. the normalised tensor: qkv path + residual
         nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
                        ldo=C, **geo)
@@ -408,7 +438,9 @@ class UNetFunction:
         obs = obs_mask.reshape(B, T, 1, 1, 1).to(th.float32)
         mask = (obs_mask.reshape(B, T) + latent_mask.reshape(B, T)).clamp(max=1).to(th.float32).contiguous()
         # --- embeddings (per batch element: rows of the reference's (B*T, 4ch) emb are equal within b)
-        freqs = timestep_freqs(ch).to(x.device)
+        freqs = getattr(engine, "_freqs", None)
+        if freqs is None or freqs.device != x.device:
+            freqs = engine._freqs = timestep_freqs(ch).to(x.device)     # uploaded once (graph capture safe)
         args = timesteps.to(th.float32)[:, None] * freqs[None]
         temb = th.cat([th.cos(args), th.sin(args)], dim=-1)
         emb = m.time_embed[2](F.silu(m.time_embed[0](temb)))            # (B, 4ch)

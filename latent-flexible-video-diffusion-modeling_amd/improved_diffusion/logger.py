@@ -19,6 +19,7 @@ class Logger(object):
         self.name2val = defaultdict(float)
         self.name2cnt = defaultdict(int)
         self.nondistributed_name2val = defaultdict(float)
+        self.pre_dump_hooks = []
 
     def logkv(self, key, val, distributed=True):
         (self.name2val if distributed else self.nondistributed_name2val)[key] = val
@@ -29,6 +30,8 @@ class Logger(object):
         self.name2cnt[key] = cnt + 1
 
     def dumpkvs(self):
+        for hook in list(self.pre_dump_hooks):     # e.g. TrainLoop's deferred loss terms
+            hook()
         local = {k: (v, self.name2cnt.get(k, 1)) for k, v in self.name2val.items()}
         rank = dist.get_rank() if dist.is_initialized() else 0
         if dist.is_initialized() and dist.get_world_size() > 1:

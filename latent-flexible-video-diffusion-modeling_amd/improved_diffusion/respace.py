@@ -61,7 +61,9 @@ class SpacedDiffusion(GaussianDiffusion):
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model
-        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        if not hasattr(self, "_map_cache"):
+            self._map_cache = {}      # device-resident remap tables, shared by every wrapper of this diffusion
+        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps, self._map_cache)
 
     def _scale_timesteps(self, t):
         return t  # done by the wrapped model (reference respace.py:105-107)
@@ -77,12 +79,12 @@ class _WrappedModel:
     """Maps spaced timestep indices to the base process and rescales them to 0..1000
     (reference respace.py:110-124)."""
 
-    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
+    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps, map_cache=None):
         self.model = model
         self.timestep_map = timestep_map
         self.rescale_timesteps = rescale_timesteps
         self.original_num_steps = original_num_steps
-        self._maps = {}
+        self._maps = map_cache if map_cache is not None else {}
 
     def parameters(self):
         return self.model.parameters()

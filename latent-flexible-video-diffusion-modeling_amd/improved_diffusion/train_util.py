@@ -78,6 +78,7 @@ class TrainLoop:
         if use_fp16:
             raise NotImplementedError("use_fp16 is off in the reference defaults; the native path is fp32")
         self.args = args
+        dist_util.limit_host_threads()
         self.model = model
         self.diffusion = diffusion
         self.data = data
@@ -135,6 +136,7 @@ class TrainLoop:
             self.ema_flat.append(flat)
         self.ema_params = [self.arena.views(f) for f in self.ema_flat]
         self.grad_sqsum = th.zeros(1, device=dev)
+        self._graph_state = {}
 
         self.use_ddp = self.world > 1
         self.ddp_model = self.model            # gradient averaging is done on the arena (see optimize_normal)
@@ -176,10 +178,10 @@ class TrainLoop:
         """A random arithmetic-ish progression of <= max_indices frame indices in [0, T)
         (reference train_util.py:180-191; same sequence of random draws)."""
         while True:
-            s = th.randint(low=1, high=max_indices + 1, size=())
+            s = int(th.randint(low=1, high=max_indices + 1, size=()))
             max_scale = T / (float(s) - 0.999)
             scale = np.exp(np.random.rand() * np.log(max_scale))
-            pos = th.rand(()) * (T - scale * (s - 1))
+            pos = th.rand(()) * (T - scale * (s - 1))      # float32 tensor arithmetic, as in the reference
             indices = [int(pos + i * scale) for i in range(s)]
             if all(0 <= i < T for i in indices):
                 return indices
@@ -190,17 +192,22 @@ class TrainLoop:
         (reference train_util.py:193-222)."""
         N = self.max_frames
         B, T, *_ = batch1.shape
-        masks = {k: th.zeros_like(batch1[:, :, :1, :1, :1]) for k in ('obs', 'latent')}
-        for obs_row, latent_row in zip(masks['obs'], masks['latent']):
+        # Host-side bookkeeping in numpy (the reference's loop indexes torch rows element by element, which
+        # costs tens of ms per step); the sequence of random draws is the reference's.
+        obs_np = np.zeros((B, T), dtype=np.float32)
+        lat_np = np.zeros((B, T), dtype=np.float32)
+        for obs_row, latent_row in zip(obs_np, lat_np):
             latent_row[self.sample_some_indices(max_indices=N, T=T)] = 1.
             while True:
                 mask = obs_row if th.rand(()) < 0.5 else latent_row
-                indices = th.tensor(self.sample_some_indices(max_indices=N, T=T))
-                taken = (obs_row[indices] + latent_row[indices]).view(-1)
-                indices = indices[taken == 0]
-                if len(indices) > N - sum(obs_row) - sum(latent_row):
+                indices = np.asarray(self.sample_some_indices(max_indices=N, T=T), dtype=np.int64)
+                indices = indices[(obs_row[indices] + latent_row[indices]) == 0]
+                if len(indices) > N - obs_row.sum() - latent_row.sum():
                     break
                 mask[indices] = 1.
+        shape5 = (B, T, 1, 1, 1)
+        masks = {'obs': th.from_numpy(obs_np).to(batch1.dtype).view(shape5).to(batch1.device),
+                 'latent': th.from_numpy(lat_np).to(batch1.dtype).view(shape5).to(batch1.device)}
         if len(set_masks['obs']) > 0:
             for k in masks:
                 n_set = min(len(set_masks[k]), len(masks[k]))
@@ -259,6 +266,41 @@ class TrainLoop:
         self.log_step()
         logger.logkv("timing/step_time", time() - t0)
 
+    def _micro_step(self, micro, frame_indices, obs_mask, latent_mask, t, weights):
+        """q_sample -> U-Net forward -> masked MSE -> backward for one micro-batch (device tensors in, the
+        per-sample loss terms out).  No host synchronisation inside: the body is hipGraph-capturable."""
+        losses = self.diffusion.training_losses(
+            self.ddp_model, micro, t,
+            model_kwargs={'frame_indices': frame_indices, 'obs_mask': obs_mask, 'latent_mask': latent_mask, 'x0': micro},
+            latent_mask=(1 - obs_mask) if self.pad_with_random_frames else latent_mask, eval_mask=latent_mask)
+        loss = (losses["loss"] * weights).mean()
+        loss.backward()          # gradients accumulate in the arena across micro-batches
+        return {k: (v * weights).detach() for k, v in losses.items()}, losses["loss"].detach()
+
+    def _graphed_micro_step(self, inputs):
+        """Replay the captured micro-step (forward + backward, ~1000 launches) as ONE hipGraph: the training
+        step is host-bound otherwise.  Captured once the shapes have been seen twice; static input buffers."""
+        key = tuple((tuple(x.shape), x.dtype) for x in inputs)
+        st = self._graph_state
+        if st.get("key") != key:
+            st.clear()
+            st.update(key=key, seen=0)
+        st["seen"] += 1
+        if st["seen"] <= 2 or os.environ.get("LFVDM_TRAIN_GRAPH", "1") == "0":
+            return self._micro_step(*inputs)          # eager warm-up (also sets kernel attributes)
+        if "graph" not in st:
+            st["static_in"] = [x.clone() for x in inputs]
+            th.cuda.synchronize()
+            g = th.cuda.CUDAGraph()
+            with th.cuda.graph(g):
+                st["static_out"] = self._micro_step(*st["static_in"])
+            st["graph"] = g
+            # the capture itself does not execute: run the step for real below
+        for dst, src in zip(st["static_in"], inputs):
+            dst.copy_(src)
+        st["graph"].replay()
+        return st["static_out"]
+
     def forward_backward(self):
         self.arena.zero_grad()
         batch1 = next(self.data)[0]
@@ -272,15 +314,26 @@ class TrainLoop:
             micro, frame_indices = micro.to(dev), frame_indices.to(dev)
             obs_mask, latent_mask = obs_mask.to(dev), latent_mask.to(dev)
             t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
-            losses = self.diffusion.training_losses(
-                self.ddp_model, micro, t,
-                model_kwargs={'frame_indices': frame_indices, 'obs_mask': obs_mask, 'latent_mask': latent_mask, 'x0': micro},
-                latent_mask=(1 - obs_mask) if self.pad_with_random_frames else latent_mask, eval_mask=latent_mask)
+            inputs = (micro, frame_indices, obs_mask, latent_mask, t, weights)
+            if micro.is_cuda and self.pad_with_random_frames:
+                weighted, raw = self._graphed_micro_step(inputs)
+            else:
+                weighted, raw = self._micro_step(*inputs)
             if isinstance(self.schedule_sampler, LossAwareSampler):
-                self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
-            loss = (losses["loss"] * weights).mean()
-            log_loss_dict(self.diffusion, t, {k: v * weights for k, v in losses.items()})
-            loss.backward()      # gradients accumulate in the arena across micro-batches
+                self.schedule_sampler.update_with_local_losses(t, raw)
+            # The loss terms are logged one micro-step late (or at the next dumpkvs/save): reading them now
+            # would stall the host on the GPU and serialise batch preparation with the device work.
+            self._flush_loss_log()
+            self._pending_log = (t.clone(), {k: v.clone() for k, v in weighted.items()})
+
+    def _flush_loss_log(self):
+        if self._flush_loss_log not in logger.pre_dump_hooks:
+            logger.pre_dump_hooks[:] = [h for h in logger.pre_dump_hooks
+                                        if getattr(h, "__func__", None) is not TrainLoop._flush_loss_log]
+            logger.pre_dump_hooks.append(self._flush_loss_log)
+        pending, self._pending_log = getattr(self, "_pending_log", None), None
+        if pending is not None:
+            log_loss_dict(self.diffusion, pending[0], pending[1])
 
     def optimize_normal(self):
         """All-reduce (once) + fused AdamW/EMA/grad-norm (reference train_util.py:346-357)."""

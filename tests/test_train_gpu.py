@@ -73,6 +73,7 @@ def test_training_reduces_loss_and_checkpoint_roundtrip(tmp_path):
     losses = []
     for _ in range(12):
         loop.run_step()
+        loop._flush_loss_log()          # loss terms are logged one step late unless flushed
         losses.append(logger.name2val["loss"])
         logger.dumpkvs()
         loop.step += 1
