@@ -190,6 +190,42 @@ def bench_train(rank, world, dev, steps, warmup):
                         "one RCCL all-reduce of the fp32 gradient arena per step (BASELINE.json configs[2])"}
 
 
+def bench_long_video(dev, max_windows):
+    """BASELINE.json configs[3]: one 1000-frame video generated by the hierarchy-2 schedule in windows of <= 20
+    frames, 250 respaced steps per window (97 windows with 36 observed frames), batch 1, cfg-B network."""
+    from types import SimpleNamespace
+    from improved_diffusion.video_sampler import sample_video, default_sampling_args
+    from improved_diffusion.sampling_schemes import sampling_schemes
+    model, diffusion = make_model_and_diffusion(64, dev, respacing="250")
+    T = 1000
+    g = th.Generator().manual_seed(77)
+    video = (th.randn(1, 1, 4, 16, 16, generator=g) + 0.1 * th.randn(1, T, 4, 16, 16, generator=g).cumsum(1)) * 0.5
+    args = default_sampling_args(sampling_scheme="hierarchy-2", n_obs=36, max_frames=20, max_latent_frames=10, device=str(dev))
+    if max_windows < 97:      # truncated run: shorten the video so that the schedule ends early
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            while True:
+                n = sum(1 for _ in iter(sampling_schemes["hierarchy-2"](video_length=T, num_obs=36, max_frames=20, step_size=10)))
+                if n <= max_windows or T <= 60:
+                    break
+                T -= 10
+        video = video[:, :T].contiguous()
+    th.manual_seed(5)
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        samples, used = sample_video(args, model, diffusion, video, verbose=False)
+    th.cuda.synchronize()
+    el = time.perf_counter() - t0
+    steps = len(used) * diffusion.num_timesteps
+    lengths = sorted({len(o[0]) + len(l[0]) for o, l in used})
+    return {"workload": f"long video: hierarchy-2, T={T}, K=20, step=10, n_obs=36, respacing 250 (BASELINE.json configs[3])",
+            "windows": len(used), "window_lengths": lengths, "denoising_steps": steps, "seconds": round(el, 2),
+            "steps_per_s_incl_setup": round(steps / el, 1), "frames_generated_per_s": round((T - 36) / el, 2),
+            "finite": bool(th.isfinite(samples).all())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +234,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10, help="timed optimizer steps of the training leg (0 = skip)")
+    ap.add_argument("--long-video-windows", type=int, default=0,
+                    help="also run the hierarchy-2 long-video leg with at most this many windows (97 = full; 0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -261,6 +299,8 @@ def main():
     }
     if train is not None:
         out["train"] = train
+    if args.long_video_windows > 0 and rank == 0:
+        out["long_video"] = bench_long_video(dev, args.long_video_windows)
     if rank == 0:
         if not args.no_breakdown:
             groups = kernel_breakdown(sampler.plan)

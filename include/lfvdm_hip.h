@@ -89,7 +89,8 @@ typedef struct lfvdm_conv_args {
     int32_t tune;     /* 0: built-in makespan model picks tile shape / K-chunk (never split-K); otherwise a
                        * code returned by lfvdm_conv_igemm_candidates (set by an autotuner for a fixed shape) */
     /* optional workspace enabling deterministic split-K over workgroups for small-M layers: slabs of partial
-     * tiles + one arrival ticket per output tile (the launcher zeroes the tickets with a memset node) */
+     * tiles + one arrival ticket per output tile.  The tickets must be ZERO before the first launch; every
+     * launch leaves them zero again (the last slice to arrive resets its tile's ticket) */
     float* splitk_ws;
     int32_t* splitk_cnt;
     int64_t splitk_ws_floats;

@@ -405,6 +405,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             const int ticket = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (ticket == KZ - 1) ? 1 : 0;
             if (s_last) {
+                // self-cleaning ticket: nobody else touches it once all KZ slices have arrived, and the next
+                // launch is stream-ordered behind this one - no memset node per launch
+                __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -516,9 +519,6 @@ int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
         attr_set = true;
     }
     const dim3 grid((unsigned)((M + CF::BM - 1) / CF::BM), (unsigned)((a->Cout + CF::BN - 1) / CF::BN), (unsigned)kz);
-    if (kz > 1) {   // arrival tickets of the split-K tiles start from zero (stream-ordered memset node)
-        if (hipMemsetAsync(a->splitk_cnt, 0, (size_t)grid.x * grid.y * sizeof(int), s) != hipSuccess) return LFVDM_E_LAUNCH;
-    }
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;

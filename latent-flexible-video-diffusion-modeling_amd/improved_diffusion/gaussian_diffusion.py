@@ -303,7 +303,12 @@ class GaussianDiffusion:
         s = self._samplers.get(key)
         if s is None or s.unet is not unet or s.engine is not unet.native_engine():
             s = GraphSampler(self, unet, shape, clip_denoised)
-            self._samplers = {key: s}  # keep one (graphs pin device memory)
+            self._samplers.pop(key, None)
+            while len(self._samplers) >= 4:   # graphs pin device memory: keep the few window shapes of a
+                self._samplers.pop(next(iter(self._samplers)))   # long-video schedule (K, K-1, tail)
+        else:
+            self._samplers.pop(key)           # re-insert: most recently used last
+        self._samplers[key] = s
         return s
 
     def model_timestep_table(self, device):
@@ -410,6 +415,9 @@ class GraphSampler:
                           model_kwargs["obs_mask"], model_kwargs["latent_mask"])
             if self.graph is None:
                 import os
+                # building the graph draws warm-up noise: keep the caller's RNG stream untouched, so that a
+                # seed gives the same video whether or not this window shape was seen before
+                rng_state = th.cuda.get_rng_state(pl.dev)
                 if os.environ.get("LFVDM_AUTOTUNE", "1") != "0" and not getattr(pl, "tuned", False):
                     saved0 = pl.x_in.clone()
                     pl.launch()               # realistic operand contents for the timing runs
@@ -428,6 +436,8 @@ class GraphSampler:
                     self._step_body()
                 self.graph = g
                 pl.x_in.copy_(saved)
+                th.cuda.synchronize()
+                th.cuda.set_rng_state(rng_state, pl.dev)
             self.t_buf.fill_(self.diffusion.num_timesteps - 1)
         self.expected_t = self.diffusion.num_timesteps - 1
 

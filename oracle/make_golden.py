@@ -294,10 +294,43 @@ def gen_diffusion():
     np.savez_compressed(os.path.join(OUT, "diffusion.npz"), **out)
 
 
+SCHEME_CASES = [
+    # (scheme, video_length, n_obs, max_frames, step_size)
+    ("autoreg", 1000, 36, 20, 10), ("autoreg", 1000, 0, 20, 10), ("autoreg", 47, 3, 8, 3),
+    ("long-range", 1000, 36, 20, 10), ("long-range", 1000, 0, 20, 10), ("long-range", 61, 5, 10, 4),
+    ("hierarchy-2", 1000, 36, 20, 10), ("hierarchy-2", 1000, 0, 20, 10), ("hierarchy-2", 300, 36, 14, 7),
+    ("hierarchy-2", 100, 2, 8, 2), ("hierarchy-3", 1000, 36, 20, 10), ("hierarchy-3", 300, 0, 20, 5),
+    ("hierarchy-4", 300, 5, 10, 4), ("hierarchy-5", 1000, 1, 20, 10),
+]
+
+
+def gen_schemes():
+    """Window index sequences of the reference's non-adaptive sampling schemes."""
+    import contextlib
+    import io
+    import json
+    from improved_diffusion import sampling_schemes as rss  # reference
+    cases = []
+    for name, T, n_obs, K, step in SCHEME_CASES:
+        with contextlib.redirect_stdout(io.StringIO()):
+            it = iter(rss.sampling_schemes[name](video_length=T, num_obs=n_obs, max_frames=K, step_size=step))
+            it.set_videos([None, None])          # batch of 2: every video gets the same lists
+            windows = [([int(i) for i in o[0]], [int(i) for i in l[0]]) for o, l in it]
+        assert sorted(set(range(n_obs)) | {i for _, l in windows for i in l}) == list(range(T))
+        cases.append(dict(scheme=name, video_length=T, n_obs=n_obs, max_frames=K, step_size=step, windows=windows))
+        print(f"[schemes] {name} T={T} n_obs={n_obs} K={K} step={step}: {len(windows)} windows")
+    with open(os.path.join(OUT, "schemes.json"), "w") as f:
+        json.dump(cases, f, separators=(",", ":"))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "schemes":
+        gen_schemes()
+        sys.exit(0)
     gen_ops()
     gen_forward()
     gen_backward()
     gen_diffusion()
+    gen_schemes()
     print("golden vectors written to", OUT)

@@ -23,6 +23,8 @@ def main():
     pl.refresh_weights()
     pl.set_inputs(th.randn(B, T, 4, 16, 16, device=dev), inputs["x0"], th.tensor([500.0, 20.0], device=dev),
                   inputs["frame_indices"], inputs["obs_mask"], inputs["latent_mask"])
+    if os.environ.get('LFVDM_AUTOTUNE', '1') != '0':
+        pl.autotune()
     L = nat.lib()
     s = nat.stream()
     n = len(pl.steps)
