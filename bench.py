@@ -226,7 +226,19 @@ def bench_long_video(dev, max_windows):
             "finite": bool(th.isfinite(samples).all())}
 
 
+def pmc_traffic(kernel_name):
+    """HBM-side bytes per launch of one kernel from the committed rocprofv3 counter passes
+    (profiles/r01_pmc_traffic.json, produced by tools_pmc_target.py + tools_pmc_summarize.py); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"].get(kernel_name, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
+    # tile shapes measured once on an MI355X and committed: the same kernels run in every bench / profile pass
+    os.environ.setdefault("LFVDM_TUNE_CACHE", os.path.join(ROOT, "profiles", "tune_cache_mi355x.json"))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=900)
@@ -309,7 +321,7 @@ def main():
             dom_name, dom = max(convs.items(), key=lambda kv: kv[1]["ms"])
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel": dom_name,
+                               "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom_name), "kernel": dom_name,
                                "launches_per_step": dom["launches"],
                                "avg_launch_us": round(1000.0 * dom["ms"] / dom["launches"], 2),
                                "note": "fp32 MFMA; achieved = algorithmic conv/GEMM FLOPs of these launches / their HIP-event time"}

@@ -108,13 +108,14 @@ __global__ __launch_bounds__(256) void rpe_nets_kernel(const lfvdm_rpe_job* __re
 // on both K (A operand) and Q (B operand).
 // FP = head dim padded to a multiple of 16 (compile time); F = real head dim (multiple of 4): the
 // pad columns are zero in LDS / in the Q fragments and are never stored.
-template <int FP>
+template <int FP, int KB>
 __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restrict__ qkv, float* __restrict__ o, int P,
                                                            int C, int heads, int F) {
     constexpr int FG = FP / 16;   // 16-wide f groups
+    constexpr int KT = KB / 16;   // 16-key tiles per staged key block (KB = 32 keeps FP = 128 under 64 KB of LDS)
     constexpr int KLD = FP + 8, VLD = FP + 4;
-    __shared__ __attribute__((aligned(16))) float Ks[64 * KLD];
-    __shared__ __attribute__((aligned(16))) float Vs[64 * VLD];
+    __shared__ __attribute__((aligned(16))) float Ks[KB * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[KB * VLD];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = blockIdx.z, h = blockIdx.y;
@@ -140,9 +141,9 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
     for (int g = 0; g < FG; ++g) oacc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int kb = 0; kb < P; kb += 64) {
+    for (int kb = 0; kb < P; kb += KB) {
         __syncthreads();  // previous block fully consumed
-        for (int e = threadIdx.x; e < 64 * (FP / 4); e += 256) {
+        for (int e = threadIdx.x; e < KB * (FP / 4); e += 256) {
             const int key = e / (FP / 4), fq = e - key * (FP / 4);
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
             if (kb + key < P && fq * 4 < F) {
@@ -156,9 +157,9 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
         __syncthreads();
 
         // S^T tiles: rows = keys 16j + 4kk + r, column = query lq
-        f32x4 s[4];
+        f32x4 s[KT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < KT; ++j) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < FG; ++g) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
         }
         float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < KT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (kb + 16 * j + 4 * kk + r >= P) s[j][r] = -INFINITY;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
         const float alpha = __expf(m_run - m_new);  // m_run = -inf on the first block -> 0
         float psum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < KT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = __expf(s[j][r] - m_new);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
         for (int g = 0; g < FG; ++g) oacc[g] *= alpha;
         // O^T[f][q] += V^T[f][key] * P^T[key][q]; MFMA (j, r): k index kk <-> key 16j + 4kk + r
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < KT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* vrow = Vs + (16 * j + 4 * kk + r) * VLD + lq;
@@ -251,123 +252,252 @@ __global__ __launch_bounds__(256) void attn_spatial_probs_kernel(const float* __
 // ======================================================================================
 // Temporal attention with RPE
 // ======================================================================================
-// One wave per (b, pixel, head).  Lane (t = lane&31, half = lane>>5) owns query frame t and the key
-// frames s = half, half+2, ...  q/k/v of the (pixel, head) are staged wave-privately in LDS.
+// Workgroup = one (b, head) and a strip of 4*PPW pixels; wave = PPW pixels x T query frames, lane = j*T + t.
+// A lane owns ALL T logits of its (pixel, query frame) in registers, so the softmax needs no cross-lane
+// step.  The head dim is walked in chunks of FC channels: per chunk the R_k / R_q slices of this (b, head)
+// - [T][T][FC], shared by every pixel - are staged ONCE per workgroup in LDS (R_q transposed to [t][s]), the
+// k (then v) rows of the wave's pixels wave-privately; q stays in registers.  Rows are padded by 4 floats:
+// lanes of consecutive t read b128 words 4 banks apart (conflict-free), lanes of one pixel share k/v words
+// (LDS broadcast).  TMAX bounds the unrolled key loop (T <= TMAX).
 constexpr int TA_MAXT = 32;
 
-template <int F>
-__global__ __launch_bounds__(256) void attn_temporal_kernel(const float* __restrict__ qkv, const float* __restrict__ Rq,
-                                                            const float* __restrict__ Rk, const float* __restrict__ Rv,
-                                                            const float* __restrict__ mask, float* __restrict__ o,
-                                                            float* __restrict__ attn_out, int B, int T, int P, int C,
-                                                            int heads) {
-    constexpr int LD = F + 4;
-    __shared__ __attribute__((aligned(16))) float sm[4][3 * TA_MAXT * LD];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const long wid = (long)blockIdx.x * 4 + wave;  // ((b*P + p)*heads + h)
-    if (wid >= (long)B * P * heads) return;
-    const int h = (int)(wid % heads);
-    const long bp = wid / heads;
-    const int p = (int)(bp % P), b = (int)(bp / P);
-    float* qs = sm[wave];
-    float* ks = qs + TA_MAXT * LD;
-    float* vs = ks + TA_MAXT * LD;
+// The kernel is a short pipeline of phases: NC logit chunks, then NC PV chunks.  The global loads of phase
+// i+1 are issued into registers BEFORE phase i computes (the loop over chunks is latency-bound otherwise:
+// every staging pass costs a full L2 round trip), and committed to LDS after it.
+template <int TMAX, int FC>
+struct TAStage {
+    static constexpr int NQ = FC / 4;
+    static constexpr int RB = (TMAX * TMAX * NQ + 255) / 256;   // R float4 per thread per slice
+    f32x4 ra[RB], rb[RB], kv[NQ], q[NQ];
+};
+
+template <int TMAX, int FC>
+__global__ __launch_bounds__(256)
+void attn_temporal_kernel(const float* __restrict__ qkv, const float* __restrict__ Rq, const float* __restrict__ Rk,
+                          const float* __restrict__ Rv, const float* __restrict__ mask, float* __restrict__ o,
+                          float* __restrict__ attn_out, int T, int P, int C, int heads, int PPW) {
+    using ST = TAStage<TMAX, FC>;
+    constexpr int NQ = ST::NQ, RB = ST::RB;
+    extern __shared__ __attribute__((aligned(16))) float ta_smem[];
+    const int RST = T * FC + 4;                 // row stride of the R slices ([t] rows) and of a pixel's k/v rows
+    float* Rk_s = ta_smem;                      // [T][RST]   (PV phases: R_v)
+    float* Rq_s = Rk_s + T * RST;               // [T][RST]   R_q transposed: row t holds R_q[s][t] for all s
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* kv_s = Rq_s + T * RST + wave * PPW * RST;   // [PPW][RST] wave-private
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int F = C / heads;
+    const int NC = F / FC;
+    const float invT = 1.0f / (float)T;
+    const int j = (int)(((float)lane + 0.5f) * invT), t = lane - j * T;
+    const int p0 = (blockIdx.x * 4 + wave) * PPW;      // first pixel of this wave
+    const int p = p0 + j;
+    const bool active = j < PPW && p < P;
     const float scale = rsqrtf((float)F);
     const size_t ld = (size_t)3 * C;
+    const float* qrow = qkv + ((size_t)(b * T + t) * P + p) * ld + h * F;   // dereferenced only if active
+    const float* Rbase[3] = {Rk + (size_t)b * T * T * C + h * F, Rq + (size_t)b * T * T * C + h * F,
+                             Rv + (size_t)b * T * T * C + h * F};
 
-    // stage q*scale, k, v rows of the T frames
-    for (int e = lane; e < T * (F / 4); e += 64) {
-        const int t = e / (F / 4), fq = e - t * (F / 4);
-        const float* row = qkv + ((size_t)(b * T + t) * P + p) * ld + h * F + fq * 4;
-        st4(qs + t * LD + fq * 4, ld4(row) * scale);
-        st4(ks + t * LD + fq * 4, ld4(row + C));
-        st4(vs + t * LD + fq * 4, ld4(row + 2 * C));
+    // per-thread staging slots: global offsets (without the chunk offset) and LDS offsets, computed once.
+    // Slots past the end load from offset 0 (always valid) and are simply not committed: issue() is
+    // branch-free, all loads of a phase go out back to back.
+    int r_g[RB], r_la[RB], r_lb[RB];
+    unsigned r_ok = 0, k_ok = 0, k_keep = 0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int e = tid + 256 * i;
+        const int u = e % NQ, ts = e / NQ;
+        const int a = (int)(((float)ts + 0.5f) * invT), c = ts - a * T;
+        const bool ok = e < T * T * NQ;
+        r_ok |= ok ? (1u << i) : 0u;
+        r_g[i] = ok ? ts * C + 4 * u : 0;
+        r_la[i] = a * RST + c * FC + 4 * u;
+        r_lb[i] = c * RST + a * FC + 4 * u;
     }
-    wave_lds_fence();
+    int k_g[NQ], k_l[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int e = lane + 64 * i;
+        const int u = e % NQ, js = e / NQ;
+        const int jj = (int)(((float)js + 0.5f) * invT), ss = js - jj * T;
+        const bool ok = e < PPW * T * NQ, inside = ok && p0 + jj < P;
+        k_ok |= ok ? (1u << i) : 0u;
+        k_keep |= inside ? (1u << i) : 0u;       // pixels past the end are staged as zeros
+        k_g[i] = inside ? (int)(((size_t)(b * T + ss) * P + p0 + jj) * ld) + h * F + 4 * u : 0;
+        k_l[i] = jj * RST + ss * FC + 4 * u;
+    }
+    const float* qsafe = active ? qrow : qkv;
 
-    const int t = lane & 31, half = lane >> 5;
-    const bool tv = t < T;
-    const int tt = tv ? t : 0;
-    const float mt = mask ? mask[b * T + tt] : 1.f;
-    float logit[TA_MAXT / 2];
-    float mx = -INFINITY;
+    ST st;
+    auto issue = [&](int ph) {   // ph is wave-uniform
+        const bool lg = ph < NC;
+        const int f0 = (lg ? ph : ph - NC) * FC;
+        const float* A = (lg ? Rbase[0] : Rbase[2]) + f0;
+        const float* Bq = Rbase[1] + (lg ? f0 : 0);
+        const float* KV = qkv + (lg ? C : 2 * C) + f0;
 #pragma unroll
-    for (int i = 0; i < TA_MAXT / 2; ++i) {
-        const int s = 2 * i + half;
-        float acc = -INFINITY;
-        if (tv && s < T) {
-            const float* rk = Rk + (((size_t)(b * T + tt) * T + s) * C) + h * F;
-            const float* rq = Rq + (((size_t)(b * T + s) * T + tt) * C) + h * F;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-            for (int f = 0; f < F; f += 4) {
-                const f32x4 q4 = ld4(qs + tt * LD + f), k4 = ld4(ks + s * LD + f);
-                const f32x4 rk4 = ld4(rk + f), rq4 = ld4(rq + f);
-                a0 += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
-                a1 += q4.x * rk4.x + q4.y * rk4.y + q4.z * rk4.z + q4.w * rk4.w;
-                a2 += (k4.x * scale) * rq4.x + (k4.y * scale) * rq4.y + (k4.z * scale) * rq4.z + (k4.w * scale) * rq4.w;
-            }
-            acc = a0 + a1 + a2;
-            if (mask) {
-                const float ms = mask[b * T + s];
-                const float allowed = mt * ms + (1.f - mt) * (1.f - ms);
-                const float pen = 1.f - allowed;
-                acc -= (pen == 1.f) ? INFINITY : pen;
-            }
+        for (int i = 0; i < RB; ++i) {
+            st.ra[i] = ld4(A + r_g[i]);
+            st.rb[i] = ld4(Bq + r_g[i]);
         }
-        logit[i] = acc;
-        mx = fmaxf(mx, acc);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < TA_MAXT / 2; ++i) {
-        const float e = (logit[i] == -INFINITY) ? 0.f : __expf(logit[i] - mx);
-        logit[i] = e;
-        sum += e;
-    }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-
-    if (attn_out && tv) {
-        float* ar = attn_out + ((size_t)wid * T + tt) * T;
+        for (int i = 0; i < NQ; ++i) st.kv[i] = ld4(KV + k_g[i]);
 #pragma unroll
-        for (int i = 0; i < TA_MAXT / 2; ++i) {
-            const int s = 2 * i + half;
-            if (s < T) ar[s] = logit[i] * inv;
-        }
-    }
-
-    // o[t][f] = sum_s p[t][s] * (v[s][f] + Rv[t][s][f])
-    constexpr int FO = F < 16 ? F : 16;   // output channels per pass
-    constexpr int NU = FO / 4;
+        for (int u = 0; u < NQ; ++u) st.q[u] = ld4(qsafe + (lg ? f0 : 0) + 4 * u);
+    };
+    auto commit = [&](int ph) {
+        const bool lg = ph < NC;
 #pragma unroll
-    for (int f0 = 0; f0 < F; f0 += FO) {
-        f32x4 acc[NU];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < TA_MAXT / 2; ++i) {
-            const int s = 2 * i + half;
-            if (tv && s < T) {
-                const float pr = logit[i] * inv;
-                const float* rv = Rv + (((size_t)(b * T + tt) * T + s) * C) + h * F + f0;
-#pragma unroll
-                for (int u = 0; u < NU; ++u) acc[u] += pr * (ld4(vs + s * LD + f0 + 4 * u) + ld4(rv + 4 * u));
+        for (int i = 0; i < RB; ++i) {
+            if (r_ok & (1u << i)) {
+                st4(Rk_s + r_la[i], st.ra[i]);
+                if (lg) st4(Rq_s + r_lb[i], st.rb[i]);
             }
         }
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            acc[u].x += __shfl_xor(acc[u].x, 32, 64); acc[u].y += __shfl_xor(acc[u].y, 32, 64);
-            acc[u].z += __shfl_xor(acc[u].z, 32, 64); acc[u].w += __shfl_xor(acc[u].w, 32, 64);
-        }
-        if (tv && half == 0) {
-            float* orow = o + ((size_t)(b * T + tt) * P + p) * C + h * F + f0;
+        for (int i = 0; i < NQ; ++i)
+            if (k_ok & (1u << i)) st4(kv_s + k_l[i], (k_keep & (1u << i)) ? st.kv[i] : (f32x4){0.f, 0.f, 0.f, 0.f});
+    };
+
+    float logit[TMAX];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) st4(orow + 4 * u, acc[u]);
+    for (int s = 0; s < TMAX; ++s) logit[s] = 0.f;
+
+    issue(0);
+    for (int ph = 0; ph < NC; ++ph) {
+        __syncthreads();           // previous phase fully consumed
+        commit(ph);
+        f32x4 q4[NQ];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) q4[u] = st.q[u] * scale;
+        __syncthreads();
+        issue(ph + 1);             // next logit chunk, or the first PV chunk
+#ifdef TA_DEBUG
+        if (active && !(TA_DEBUG & 1)) {
+#else
+        if (active) {
+#endif
+            const float* kr = kv_s + j * RST;
+            const float* rkr = Rk_s + t * RST;
+            const float* rqr = Rq_s + t * RST;
+#pragma unroll
+            for (int s = 0; s < TMAX; ++s) {
+                if (s < T) {
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) {
+                        const f32x4 k4 = ld4(kr + s * FC + 4 * u);
+                        const f32x4 rk4 = ld4(rkr + s * FC + 4 * u);
+                        const f32x4 rq4 = ld4(rqr + s * FC + 4 * u);
+                        a0 += q4[u].x * (k4.x + rk4.x) + q4[u].y * (k4.y + rk4.y) + q4[u].z * (k4.z + rk4.z) + q4[u].w * (k4.w + rk4.w);
+                        a1 += k4.x * rq4.x + k4.y * rq4.y + k4.z * rq4.z + k4.w * rq4.w;
+                    }
+                    logit[s] += a0 + a1 * scale;
+                }
+            }
         }
     }
+
+    // two-clique mask + softmax, all in this lane's registers
+    if (active) {
+        const float mt = mask ? mask[b * T + t] : 1.f;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < TMAX; ++s) {
+            float v = -INFINITY;
+            if (s < T) {
+                v = logit[s];
+                if (mask) {
+                    const float ms = mask[b * T + s];
+                    const float pen = 1.f - (mt * ms + (1.f - mt) * (1.f - ms));
+                    v -= (pen == 1.f) ? INFINITY : pen;
+                }
+            }
+            logit[s] = v;
+            mx = fmaxf(mx, v);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < TMAX; ++s) {
+            const float e = (logit[s] == -INFINITY) ? 0.f : __expf(logit[s] - mx);
+            logit[s] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int s = 0; s < TMAX; ++s) logit[s] *= inv;
+        if (attn_out) {
+            float* ar = attn_out + ((((size_t)b * P + p) * heads + h) * T + t) * T;
+#pragma unroll
+            for (int s = 0; s < TMAX; ++s)
+                if (s < T) ar[s] = logit[s];
+        }
+    }
+
+    // o[t][f] = sum_s p[t][s] * (v[s][f] + R_v[t][s][f]), chunk by chunk
+    for (int ph = NC; ph < 2 * NC; ++ph) {
+        __syncthreads();
+        commit(ph);
+        __syncthreads();
+        if (ph + 1 < 2 * NC) issue(ph + 1);
+#ifdef TA_DEBUG
+        if (active && !(TA_DEBUG & 2)) {
+#else
+        if (active) {
+#endif
+            const float* vr = kv_s + j * RST;
+            const float* rvr = Rk_s + t * RST;
+            f32x4 acc[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < TMAX; ++s) {
+                if (s < T) {
+                    // opaque copy: stops the compiler from hoisting 24 broadcast register pairs (for packed
+                    // FMAs) out of the chunk loop and spilling them to scratch
+                    float pr = logit[s];
+                    asm volatile("" : "+v"(pr));
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) acc[u] += pr * (ld4(vr + s * FC + 4 * u) + ld4(rvr + s * FC + 4 * u));
+                }
+            }
+            float* orow = o + ((size_t)(b * T + t) * P + p) * C + h * F + (ph - NC) * FC;
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) st4(orow + 4 * u, acc[u]);
+        }
+    }
+}
+
+template <int TMAX, int FC>
+int launch_temporal(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
+                    float* attn_out, int B, int T, int P, int C, int heads, hipStream_t s) {
+    const int PPW = 64 / T;                                  // pixels per wave
+    const int RST = T * FC + 4;
+    const size_t lds = (size_t)(2 * T + 4 * PPW) * RST * sizeof(float);
+    if (lds > 160 * 1024) return LFVDM_E_UNSUPPORTED;
+    static size_t attr_bytes = 0;   // raise the dynamic-LDS limit of this instance when a larger T needs it
+    if (lds > attr_bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_kernel<TMAX, FC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return LFVDM_E_LAUNCH;
+        attr_bytes = lds;
+    }
+    const dim3 grid((unsigned)((P + 4 * PPW - 1) / (4 * PPW)), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL((attn_temporal_kernel<TMAX, FC>), grid, dim3(256), lds, s, qkv, Rq, Rk, Rv, mask, o, attn_out, T, P, C,
+                       heads, PPW);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+template <int FC>
+int launch_temporal_t(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
+                      float* attn_out, int B, int T, int P, int C, int heads, hipStream_t s) {
+    if (T <= 8) return launch_temporal<8, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
+    if (T <= 16) return launch_temporal<16, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
+    if (T <= 24) return launch_temporal<24, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
+    return launch_temporal<32, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
 }
 
 }  // namespace
@@ -395,14 +525,17 @@ extern "C" int lfvdm_attn_spatial(const float* qkv, float* o, float* attn_out, i
     const int F = C / heads;
     const dim3 grid((P + 63) / 64, heads, N);
     hipStream_t s = (hipStream_t)stream;
-    if (F % 4 || F > 96) return LFVDM_E_UNSUPPORTED;
+    if (F % 4 || F > 128) return LFVDM_E_UNSUPPORTED;
     const int FP = (F + 15) / 16 * 16;
     switch (FP) {
-        case 16: hipLaunchKernelGGL(attn_spatial_kernel<16>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 32: hipLaunchKernelGGL(attn_spatial_kernel<32>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 48: hipLaunchKernelGGL(attn_spatial_kernel<48>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 64: hipLaunchKernelGGL(attn_spatial_kernel<64>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 96: hipLaunchKernelGGL(attn_spatial_kernel<96>, grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 16: hipLaunchKernelGGL((attn_spatial_kernel<16, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 32: hipLaunchKernelGGL((attn_spatial_kernel<32, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 48: hipLaunchKernelGGL((attn_spatial_kernel<48, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 64: hipLaunchKernelGGL((attn_spatial_kernel<64, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 96: hipLaunchKernelGGL((attn_spatial_kernel<96, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 80: hipLaunchKernelGGL((attn_spatial_kernel<80, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 112: hipLaunchKernelGGL((attn_spatial_kernel<112, 32>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 128: hipLaunchKernelGGL((attn_spatial_kernel<128, 32>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
         default: return LFVDM_E_UNSUPPORTED;
     }
     LFVDM_CHECK_LAUNCH();
@@ -418,16 +551,8 @@ extern "C" int lfvdm_attn_temporal(const float* qkv, const float* Rq, const floa
     if (B <= 0 || T <= 0 || T > TA_MAXT || P <= 0 || heads <= 0 || C % heads) return LFVDM_E_SHAPE;
     if (!Rq || !Rk || !Rv) return LFVDM_E_SHAPE;
     const int F = C / heads;
-    const long waves = (long)B * P * heads;
-    const dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
-    switch (F) {
-        case 8: hipLaunchKernelGGL(attn_temporal_kernel<8>, grid, dim3(256), 0, s, qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads); break;
-        case 16: hipLaunchKernelGGL(attn_temporal_kernel<16>, grid, dim3(256), 0, s, qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads); break;
-        case 32: hipLaunchKernelGGL(attn_temporal_kernel<32>, grid, dim3(256), 0, s, qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads); break;
-        case 64: hipLaunchKernelGGL(attn_temporal_kernel<64>, grid, dim3(256), 0, s, qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads); break;
-        default: return LFVDM_E_UNSUPPORTED;
-    }
-    LFVDM_CHECK_LAUNCH();
-    return LFVDM_OK;
+    if (F % 16 == 0 && T <= 24) return launch_temporal_t<16>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
+    if (F % 8 == 0) return launch_temporal_t<8>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
+    return LFVDM_E_UNSUPPORTED;
 }

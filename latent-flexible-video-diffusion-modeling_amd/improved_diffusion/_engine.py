@@ -14,6 +14,8 @@ Design (MI355X-first, not a translation of the reference's ATen op stream, unet.
     denoising step is captured into one hipGraph by the sampler (gaussian_diffusion.py).
 """
 import ctypes as C
+import json
+import os
 
 import torch as th
 import torch.nn as nn
@@ -24,6 +26,42 @@ from .nn import timestep_freqs
 
 def _p(t):
     return t.data_ptr()
+
+
+def _tune_cache(engine):
+    """Launch-shape -> tuned code, per engine; optionally persisted in the JSON file named by LFVDM_TUNE_CACHE
+    (entries are only valid for the library ABI version they were measured with)."""
+    cache = engine.__dict__.get("tune_cache")
+    if cache is None:
+        cache = engine.__dict__["tune_cache"] = {}
+        path = os.environ.get("LFVDM_TUNE_CACHE", "")
+        if path and os.path.exists(path):
+            try:
+                with open(path) as f:
+                    blob = json.load(f)
+                if blob.get("abi") == int(nat.lib().lfvdm_abi_version()):
+                    cache.update({tuple(json.loads(k)): int(v) for k, v in blob["entries"].items()})
+            except (OSError, ValueError, KeyError):
+                pass
+        engine.__dict__["tune_cache_saved"] = len(cache)
+    return cache
+
+
+def _tune_cache_save(engine):
+    path = os.environ.get("LFVDM_TUNE_CACHE", "")
+    cache = engine.__dict__.get("tune_cache") or {}
+    if not path or len(cache) == engine.__dict__.get("tune_cache_saved", 0):
+        return
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump({"abi": int(nat.lib().lfvdm_abi_version()),
+                       "entries": {json.dumps([int(x) for x in k]): int(v) for k, v in sorted(cache.items())}}, f, indent=0)
+        os.replace(tmp, path)
+        engine.__dict__["tune_cache_saved"] = len(cache)
+    except OSError:
+        pass
 
 
 class Plan:
@@ -319,7 +357,7 @@ class Plan:
             a = args[0]._obj
             key = (a.N, a.Hs, a.Ws, a.up, a.stride, a.ksize, a.Ho, a.Wo, a.C0, a.C1, a.Cout, a.s2C0, a.s2C1,
                    bool(a.coefA), a.act, bool(a.res), bool(a.resA), a.out_mode)
-            cache = self.engine.__dict__.setdefault("tune_cache", {})
+            cache = _tune_cache(self.engine)
             if key in cache:             # same launch shape already timed (another plan / window length)
                 a.tune = cache[key]
                 tuned += 1
@@ -344,6 +382,7 @@ class Plan:
             cache[key] = best
             tuned += 1
         self.tuned = True
+        _tune_cache_save(self.engine)
         return tuned
 
     # ------------------------------------------------------------------ run

@@ -39,6 +39,10 @@ CONFIGS = {
     "cfgA": (dict(model_channels=32, channel_mult=(1, 2, 2, 2), attention_resolutions=(2, 4)), 1, 5, 32, 0),
     "cfgB": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 20, 16, 3),
     "cfgB_T14": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 14, 16, 0),
+    # BASELINE.json configs[4] (pixel space 128x128x3, num_channels=128, reference defaults: num_res_blocks=2,
+    # channel_mult (1,1,2,3,4), attention at 16x16 and 8x8 -> head dims 96 and 128) on 2 frames
+    "cfgE_T2": (dict(in_channels=3, model_channels=128, num_res_blocks=2, channel_mult=(1, 1, 2, 3, 4),
+                     attention_resolutions=(8, 16)), 1, 2, 128, 0),
 }
 
 
@@ -67,8 +71,10 @@ def maxdiff(a, b):
     return float((a - b).abs().max())
 
 
-def gen_forward():
+def gen_forward(only=None):
     for name, (kw, B, T, H, n_pad) in CONFIGS.items():
+        if only and name not in only:
+            continue
         cfg = uo.make_cfg(**kw)
         model, sd = build_reference_model(cfg)
         inp = recipe.make_inputs(name, B, T, cfg["in_channels"], H, H, n_pad=n_pad)
@@ -327,6 +333,9 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "schemes":
         gen_schemes()
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "forward":
+        gen_forward(only=sys.argv[2:])
         sys.exit(0)
     gen_ops()
     gen_forward()

@@ -221,7 +221,8 @@ def test_rpe_nets(nat, Cc, heads):
         close(R, ref, 2e-5)
 
 
-@pytest.mark.parametrize("N,P,Cc,heads", [(3, 256, 64, 4), (2, 64, 128, 4), (5, 4, 128, 4), (2, 100, 64, 2), (1, 256, 32, 2), (2, 64, 32, 4), (1, 70, 96, 4)])
+@pytest.mark.parametrize("N,P,Cc,heads", [(3, 256, 64, 4), (2, 64, 128, 4), (5, 4, 128, 4), (2, 100, 64, 2), (1, 256, 32, 2), (2, 64, 32, 4), (1, 70, 96, 4),
+                                            (2, 256, 384, 4), (2, 64, 512, 4), (1, 50, 320, 4), (1, 33, 448, 4)])
 def test_attn_spatial(nat, N, P, Cc, heads):
     qkv = rnd("as/qkv", N, P, 3 * Cc)
     Fh = Cc // heads
@@ -235,7 +236,9 @@ def test_attn_spatial(nat, N, P, Cc, heads):
     close(a, attn, 1e-5)
 
 
-@pytest.mark.parametrize("B,T,P,Cc,heads", [(2, 20, 16, 64, 4), (2, 5, 4, 128, 4), (1, 14, 9, 64, 4), (2, 32, 3, 32, 2), (2, 4, 16, 32, 4)])
+@pytest.mark.parametrize("B,T,P,Cc,heads", [(2, 20, 16, 64, 4), (2, 5, 4, 128, 4), (1, 14, 9, 64, 4), (2, 32, 3, 32, 2), (2, 4, 16, 32, 4),
+                                                   (1, 20, 7, 384, 4), (1, 3, 5, 512, 4), (2, 24, 2, 64, 4), (1, 27, 3, 96, 4),
+                                                   (1, 8, 37, 64, 2), (2, 1, 6, 32, 4)])
 def test_temporal_attention_block(nat, B, T, P, Cc, heads):
     """gn_temporal + qkv GEMM + RPE nets + temporal core + proj GEMM vs oracle rpe_attention (rpe.py:133-174)."""
     ted = 128

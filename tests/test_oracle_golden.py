@@ -17,6 +17,9 @@ CONFIGS = {
     "cfgA": (dict(model_channels=32, channel_mult=(1, 2, 2, 2), attention_resolutions=(2, 4)), 1, 5, 32, 0),
     "cfgB": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 20, 16, 3),
     "cfgB_T14": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 14, 16, 0),
+    # BASELINE.json configs[4]: pixel space 128x128x3, num_channels=128, num_res_blocks=2 (head dims 96 / 128), 2 frames
+    "cfgE_T2": (dict(in_channels=3, model_channels=128, num_res_blocks=2, channel_mult=(1, 1, 2, 3, 4),
+                     attention_resolutions=(8, 16)), 1, 2, 128, 0),
 }
 
 
