@@ -214,11 +214,26 @@ int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, co
  * attn_out (optional, may be NULL): softmax probabilities for logging
  *   spatial [N][heads][P][P], temporal [B*P][heads][T][T].
  * ------------------------------------------------------------------------------------- */
-int lfvdm_attn_spatial(const float* qkv, float* o, float* attn_out, int N, int P, int C, int heads, void* stream);
+/* lse_out (optional, may be NULL): log-sum-exp of every query row [N][heads][P], kept for the backward. */
+int lfvdm_attn_spatial(const float* qkv, float* o, float* attn_out, float* lse_out, int N, int P, int C, int heads,
+                       void* stream);
+
+/* Backward of the spatial core (autograd of rpe.py:143-169 with attn_mask = None, no RPE): from qkv, the
+ * forward output o, its gradient d_o and the saved lse, writes dqkv [M][3C] (same layout as qkv).
+ * delta_ws: workspace of N*heads*P floats (rowdot(o, d_o)).  S and P are recomputed tile by tile. */
+int lfvdm_attn_spatial_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* delta_ws,
+                           float* dqkv, int N, int P, int C, int heads, void* stream);
 
 int lfvdm_attn_temporal(const float* qkv, const float* Rq, const float* Rk, const float* Rv,
                         const float* mask /* [B][T] or NULL */, float* o, float* attn_out,
                         int B, int T, int P, int C, int heads, void* stream);
+
+/* Backward of the temporal core: from qkv, d_o (gradient of the core output), the three R tensors and the mask
+ * writes dqkv [M][3C] and dRq / dRk / dRv [B][T][T][C] (every element written, no atomics).
+ * ws_p, ws_ds: workspaces of B*P*heads*T*T floats each (rows of P and dS, recomputed from the inputs). */
+int lfvdm_attn_temporal_bwd(const float* qkv, const float* d_o, const float* Rq, const float* Rk, const float* Rv,
+                            const float* mask, float* ws_p, float* ws_ds, float* dqkv, float* dRq, float* dRk,
+                            float* dRv, int B, int T, int P, int C, int heads, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Diffusion step math (gaussian_diffusion.py).  Tables are device fp32 arrays gathered by

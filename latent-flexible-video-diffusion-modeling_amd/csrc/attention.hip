@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void rpe_nets_kernel(const lfvdm_rpe_job* __re
 // FP = head dim padded to a multiple of 16 (compile time); F = real head dim (multiple of 4): the
 // pad columns are zero in LDS / in the Q fragments and are never stored.
 template <int FP, int KB>
-__global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restrict__ qkv, float* __restrict__ o, int P,
-                                                           int C, int heads, int F) {
+__global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                           float* __restrict__ lse, int P, int C, int heads, int F) {
     constexpr int FG = FP / 16;   // 16-wide f groups
     constexpr int KT = KB / 16;   // 16-key tiles per staged key block (KB = 32 keeps FP = 128 under 64 KB of LDS)
     constexpr int KLD = FP + 8, VLD = FP + 4;
@@ -209,11 +209,163 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_run;
     const int q = q0 + lq;
+    if (lse && q < P && kk == 0) lse[((size_t)n * heads + h) * P + q] = m_run + __logf(l_run);   // saved for the backward
     if (q < P) {
 #pragma unroll
         for (int g = 0; g < FG; ++g)
             if (16 * g + 4 * kk < F) st4(o + ((size_t)n * P + q) * C + h * F + 16 * g + 4 * kk, oacc[g] * inv);
     }
+}
+
+// --------------------------------------------------------------------------------------
+// Spatial attention backward (flash style, recomputes S from q, k and the saved log-sum-exp).
+// One kernel body, two roles:
+//   DKV = false: workgroup = 64 QUERIES held as MFMA B operands (q*scale, dO), key blocks streamed through LDS
+//                -> dq = scale * sum_keys dS * K
+//   DKV = true : workgroup = 64 KEYS held as B operands (k, v), query blocks (q*scale, dO, lse, delta) streamed
+//                -> dk = sum_queries dS^T * (q*scale),  dv = sum_queries P^T * dO
+// with P = exp(S - lse[query]), dP = dO . V^T, dS = P * (dP - delta[query]), delta = rowdot(O, dO).
+// Tiles are T[y][x]: y = streamed token (row 16j + 4kk + r), x = stationary token (column lq), so the same
+// LDS rows serve the row-wise b128 reads of the two tile products and the transposed scalar reads of the
+// accumulations (row stride FP + 4: both patterns at most 2-way conflicted).
+template <int FP, int KB, bool DKV>
+__global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               float* __restrict__ dqkv, int P, int C, int heads, int F) {
+    constexpr int FG = FP / 16, KT = KB / 16, LD = FP + 4;
+    __shared__ __attribute__((aligned(16))) float A1s[KB * LD];
+    __shared__ __attribute__((aligned(16))) float A2s[KB * LD];
+    __shared__ float Ls[KB], Ds[KB];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = blockIdx.z, h = blockIdx.y;
+    const int x = blockIdx.x * 64 + wave * 16 + (lane & 15);
+    const int lq = lane & 15, kk = lane >> 4;
+    const float scale = rsqrtf((float)F);
+    const size_t ld = (size_t)3 * C;
+    const float* base = qkv + (size_t)n * P * ld + h * F;
+    const float* dobase = dO + (size_t)n * P * C + h * F;
+    const size_t sbase = ((size_t)n * heads + h) * P;
+    const bool xin = x < P;
+
+    f32x4 B1[FG], B2[FG], acc1[FG], acc2[FG];
+#pragma unroll
+    for (int g = 0; g < FG; ++g) {
+        f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = {0.f, 0.f, 0.f, 0.f};
+        if (xin && 16 * g + 4 * kk < F) {
+            if (DKV) {
+                v1 = ld4(base + (size_t)x * ld + C + 16 * g + 4 * kk);
+                v2 = ld4(base + (size_t)x * ld + 2 * C + 16 * g + 4 * kk);
+            } else {
+                v1 = ld4(base + (size_t)x * ld + 16 * g + 4 * kk) * scale;
+                v2 = ld4(dobase + (size_t)x * C + 16 * g + 4 * kk);
+            }
+        }
+        B1[g] = v1;
+        B2[g] = v2;
+        acc1[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float Lx = 0.f, Dx = 0.f;
+    if (!DKV && xin) {
+        Lx = lse[sbase + x];
+        Dx = delta[sbase + x];
+    }
+
+    for (int yb = 0; yb < P; yb += KB) {
+        __syncthreads();   // previous block fully consumed
+        for (int e = threadIdx.x; e < KB * (FP / 4); e += 256) {
+            const int y = e / (FP / 4), fq = e - y * (FP / 4);
+            f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = {0.f, 0.f, 0.f, 0.f};
+            if (yb + y < P && fq * 4 < F) {
+                const float* row = base + (size_t)(yb + y) * ld + fq * 4;
+                if (DKV) {
+                    v1 = ld4(row) * scale;
+                    v2 = ld4(dobase + (size_t)(yb + y) * C + fq * 4);
+                } else {
+                    v1 = ld4(row + C);
+                    v2 = ld4(row + 2 * C);
+                }
+            }
+            st4(A1s + y * LD + fq * 4, v1);
+            st4(A2s + y * LD + fq * 4, v2);
+        }
+        if (DKV && threadIdx.x < KB) {
+            const bool in = yb + (int)threadIdx.x < P;
+            Ls[threadIdx.x] = in ? lse[sbase + yb + threadIdx.x] : 0.f;
+            Ds[threadIdx.x] = in ? delta[sbase + yb + threadIdx.x] : 0.f;
+        }
+        __syncthreads();
+
+        f32x4 pt[KT], dst[KT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < FG; ++g) {
+                const f32x4 a1 = ld4(A1s + (16 * j + lq) * LD + 16 * g + 4 * kk);
+                const f32x4 a2 = ld4(A2s + (16 * j + lq) * LD + 16 * g + 4 * kk);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], B1[g][e], t1, 0, 0, 0);
+                    t2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[e], B2[g][e], t2, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int yl = 16 * j + 4 * kk + r;
+                const float L = DKV ? Ls[yl] : Lx;
+                const float D = DKV ? Ds[yl] : Dx;
+                const float pv = (yb + yl < P) ? __expf(t1[r] - L) : 0.f;
+                pt[j][r] = pv;
+                dst[j][r] = pv * (t2[r] - D);
+            }
+        }
+        // acc1^T[f][x] += A1^T[f][y] * dS[y][x];  (DKV) acc2^T[f][x] += A2^T[f][y] * P[y][x]
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (16 * j + 4 * kk + r) * LD + lq;
+#pragma unroll
+                for (int g = 0; g < FG; ++g) {
+                    acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1s[row + 16 * g], dst[j][r], acc1[g], 0, 0, 0);
+                    if (DKV) acc2[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2s[row + 16 * g], pt[j][r], acc2[g], 0, 0, 0);
+                }
+            }
+    }
+    if (xin) {
+        float* out = dqkv + ((size_t)n * P + x) * ld + h * F;
+#pragma unroll
+        for (int g = 0; g < FG; ++g)
+            if (16 * g + 4 * kk < F) {
+                if (DKV) {
+                    st4(out + C + 16 * g + 4 * kk, acc1[g]);
+                    st4(out + 2 * C + 16 * g + 4 * kk, acc2[g]);
+                } else {
+                    st4(out + 16 * g + 4 * kk, acc1[g] * scale);
+                }
+            }
+    }
+}
+
+// delta[n][h][p] = sum_f O[n,p,h,f] * dO[n,p,h,f]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ dO,
+                                                         float* __restrict__ delta, long total, int P, int C, int heads, int F) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // ((n*P + p)*heads + h)
+    if (i >= total) return;
+    const int h = (int)(i % heads);
+    const long tok = i / heads;
+    const int p = (int)(tok % P);
+    const long n = tok / P;
+    const float* a = o + tok * C + h * F;
+    const float* b = dO + tok * C + h * F;
+    float acc = 0.f;
+    for (int f = 0; f < F; f += 4) {
+        const f32x4 u = ld4(a + f), v = ld4(b + f);
+        acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    }
+    delta[((size_t)n * heads + h) * P + p] = acc;
 }
 
 // probabilities for logging (return_attn_weights): plain two-pass softmax, one wave per query row
@@ -520,29 +672,68 @@ extern "C" int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int tota
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_attn_spatial(const float* qkv, float* o, float* attn_out, int N, int P, int C, int heads, void* stream) {
+extern "C" int lfvdm_attn_spatial(const float* qkv, float* o, float* attn_out, float* lse_out, int N, int P, int C, int heads,
+                                  void* stream) {
     if (N <= 0 || P <= 0 || heads <= 0 || C % heads) return LFVDM_E_SHAPE;
     const int F = C / heads;
     const dim3 grid((P + 63) / 64, heads, N);
     hipStream_t s = (hipStream_t)stream;
     if (F % 4 || F > 128) return LFVDM_E_UNSUPPORTED;
     const int FP = (F + 15) / 16 * 16;
+#define LFVDM_SPATIAL_FWD(FPV, KBV) \
+    hipLaunchKernelGGL((attn_spatial_kernel<FPV, KBV>), grid, dim3(256), 0, s, qkv, o, lse_out, P, C, heads, F)
     switch (FP) {
-        case 16: hipLaunchKernelGGL((attn_spatial_kernel<16, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 32: hipLaunchKernelGGL((attn_spatial_kernel<32, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 48: hipLaunchKernelGGL((attn_spatial_kernel<48, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 64: hipLaunchKernelGGL((attn_spatial_kernel<64, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 96: hipLaunchKernelGGL((attn_spatial_kernel<96, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 80: hipLaunchKernelGGL((attn_spatial_kernel<80, 64>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 112: hipLaunchKernelGGL((attn_spatial_kernel<112, 32>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
-        case 128: hipLaunchKernelGGL((attn_spatial_kernel<128, 32>), grid, dim3(256), 0, s, qkv, o, P, C, heads, F); break;
+        case 16: LFVDM_SPATIAL_FWD(16, 64); break;
+        case 32: LFVDM_SPATIAL_FWD(32, 64); break;
+        case 48: LFVDM_SPATIAL_FWD(48, 64); break;
+        case 64: LFVDM_SPATIAL_FWD(64, 64); break;
+        case 80: LFVDM_SPATIAL_FWD(80, 64); break;
+        case 96: LFVDM_SPATIAL_FWD(96, 64); break;
+        case 112: LFVDM_SPATIAL_FWD(112, 32); break;
+        case 128: LFVDM_SPATIAL_FWD(128, 32); break;
         default: return LFVDM_E_UNSUPPORTED;
     }
+#undef LFVDM_SPATIAL_FWD
     LFVDM_CHECK_LAUNCH();
     if (attn_out) {
         hipLaunchKernelGGL(attn_spatial_probs_kernel, dim3((heads * P + 3) / 4, N), dim3(256), 0, s, qkv, attn_out, P, C, heads, F);
         LFVDM_CHECK_LAUNCH();
     }
+    return LFVDM_OK;
+}
+
+template <int FP, int KB>
+static void launch_spatial_bwd(const float* qkv, const float* dO, const float* lse, const float* delta, float* dqkv, int N, int P,
+                               int C, int heads, int F, hipStream_t s) {
+    const dim3 grid((P + 63) / 64, heads, N);
+    hipLaunchKernelGGL((attn_spatial_bwd_kernel<FP, KB, false>), grid, dim3(256), 0, s, qkv, dO, lse, delta, dqkv, P, C, heads, F);
+    hipLaunchKernelGGL((attn_spatial_bwd_kernel<FP, KB, true>), grid, dim3(256), 0, s, qkv, dO, lse, delta, dqkv, P, C, heads, F);
+}
+
+extern "C" int lfvdm_attn_spatial_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* delta_ws,
+                                      float* dqkv, int N, int P, int C, int heads, void* stream) {
+    if (N <= 0 || P <= 0 || heads <= 0 || C % heads) return LFVDM_E_SHAPE;
+    if (!qkv || !o || !d_o || !lse || !delta_ws || !dqkv) return LFVDM_E_SHAPE;
+    const int F = C / heads;
+    if (F % 4 || F > 128) return LFVDM_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)N * P * heads;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o, d_o, delta_ws, total, P, C,
+                       heads, F);
+    LFVDM_CHECK_LAUNCH();
+    const int FP = (F + 15) / 16 * 16;
+    switch (FP) {
+        case 16: launch_spatial_bwd<16, 64>(qkv, d_o, lse, delta_ws, dqkv, N, P, C, heads, F, s); break;
+        case 32: launch_spatial_bwd<32, 64>(qkv, d_o, lse, delta_ws, dqkv, N, P, C, heads, F, s); break;
+        case 48: launch_spatial_bwd<48, 64>(qkv, d_o, lse, delta_ws, dqkv, N, P, C, heads, F, s); break;
+        case 64: launch_spatial_bwd<64, 64>(qkv, d_o, lse, delta_ws, dqkv, N, P, C, heads, F, s); break;
+        case 80: launch_spatial_bwd<80, 32>(qkv, d_o, lse, delta_ws, dqkv, N, P, C, heads, F, s); break;
+        case 96: launch_spatial_bwd<96, 32>(qkv, d_o, lse, delta_ws, dqkv, N, P, C, heads, F, s); break;
+        case 112: launch_spatial_bwd<112, 32>(qkv, d_o, lse, delta_ws, dqkv, N, P, C, heads, F, s); break;
+        case 128: launch_spatial_bwd<128, 32>(qkv, d_o, lse, delta_ws, dqkv, N, P, C, heads, F, s); break;
+        default: return LFVDM_E_UNSUPPORTED;
+    }
+    LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
 

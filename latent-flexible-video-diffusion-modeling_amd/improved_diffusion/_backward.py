@@ -138,6 +138,7 @@ class LinearFn(th.autograd.Function):
             kw.update(res=res, ldr=O)
         nat.conv_igemm(**kw)
         ctx.save_for_backward(x, w)
+        ctx.params = (w, b) if (w.is_leaf and b is not None and b.is_leaf) else None
         ctx.has_res = res is not None
         return y
 
@@ -147,7 +148,12 @@ class LinearFn(th.autograd.Function):
         M, K = x.shape
         O = w.shape[0]
         dy = dy.contiguous()
-        dw, db = _wgrad_into((O, K), x, src0=x, C0=K, N=M, Hs=1, Ws=1, Ho=1, Wo=1, res=dy, ldr=O)
+        wkw = dict(src0=x, C0=K, N=M, Hs=1, Ws=1, Ho=1, Wo=1, res=dy, ldr=O)
+        if ctx.params is not None:
+            _wgrad_accumulate(ctx.params[0], ctx.params[1], **wkw)
+            dw = db = None
+        else:
+            dw, db = _wgrad_into((O, K), x, **wkw)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _new(M, K, like=x)
@@ -343,13 +349,11 @@ class TemporalAttnFn(th.autograd.Function):
         dwp = dbp = dwq = dbq = None
         do = _new(M, C, like=x)
         nat.conv_igemm(src0=dy, C0=C, ksize=1, W=_pack_t(wproj.view(C, C, 1, 1)), Cout=C, out=do, ldo=C, **one)
-        # attention core backward (interim: recompute on batched library GEMMs)
-        with th.enable_grad():
-            qkv_ = qkv.detach().requires_grad_(True)
-            Rs = [r.detach().requires_grad_(True) for r in (Rq, Rk, Rv)]
-            o_ = _temporal_core_torch(qkv_, Rs[0], Rs[1], Rs[2], mask, B, T, P, C, heads)
-            dqkv, dRq, dRk, dRv = th.autograd.grad(o_, [qkv_] + Rs, do)
-        dqkv = dqkv.contiguous()
+        # attention core backward: HIP kernels (rows -> dq, P, dS; cols -> dk, dv; rpe -> dR_q/k/v over pixels)
+        dqkv = _new(M, 3 * C, like=x)
+        dRq, dRk, dRv = (_new(B * T * T, C, like=x).view(B, T, T, C) for _ in range(3))
+        ws_p, ws_ds = _new(B * P * heads * T, T, like=x), _new(B * P * heads * T, T, like=x)
+        nat.attn_temporal_bwd(qkv, do, Rq, Rk, Rv, mask, ws_p, ws_ds, dqkv, dRq, dRk, dRv, B, T, P, C, heads)
         _wgrad_accumulate(pwq, pbq, src0=xn, C0=C, res=dqkv, ldr=3 * C, **one)
         dxn = _new(M, C, like=x)
         nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
@@ -373,18 +377,19 @@ class SpatialAttnFn(th.autograd.Function):
         nat.conv_igemm(src0=x, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=cA, coefB=cB, W=wqkv, bias=bqkv, Cout=3 * C,
                        out=qkv, ldo=3 * C)
         o = _new(M, C, like=x)
-        nat.attn_spatial(qkv, o, None, N, P, C, heads)
+        lse = _new(N * heads, P, like=x)
+        nat.attn_spatial(qkv, o, None, N, P, C, heads, lse=lse)
         y = _new(M, C, like=x)
         nat.conv_igemm(src0=o, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=wproj, bias=bproj, Cout=C, res=x, ldr=C, resA=cA,
                        resB=cB, out=y, ldo=C)
-        ctx.save_for_backward(x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o)
+        ctx.save_for_backward(x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o, lse)
         ctx.params = (wqkv, bqkv, wproj, bproj)
         ctx.geom = (N, P, heads)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o = ctx.saved_tensors
+        x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o, lse = ctx.saved_tensors
         N, P, heads = ctx.geom
         C = x.shape[1]
         M, Fh = N * P, C // heads
@@ -395,17 +400,9 @@ class SpatialAttnFn(th.autograd.Function):
         dwp = dbp = dwq = dbq = None
         do = _new(M, C, like=x)
         nat.conv_igemm(src0=dy, C0=C, ksize=1, W=_pack_t(wproj.view(C, C, 1, 1)), Cout=C, out=do, ldo=C, **geo)
-        # core backward (interim): S, P recomputed with batched library GEMMs
-        q, k, v = (t.permute(0, 2, 1, 3) for t in qkv.view(N, P, 3, heads, Fh).unbind(2))   # N, H, P, F
-        scale = Fh ** -0.5
-        dO = do.view(N, P, heads, Fh).permute(0, 2, 1, 3)
-        attn = th.softmax((q * scale) @ k.transpose(-1, -2), dim=-1)
-        dv = attn.transpose(-1, -2) @ dO
-        dP = dO @ v.transpose(-1, -2)
-        dS = attn * (dP - (attn * dP).sum(-1, keepdim=True))
-        dq = (dS @ k) * scale
-        dk = dS.transpose(-1, -2) @ (q * scale)
-        dqkv = th.stack([dq, dk, dv], dim=0).permute(1, 3, 0, 2, 4).reshape(M, 3 * C).contiguous()
+        # core backward: flash-style HIP kernels (S, P recomputed from q, k and the saved log-sum-exp)
+        dqkv = _new(M, 3 * C, like=x)
+        nat.attn_spatial_bwd(qkv, o, do, lse, _new(N * heads, P, like=x), dqkv, N, P, C, heads)
         _wgrad_accumulate(pwq, pbq, src0=x, C0=C, ksize=1, coefA=cA, coefB=cB, res=dqkv, ldr=3 * C, **geo)
         dxn = _new(M, C, like=x)   # gradient w.r.t. the normalised tensor: qkv path + residual
         nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
@@ -416,10 +413,14 @@ class SpatialAttnFn(th.autograd.Function):
 
 # ----------------------------------------------------------------------------- whole network
 def _rpe_R(net, temb_b, rel, B, T):
-    """RPENet (rpe.py:20-31) on device; tiny, stays on library ops in the training path."""
+    """RPENet (rpe.py:20-31) on device: the 3-feature / time-embedding projections are tiny library ops, the
+    C x C output layer runs on the HIP GEMM kernels."""
     relf = rel.to(th.float32)
     feats = th.stack([th.log1p(relf.clamp(min=0)), th.log1p((-relf).clamp(min=0)), (rel == 0).to(th.float32)], dim=-1)
     hid = net.embed_diffusion_time(temb_b).view(B, 1, 1, -1) + net.embed_distances(feats)
+    C = hid.shape[-1]
+    if C % 32 == 0:   # the C x C output layer on the implicit-GEMM / wgrad kernels (rows = B*T*T)
+        return LinearFn.apply(F.silu(hid).reshape(B * T * T, C), net.out.weight, net.out.bias, None).view(B, T, T, C)
     return net.out(F.silu(hid)).contiguous()       # B, T, T, C
 
 

@@ -324,7 +324,7 @@ class Plan:
         if self.want_attn:
             asp = self.buf(N, heads, P, P)
             self.attn_s.append(asp)
-        self.add(L.lfvdm_attn_spatial, _p(self.s_qkv), _p(self.s_o), _p(asp) if asp is not None else None, N, P, Cc, heads)
+        self.add(L.lfvdm_attn_spatial, _p(self.s_qkv), _p(self.s_o), _p(asp) if asp is not None else None, None, N, P, Cc, heads)
         ys = self.buf(M, Cc)
         self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
                       bias=sa.proj_out.bias, Cout=Cc, res=yt, ldr=Cc, resA=self.s_cA, resB=self.s_cB, out=ys, ldo=Cc)

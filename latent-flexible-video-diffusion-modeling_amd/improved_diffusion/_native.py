@@ -71,7 +71,9 @@ _SIGS = {
     "lfvdm_gn_temporal": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rowdot": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_nets": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
-    "lfvdm_attn_spatial": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_attn_spatial": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_attn_temporal_bwd": ([c_fp] * 12 + [c_i] * 5 + [c_fp], c_i),
+    "lfvdm_attn_spatial_bwd": ([c_fp] * 6 + [c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_attn_temporal": ([c_fp] * 7 + [c_i] * 5 + [c_fp], c_i),
     "lfvdm_adamw_ema": ([C.POINTER(AdamWArgs), c_fp], c_i),
     "lfvdm_q_sample": ([c_fp] * 6 + [c_i, c_i, c_fp], c_i),
@@ -204,13 +206,25 @@ def rpe_nets(jobs_dev, njobs, total_tiles, frame_indices, B, T):
                                stream()), "lfvdm_rpe_nets")
 
 
-def attn_spatial(qkv, o, attn_out, N, P, Cc, heads):
-    check(lib().lfvdm_attn_spatial(ptr(qkv), ptr(o), ptr(attn_out), N, P, Cc, heads, stream()), "lfvdm_attn_spatial")
+def attn_spatial(qkv, o, attn_out, N, P, Cc, heads, lse=None):
+    check(lib().lfvdm_attn_spatial(ptr(qkv), ptr(o), ptr(attn_out), ptr(lse), N, P, Cc, heads, stream()),
+          "lfvdm_attn_spatial")
+
+
+def attn_spatial_bwd(qkv, o, d_o, lse, delta_ws, dqkv, N, P, Cc, heads):
+    check(lib().lfvdm_attn_spatial_bwd(ptr(qkv), ptr(o), ptr(d_o), ptr(lse), ptr(delta_ws), ptr(dqkv), N, P, Cc, heads,
+                                       stream()), "lfvdm_attn_spatial_bwd")
 
 
 def attn_temporal(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, Cc, heads):
     check(lib().lfvdm_attn_temporal(ptr(qkv), ptr(Rq), ptr(Rk), ptr(Rv), ptr(mask), ptr(o), ptr(attn_out), B, T, P, Cc,
                                     heads, stream()), "lfvdm_attn_temporal")
+
+
+def attn_temporal_bwd(qkv, d_o, Rq, Rk, Rv, mask, ws_p, ws_ds, dqkv, dRq, dRk, dRv, B, T, P, Cc, heads):
+    check(lib().lfvdm_attn_temporal_bwd(ptr(qkv), ptr(d_o), ptr(Rq), ptr(Rk), ptr(Rv), ptr(mask), ptr(ws_p), ptr(ws_ds),
+                                        ptr(dqkv), ptr(dRq), ptr(dRk), ptr(dRv), B, T, P, Cc, heads, stream()),
+          "lfvdm_attn_temporal_bwd")
 
 
 def q_sample(x0, noise, t, sa, sb, out):

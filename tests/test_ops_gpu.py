@@ -236,6 +236,31 @@ def test_attn_spatial(nat, N, P, Cc, heads):
     close(a, attn, 1e-5)
 
 
+@pytest.mark.parametrize("N,P,Cc,heads", [(3, 256, 64, 4), (2, 64, 128, 4), (5, 4, 128, 4), (2, 100, 64, 2), (2, 64, 32, 4), (1, 70, 96, 4),
+                                            (1, 256, 384, 4), (2, 64, 512, 4), (1, 50, 320, 4), (1, 33, 448, 4), (1, 300, 64, 4)])
+def test_attn_spatial_backward(nat, N, P, Cc, heads):
+    """dqkv of the flash-style backward kernels vs torch autograd (fp64) of the same core (rpe.py:143-169)."""
+    qkv = rnd("asb/qkv", N, P, 3 * Cc)
+    d_o = rnd("asb/do", N, P, Cc)
+    Fh = Cc // heads
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (x.view(N, P, 3, heads, Fh)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    attn = torch.softmax((q * Fh ** -0.5) @ k.transpose(-1, -2), -1)
+    ref_o = (attn @ v).permute(0, 2, 1, 3).reshape(N, P, Cc)
+    (ref_o * d_o.double()).sum().backward()
+    qc, doc = qkv.cuda().view(N * P, 3 * Cc), d_o.cuda().view(N * P, Cc)
+    o = torch.empty(N * P, Cc, device="cuda")
+    lse = torch.empty(N * heads, P, device="cuda")
+    nat.attn_spatial(qc, o, None, N, P, Cc, heads, lse=lse)
+    ref_lse = torch.logsumexp((q * Fh ** -0.5) @ k.transpose(-1, -2), -1).reshape(N * heads, P)
+    close(lse, ref_lse.detach().float(), 2e-5)
+    dqkv = torch.full((N * P, 3 * Cc), float("nan"), device="cuda")
+    nat.attn_spatial_bwd(qc, o, doc, lse, torch.empty(N * heads, P, device="cuda"), dqkv, N, P, Cc, heads)
+    g = x.grad.float().view(N * P, 3 * Cc)
+    err = float((dqkv.cpu() - g).abs().max())
+    assert err <= 2e-5 * (1.0 + float(g.abs().max())) + 3e-5, err
+
+
 @pytest.mark.parametrize("B,T,P,Cc,heads", [(2, 20, 16, 64, 4), (2, 5, 4, 128, 4), (1, 14, 9, 64, 4), (2, 32, 3, 32, 2), (2, 4, 16, 32, 4),
                                                    (1, 20, 7, 384, 4), (1, 3, 5, 512, 4), (2, 24, 2, 64, 4), (1, 27, 3, 96, 4),
                                                    (1, 8, 37, 64, 2), (2, 1, 6, 32, 4)])
@@ -282,6 +307,51 @@ def test_temporal_attention_block(nat, B, T, P, Cc, heads):
                    Cout=Cc, res=xn.view(M, Cc), ldr=Cc, out=y, ldo=Cc)
     got = y.view(B, T, P, Cc).permute(0, 2, 3, 1)  # -> (B, P, C, T)
     close(got, ref, 1e-4)
+
+
+def _temporal_core_f64(qkv, Rq, Rk, Rv, mask, B, T, P, Cc, heads):
+    """fp64 restatement of the temporal core (reference rpe.py:143-169): rows (b, t, p), channels [3][heads][F]."""
+    Fh = Cc // heads
+    scale = Fh ** -0.5
+    x = qkv.view(B, T, P, 3, heads, Fh).permute(3, 0, 2, 4, 1, 5)      # 3, B, P, H, T, F
+    q, k, v = x[0] * scale, x[1], x[2]
+    logits = q @ k.transpose(-1, -2)
+    logits = logits + torch.einsum("bdhtf,btshf->bdhts", q, Rk.view(B, T, T, heads, Fh))
+    logits = logits + torch.einsum("bdhtf,btshf->bdhts", k * scale, Rq.view(B, T, T, heads, Fh)).transpose(-1, -2)
+    m = mask.view(B, T)
+    same = m[:, None, :] * m[:, :, None] + (1 - m[:, None, :]) * (1 - m[:, :, None])
+    logits = logits.masked_fill((same == 0).view(B, 1, 1, T, T), float("-inf"))
+    attn = torch.softmax(logits, dim=-1)
+    out = attn @ v + torch.einsum("bdhts,btshf->bdhtf", attn, Rv.view(B, T, T, heads, Fh))
+    return out.permute(0, 3, 1, 2, 4).reshape(B * T * P, Cc)
+
+
+@pytest.mark.parametrize("B,T,P,Cc,heads", [(2, 20, 16, 64, 4), (2, 5, 4, 128, 4), (1, 14, 9, 64, 4), (2, 32, 3, 32, 2), (2, 4, 16, 32, 4),
+                                                   (1, 20, 7, 384, 4), (1, 3, 5, 512, 4), (2, 24, 2, 64, 4), (1, 27, 3, 96, 4),
+                                                   (1, 8, 37, 64, 2), (2, 1, 6, 32, 4), (2, 20, 70, 128, 4)])
+def test_attn_temporal_backward(nat, B, T, P, Cc, heads):
+    """dqkv, dR_q, dR_k, dR_v of the HIP backward kernels vs fp64 autograd of the same core."""
+    M = B * T * P
+    qkv = rnd("tb/qkv", M, 3 * Cc)
+    Rs = [0.3 * rnd(f"tb/R{i}", B, T, T, Cc) for i in range(3)]
+    d_o = rnd("tb/do", M, Cc)
+    mask = (torch.from_numpy(recipe.uniform_pm1("tb/mask", B * T)).view(B, T) > 0).float()
+    leaves = [t.double().requires_grad_(True) for t in [qkv] + Rs]
+    ref = _temporal_core_f64(leaves[0], leaves[1], leaves[2], leaves[3], mask.double(), B, T, P, Cc, heads)
+    (ref * d_o.double()).sum().backward()
+    g = [t.cuda().contiguous() for t in (qkv, d_o, *Rs, mask)]
+    o = torch.empty(M, Cc, device="cuda")
+    nat.attn_temporal(g[0], g[2], g[3], g[4], g[5], o, None, B, T, P, Cc, heads)
+    close(o, ref.detach().float(), 5e-5)
+    nanf = lambda *shape: torch.full(shape, float("nan"), device="cuda")
+    dqkv, dRq, dRk, dRv = nanf(M, 3 * Cc), nanf(B, T, T, Cc), nanf(B, T, T, Cc), nanf(B, T, T, Cc)
+    ws = torch.empty(2, B * P * heads * T * T, device="cuda")
+    nat.attn_temporal_bwd(g[0], g[1], g[2], g[3], g[4], g[5], ws[0], ws[1], dqkv, dRq, dRk, dRv, B, T, P, Cc, heads)
+    for name, got, want in (("dqkv", dqkv, leaves[0].grad), ("dRq", dRq, leaves[1].grad), ("dRk", dRk, leaves[2].grad),
+                            ("dRv", dRv, leaves[3].grad)):
+        want = want.float()
+        err = float((got.cpu() - want).abs().max())
+        assert err <= 3e-5 * (1.0 + float(want.abs().max())) + 3e-5, (name, err, float(want.abs().max()))
 
 
 def test_spatial_attention_block(nat):
