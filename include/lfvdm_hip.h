@@ -123,6 +123,16 @@ int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream);
 int lfvdm_pack_conv_weight_t(const float* w_oihw, float* w_packed_t, int Cout, int Cin, int ksize, void* stream);
 int lfvdm_unpack_conv_grad(const float* g_packed, float* g_oihw, int Cout, int Cin, int ksize, int accumulate, void* stream);
 
+/* Grouped version for a training step: every job folds one packed gradient [Cout][k*k][Cin] into the OIHW
+ * parameter gradient (g += unpack(gp)) and zeroes gp for the next step.  row0 = first workgroup (filter row) of
+ * the job, jobs sorted by row0; total_rows = sum of Cout; max_row_floats = max k*k*Cin (<= 16384). */
+typedef struct lfvdm_unpack_job {
+    float* gp;
+    float* g;
+    int32_t Cout, Cin, taps, row0;
+} lfvdm_unpack_job;
+int lfvdm_unpack_conv_grads(const lfvdm_unpack_job* jobs_dev, int njobs, int total_rows, int max_row_floats, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Model prologue: input compositing + indicator channel + 3x3 input conv in one kernel
  * (unet.py:441-450 and input_blocks.0, unet.py:310-316).

@@ -12,6 +12,8 @@
 // (atomic traffic: Cout*K*msplit*4 B per launch, far below the ~1.3 TB/s atomic rate).
 // MFMA mapping: D[co][k] += A[co][m] * B[m][k]; A lane (i=co, h) reads dout[m = 8g+4h+e][co] and B lane
 // (j=k, h) reads a[m = 8g+4h+e][k] as conflict-free column reads of the row-major LDS tiles.
+#include <cstdlib>
+
 #include "common.cuh"
 
 namespace {
@@ -161,6 +163,194 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const lfvdm_conv_args p
     }
 }
 
+// --------------------------------------------------------------------------------------------------------
+// Cooperative variant for the wide layers: a 4-wave workgroup owns COT x KT 32x32 tiles of dW (COT*32 filters
+// x KT*32 input channels of one tap) for a slice of M.  Per 32-row chunk the dout tile [32][COT*32] and the
+// fused-prologue operand tile [32][KT*32] are staged ONCE in LDS and shared by all waves (the wave-private
+// kernel above re-reads every dout row once per k tile and every operand row once per filter tile from L2);
+// wave (wc, wk) multiplies the (COT/2) x (KT/2) tiles of its quadrant, re-using each LDS fragment KT/2 resp.
+// COT/2 times.  The global loads of chunk c+1 are in flight while chunk c is on the MFMA pipe.
+template <int COT, int KT>
+__global__ __launch_bounds__(256) void conv_wgrad_coop_kernel(const lfvdm_conv_args p_in, int msplit) {
+    const lfvdm_conv_args p = p_in;
+    constexpr int DLD = COT * 32 + 4, ALD = KT * 32 + 4;
+    constexpr int DQ = COT * 8, AQ = KT * 8;          // float4 per tile row
+    constexpr int ND = COT, NA = KT;                  // float4 per thread per chunk
+    constexpr int TC = COT / 2, TK = KT / 2;          // tiles per wave along co / k
+    __shared__ __attribute__((aligned(16))) float Ds[32 * DLD];
+    __shared__ __attribute__((aligned(16))) float As[32 * ALD];
+    __shared__ float bias_red[8][COT * 32];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave & 1, wk = wave >> 1;
+
+    const int Cin = p.C0 + p.C1;
+    const int taps = p.ksize * p.ksize;
+    const int cpg = Cin / (32 * KT);                   // channel groups per tap
+    const int NKG = taps * cpg;
+    const int NCG = (p.Cout + 32 * COT - 1) / (32 * COT);
+    const int HoWo = p.Ho * p.Wo;
+    const int M = p.N * HoWo;
+    const int nchunks = (M + 31) / 32;
+
+    const int task = blockIdx.x;                       // (k group, co group, m slice)
+    const int ms = task % msplit;
+    const int cg = (task / msplit) % NCG;
+    const int kg = task / (msplit * NCG);
+    const int tap = kg / cpg;
+    const int cc = (kg - tap * cpg) * 32 * KT;         // first input channel of the group
+    const int dy = p.ksize == 3 ? tap / 3 - 1 : 0;
+    const int dx = p.ksize == 3 ? tap - (tap / 3) * 3 - 1 : 0;
+    const bool second = cc >= p.C0;
+    const float* src = selv(second, p.src1, p.src0);
+    const int Csrc = selv(second, p.C1, p.C0);
+    const int cl = second ? cc - p.C0 : cc;
+    const int Hin = p.up ? 2 * p.Hs : p.Hs, Win = p.up ? 2 * p.Ws : p.Ws;
+    const int c_beg = (int)(((long)nchunks * ms) / msplit), c_end = (int)(((long)nchunks * (ms + 1)) / msplit);
+    const int co0 = cg * 32 * COT;
+    const float rHoWo = 1.0f / (float)HoWo, rWo = 1.0f / (float)p.Wo;
+    const float* dout = p.res;
+    const bool has_coef = p.coefA != nullptr;
+    const bool silu = p.act == LFVDM_ACT_SILU;
+
+    // staging slots of this thread: dout float4 (row dr, col dcol) x ND, operand float4 (row ar, col acol) x NA
+    const int dcol = (tid % DQ) * 4, drow0 = tid / DQ;        // rows drow0 + i * (256 / DQ)
+    const int acol = (tid % AQ) * 4, arow0 = tid / AQ;
+    constexpr int DRS = 256 / DQ, ARS = 256 / AQ;
+    const bool dcol_ok = co0 + dcol < p.Cout;
+
+    f32x16 acc[TC][TK];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 dv[ND], av[NA], ca[NA], cb[NA];
+    unsigned inb_mask = 0;
+    auto issue = [&](int c) {
+        const int m0 = c * 32;
+        inb_mask = 0;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int m = m0 + drow0 + i * DRS;
+            const bool ok = m < M && dcol_ok;
+            dv[i] = ld4(dout + (ok ? (size_t)m * p.ldr + co0 + dcol : 0));
+            if (!ok) dv[i] = zero;
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + arow0 + i * ARS;
+            const bool valid = m < M;
+            const int mm = valid ? m : 0;
+            const int n = fdiv(mm, HoWo, rHoWo);
+            const int rem = mm - n * HoWo;
+            const int oy = fdiv(rem, p.Wo, rWo);
+            const int ox = rem - oy * p.Wo;
+            const int iy = oy * p.stride + dy, ix = ox * p.stride + dx;
+            const bool inb = valid && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+            const int sy = p.up ? (iy >> 1) : iy, sx = p.up ? (ix >> 1) : ix;
+            av[i] = ld4(src + (inb ? ((size_t)(n * p.Hs + sy) * p.Ws + sx) * Csrc + cl + acol : 0));
+            if (has_coef) {
+                ca[i] = ld4(p.coefA + (size_t)n * Cin + cc + acol);
+                cb[i] = ld4(p.coefB + (size_t)n * Cin + cc + acol);
+            }
+            inb_mask |= inb ? (1u << i) : 0u;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            bsum += dv[i];
+            st4(Ds + (drow0 + i * DRS) * DLD + dcol, dv[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v = av[i];
+            if (has_coef) v = v * ca[i] + cb[i];
+            if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            if (!(inb_mask & (1u << i))) v = zero;
+            st4(As + (arow0 + i * ARS) * ALD + acol, v);
+        }
+    };
+
+    if (c_beg < c_end) issue(c_beg);
+    for (int c = c_beg; c < c_end; ++c) {
+        __syncthreads();            // previous chunk consumed
+        commit();
+        __syncthreads();
+        if (c + 1 < c_end) issue(c + 1);
+        const float* dcolp = Ds + wc * TC * 32 + (lane & 31);
+        const float* acolp = As + wk * TK * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mrow = 8 * g + 4 * (lane >> 5) + e;
+                float a[TC], b[TK];
+#pragma unroll
+                for (int x = 0; x < TC; ++x) a[x] = dcolp[mrow * DLD + 32 * x];
+#pragma unroll
+                for (int y = 0; y < TK; ++y) b[y] = acolp[mrow * ALD + 32 * y];
+#pragma unroll
+                for (int x = 0; x < TC; ++x)
+#pragma unroll
+                    for (int y = 0; y < TK; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+            }
+    }
+    // ---- accumulate the partial tiles (float atomics; D lane l: column k = l&31, rows (r&3)+8*(r>>2)+4*(l>>5))
+    const int Ktot = taps * Cin;
+    float* dW = p.out;
+    const bool oihw = p.out_mode == 1;
+#pragma unroll
+    for (int x = 0; x < TC; ++x)
+#pragma unroll
+        for (int y = 0; y < TK; ++y) {
+            const int ci = cc + (wk * TK + y) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wc * TC + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < p.Cout) {
+                    float* dst = oihw ? dW + ((size_t)co * Cin + ci) * taps + tap : dW + (size_t)co * Ktot + (size_t)tap * Cin + ci;
+                    atomicAdd(dst, acc[x][y][r]);
+                }
+            }
+        }
+    if (kg == 0 && p.bias != nullptr) {     // bias gradient: column sums of this slice's dout rows, once per co group
+        __syncthreads();
+        float* br = &bias_red[tid / DQ % 8][0];
+        if (tid / DQ < 8) { br[dcol + 0] = bsum.x; br[dcol + 1] = bsum.y; br[dcol + 2] = bsum.z; br[dcol + 3] = bsum.w; }
+        __syncthreads();
+        // rows of bias_red beyond the first 8 thread rows are folded in sequentially
+        for (int rr = 8; rr < DRS; rr += 8) {
+            if (tid / DQ >= rr && tid / DQ < rr + 8) { br[dcol + 0] += bsum.x; br[dcol + 1] += bsum.y; br[dcol + 2] += bsum.z; br[dcol + 3] += bsum.w; }
+            __syncthreads();
+        }
+        if (tid < COT * 32 && co0 + tid < p.Cout) {
+            float t = 0.f;
+            const int nr = DRS < 8 ? DRS : 8;
+            for (int r = 0; r < nr; ++r) t += bias_red[r][tid];
+            atomicAdd(const_cast<float*>(p.bias) + co0 + tid, t);
+        }
+    }
+}
+
+template <int COT, int KT>
+static void launch_wgrad_coop(const lfvdm_conv_args* a, hipStream_t s, int nchunks) {
+    const int Cin = a->C0 + a->C1;
+    const int NKG = a->ksize * a->ksize * (Cin / (32 * KT));
+    const int NCG = (a->Cout + 32 * COT - 1) / (32 * COT);
+    const long tiles = (long)NKG * NCG;
+    long msplit = (512 + tiles - 1) / tiles;           // about two workgroups per CU
+    if (msplit > nchunks / 2) msplit = nchunks / 2;    // at least two chunks per slice (the prefetch needs a successor)
+    if (msplit < 1) msplit = 1;
+    hipLaunchKernelGGL((conv_wgrad_coop_kernel<COT, KT>), dim3((unsigned)(tiles * msplit)), dim3(256), 0, s, *a, (int)msplit);
+}
+
 // OIHW -> [Cin][k*k][Cout] with the taps flipped: Wt[ci][t][co] = W[co][ci][k*k-1-t]
 __global__ void pack_conv_weight_t_kernel(const float* __restrict__ w, float* __restrict__ o, int Cout, int Cin, int taps) {
     const size_t total = (size_t)Cout * Cin * taps;
@@ -187,7 +377,41 @@ __global__ void unpack_conv_grad_kernel(const float* __restrict__ gp, float* __r
     }
 }
 
+// Grouped fold of packed gradients into the OIHW parameter gradients: one workgroup per filter row,
+//   g[co][ci][t] += gp[co][t][ci];  gp[co][t][ci] = 0      (coalesced on both sides through an LDS transpose)
+// so that the wgrad kernels can keep accumulating into the atomic-friendly packed layout (consecutive lanes =
+// consecutive addresses; the OIHW layout would scatter every wave atomic over ~18 cache lines).
+__global__ __launch_bounds__(256) void unpack_conv_grads_kernel(const lfvdm_unpack_job* __restrict__ jobs, int njobs) {
+    extern __shared__ float urow[];
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].row0 <= (int)blockIdx.x) ++j;
+    const lfvdm_unpack_job J = jobs[j];
+    const int co = blockIdx.x - J.row0;
+    const int n = J.taps * J.Cin;
+    float* gp = J.gp + (size_t)co * n;
+    float* g = J.g + (size_t)co * n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        urow[i] = gp[i];
+        gp[i] = 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ci = i / J.taps, t = i - ci * J.taps;
+        g[i] += urow[t * J.Cin + ci];
+    }
+}
+
 }  // namespace
+
+extern "C" int lfvdm_unpack_conv_grads(const lfvdm_unpack_job* jobs_dev, int njobs, int total_rows, int max_row_floats,
+                                       void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_rows <= 0 || max_row_floats <= 0) return LFVDM_E_SHAPE;
+    const size_t lds = (size_t)max_row_floats * sizeof(float);
+    if (lds > 64 * 1024) return LFVDM_E_UNSUPPORTED;
+    hipLaunchKernelGGL(unpack_conv_grads_kernel, dim3((unsigned)total_rows), dim3(256), lds, (hipStream_t)stream, jobs_dev, njobs);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
 
 // dW (packed) += dout^T * f(src); db += colsum(dout).  See the kernel comment for the meaning of the fields.
 extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
@@ -199,6 +423,21 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
     if ((a->coefA == nullptr) != (a->coefB == nullptr)) return LFVDM_E_SHAPE;
     const long M = (long)a->N * a->Ho * a->Wo;
     const int nchunks = (int)((M + 31) / 32);
+    {   // wide layers: cooperative workgroup tiles (the channel group must not straddle the two sources)
+        const int cot = a->Cout >= 128 ? 4 : a->Cout >= 64 ? 2 : 0;
+        int kt = 0;
+        for (int k : {4, 2})
+            if (kt == 0 && Cin % (32 * k) == 0 && a->C0 % (32 * k) == 0) kt = k;
+        if (cot && kt && !getenv("LFVDM_WGRAD_WAVE")) {
+            hipStream_t s = (hipStream_t)stream;
+            if (cot == 4 && kt == 4) launch_wgrad_coop<4, 4>(a, s, nchunks);
+            else if (cot == 4) launch_wgrad_coop<4, 2>(a, s, nchunks);
+            else if (kt == 4) launch_wgrad_coop<2, 4>(a, s, nchunks);
+            else launch_wgrad_coop<2, 2>(a, s, nchunks);
+            LFVDM_CHECK_LAUNCH();
+            return LFVDM_OK;
+        }
+    }
     const long tiles = (long)a->ksize * a->ksize * (Cin / 32) * ((a->Cout + 31) / 32);
     long msplit = (4096 + tiles - 1) / tiles;          // aim at ~4k wave tasks
     if (msplit > nchunks) msplit = nchunks;

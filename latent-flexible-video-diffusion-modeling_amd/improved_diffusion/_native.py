@@ -48,6 +48,10 @@ class RowdotJob(C.Structure):
                 ("row0", C.c_int32), ("pad_", C.c_int32)]
 
 
+class UnpackJob(C.Structure):
+    _fields_ = [("gp", c_fp), ("g", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("row0", C.c_int32)]
+
+
 class RpeJob(C.Structure):
     _fields_ = [("tproj", c_fp), ("Wd", c_fp), ("bd", c_fp), ("Wout", c_fp), ("bout", c_fp), ("R", c_fp),
                 ("C", C.c_int32), ("tile0", C.c_int32)]
@@ -62,6 +66,7 @@ _SIGS = {
     "lfvdm_conv_wgrad": ([C.POINTER(ConvArgs), c_fp], c_i),
     "lfvdm_pack_conv_weight_t": ([c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_unpack_conv_grad": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_unpack_conv_grads": ([c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_conv_in": ([c_fp] * 6 + [c_i] * 5 + [c_fp], c_i),
     "lfvdm_gn_coef": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp], c_i),
     "lfvdm_gn_coef_stats": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp, c_fp], c_i),
