@@ -169,6 +169,7 @@ def bench_train(rank, world, dev, steps, warmup):
     for _ in range(steps):
         loop.run_step()
         loop.step += 1
+    host = time.perf_counter() - t0          # host-side issue time (the GPU runs behind asynchronously)
     th.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -184,6 +185,7 @@ def bench_train(rank, world, dev, steps, warmup):
     logger.dumpkvs()
     P = sum(p.numel() for p in model.parameters())
     return {"optimizer_steps_per_s": round(steps / el, 3), "ms_per_step": round(1000.0 * el / steps, 2), "steps": steps,
+            "host_issue_ms_per_step": round(1000.0 * host / steps, 2),
             "global_batch": 2 * world, "videos_per_s": round(2 * world * steps / el, 2), "params": P,
             "allreduce_bytes_per_step": 4 * P if world > 1 else 0, "last_loss": loss,
             "workload": "train: U-Net num_channels=128 num_res_blocks=1 max_frames=20 batch 2/GPU, AdamW+EMA, "

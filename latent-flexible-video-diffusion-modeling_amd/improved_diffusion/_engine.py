@@ -28,42 +28,6 @@ def _p(t):
     return t.data_ptr()
 
 
-def _tune_cache(engine):
-    """Launch-shape -> tuned code, per engine; optionally persisted in the JSON file named by LFVDM_TUNE_CACHE
-    (entries are only valid for the library ABI version they were measured with)."""
-    cache = engine.__dict__.get("tune_cache")
-    if cache is None:
-        cache = engine.__dict__["tune_cache"] = {}
-        path = os.environ.get("LFVDM_TUNE_CACHE", "")
-        if path and os.path.exists(path):
-            try:
-                with open(path) as f:
-                    blob = json.load(f)
-                if blob.get("abi") == int(nat.lib().lfvdm_abi_version()):
-                    cache.update({tuple(json.loads(k)): int(v) for k, v in blob["entries"].items()})
-            except (OSError, ValueError, KeyError):
-                pass
-        engine.__dict__["tune_cache_saved"] = len(cache)
-    return cache
-
-
-def _tune_cache_save(engine):
-    path = os.environ.get("LFVDM_TUNE_CACHE", "")
-    cache = engine.__dict__.get("tune_cache") or {}
-    if not path or len(cache) == engine.__dict__.get("tune_cache_saved", 0):
-        return
-    try:
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "w") as f:
-            json.dump({"abi": int(nat.lib().lfvdm_abi_version()),
-                       "entries": {json.dumps([int(x) for x in k]): int(v) for k, v in sorted(cache.items())}}, f, indent=0)
-        os.replace(tmp, path)
-        engine.__dict__["tune_cache_saved"] = len(cache)
-    except OSError:
-        pass
-
-
 class Plan:
     """Launch sequence + workspaces for one (B, T, H, W)."""
 
@@ -343,46 +307,23 @@ class Plan:
 
     # ------------------------------------------------------------------ autotune
     def autotune(self, rounds=3, reps=6):
-        """Time every legal (tile shape, K-chunk, split-K) variant of each implicit-GEMM launch of this plan
-        on the device and pin the fastest in the launch arguments.  Shapes are static per plan, so this
-        runs once (about half a second); the built-in makespan model is only the starting point."""
+        """Pin the fastest (tile shape, K-chunk, split-K) variant of each implicit-GEMM launch of this plan
+        (``_native.tuned_code``: measured once per launch shape, shared by every plan and by the training path;
+        the built-in makespan model is only the starting point)."""
         L = nat.lib()
-        s = nat.stream()
-        codes = (C.c_int * 64)()
-        ev0, ev1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        cache = nat.tune_cache()
         tuned = 0
         for fn, args in self.steps:
             if fn is not L.lfvdm_conv_igemm:
                 continue
             a = args[0]._obj
-            key = (a.N, a.Hs, a.Ws, a.up, a.stride, a.ksize, a.Ho, a.Wo, a.C0, a.C1, a.Cout, a.s2C0, a.s2C1,
-                   bool(a.coefA), a.act, bool(a.res), bool(a.resA), a.out_mode)
-            cache = _tune_cache(self.engine)
-            if key in cache:             # same launch shape already timed (another plan / window length)
-                a.tune = cache[key]
-                tuned += 1
-                continue
-            n = L.lfvdm_conv_igemm_candidates(C.byref(a), codes, 64)
-            best, best_t = 0, float("inf")
-            for code in [0] + [codes[i] for i in range(n)]:
-                a.tune = code
-                if fn(C.byref(a), s) != 0:
-                    continue
-                t_min = float("inf")
-                for _ in range(rounds):
-                    ev0.record()
-                    for _ in range(reps):
-                        fn(C.byref(a), s)
-                    ev1.record()
-                    ev1.synchronize()
-                    t_min = min(t_min, ev0.elapsed_time(ev1))
-                if t_min < best_t * 0.98:      # prefer earlier (simpler) candidates on ties
-                    best, best_t = code, t_min
-            a.tune = best
-            cache[key] = best
+            key = nat.tune_key(a)
+            if key not in cache:
+                cache[key] = nat.autotune_launch(a, rounds, reps)
+            a.tune = cache[key]
             tuned += 1
         self.tuned = True
-        _tune_cache_save(self.engine)
+        nat.tune_cache_save()
         return tuned
 
     # ------------------------------------------------------------------ run

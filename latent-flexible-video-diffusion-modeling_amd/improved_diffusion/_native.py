@@ -5,7 +5,9 @@ integer shapes and the current HIP stream.  There is NO fallback: if ``liblfvdm_
 missing, importing the product on a GPU path raises immediately (build it with
 ``python latent-flexible-video-diffusion-modeling_amd/build.py``).
 """
+import atexit
 import ctypes as C
+import json
 import os
 
 import torch
@@ -145,7 +147,94 @@ def conv_igemm(**kw):
     a.W2 = ptr(kw.get("W2")); a.bias2 = ptr(kw.get("bias2"))
     a.res = ptr(kw.get("res")); a.ldr = kw.get("ldr", kw["Cout"]); a.resA = ptr(kw.get("resA")); a.resB = ptr(kw.get("resB"))
     a.out = ptr(kw["out"]); a.ldo = kw["ldo"]; a.out_mode = kw.get("out_mode", OUT_ROWS)
+    a.tune = tuned_code(a)
     check(lib().lfvdm_conv_igemm(C.byref(a), stream()), "lfvdm_conv_igemm")
+
+
+# ------------------------------------------------------------------------------------------- launch tuning
+# Launch shape -> tile/K-chunk/split-K code (lfvdm_conv_args.tune), measured on the device the first time a
+# shape is launched outside of stream capture and optionally persisted in the JSON file named by
+# LFVDM_TUNE_CACHE (entries are only valid for the library ABI version they were measured with).
+_tune = None
+_tune_saved = 0
+
+
+def tune_key(a):
+    return (a.N, a.Hs, a.Ws, a.up, a.stride, a.ksize, a.Ho, a.Wo, a.C0, a.C1, a.Cout, a.s2C0, a.s2C1, bool(a.coefA), a.act,
+            bool(a.res), bool(a.resA), a.out_mode, bool(a.splitk_ws))
+
+
+def tune_cache():
+    global _tune, _tune_saved
+    if _tune is None:
+        _tune = {}
+        path = os.environ.get("LFVDM_TUNE_CACHE", "")
+        if path and os.path.exists(path):
+            try:
+                with open(path) as f:
+                    blob = json.load(f)
+                if blob.get("abi") == int(lib().lfvdm_abi_version()):
+                    _tune.update({tuple(json.loads(k)): int(v) for k, v in blob["entries"].items()})
+            except (OSError, ValueError, KeyError):
+                pass
+        _tune_saved = len(_tune)
+        atexit.register(tune_cache_save)
+    return _tune
+
+
+def tune_cache_save():
+    global _tune_saved
+    path = os.environ.get("LFVDM_TUNE_CACHE", "")
+    if not path or _tune is None or len(_tune) == _tune_saved:
+        return
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump({"abi": int(lib().lfvdm_abi_version()),
+                       "entries": {json.dumps([int(x) for x in k]): int(v) for k, v in sorted(_tune.items())}}, f, indent=0)
+        os.replace(tmp, path)
+        _tune_saved = len(_tune)
+    except OSError:
+        pass
+
+
+def autotune_launch(a, rounds=3, reps=6):
+    """Time every legal variant of this implicit-GEMM launch (the launch is idempotent) and return the fastest
+    code.  Must not be called while the stream is capturing."""
+    L, s = lib(), stream()
+    codes = (C.c_int * 64)()
+    n = L.lfvdm_conv_igemm_candidates(C.byref(a), codes, 64)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best, best_t = 0, float("inf")
+    for code in [0] + [codes[i] for i in range(n)]:
+        a.tune = code
+        if L.lfvdm_conv_igemm(C.byref(a), s) != 0:
+            continue
+        t_min = float("inf")
+        for _ in range(rounds):
+            ev0.record()
+            for _ in range(reps):
+                L.lfvdm_conv_igemm(C.byref(a), s)
+            ev1.record()
+            ev1.synchronize()
+            t_min = min(t_min, ev0.elapsed_time(ev1))
+        if t_min < best_t * 0.98:      # prefer earlier (simpler) candidates on ties
+            best, best_t = code, t_min
+    a.tune = best
+    return best
+
+
+def tuned_code(a):
+    """Cached code for this launch shape; measures it on first sight unless LFVDM_AUTOTUNE=0 or capturing."""
+    cache = tune_cache()
+    key = tune_key(a)
+    code = cache.get(key)
+    if code is None:
+        if os.environ.get("LFVDM_AUTOTUNE", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            return 0
+        code = cache[key] = autotune_launch(a)
+    return code
 
 
 def fill_conv_args(**kw):

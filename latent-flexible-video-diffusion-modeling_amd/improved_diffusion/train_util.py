@@ -311,10 +311,15 @@ class TrainLoop:
             micro, frame_indices, obs_mask, latent_mask = self.sample_all_masks(micro1, micro2)
             micro = self.encode(micro)
             dev = dist_util.dev()
-            micro, frame_indices = micro.to(dev), frame_indices.to(dev)
-            obs_mask, latent_mask = obs_mask.to(dev), latent_mask.to(dev)
-            t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
-            inputs = (micro, frame_indices, obs_mask, latent_mask, t, weights)
+            if dev.type == "cuda" and not micro.is_cuda:
+                t, weights = self.schedule_sampler.sample(micro.shape[0], th.device("cpu"))
+                inputs = self._upload_async(dev, micro, frame_indices, obs_mask, latent_mask, t, weights)
+                micro, frame_indices, obs_mask, latent_mask, t, weights = inputs
+            else:
+                micro, frame_indices = micro.to(dev), frame_indices.to(dev)
+                obs_mask, latent_mask = obs_mask.to(dev), latent_mask.to(dev)
+                t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
+                inputs = (micro, frame_indices, obs_mask, latent_mask, t, weights)
             if micro.is_cuda and self.pad_with_random_frames:
                 weighted, raw = self._graphed_micro_step(inputs)
             else:
@@ -324,7 +329,56 @@ class TrainLoop:
             # The loss terms are logged one micro-step late (or at the next dumpkvs/save): reading them now
             # would stall the host on the GPU and serialise batch preparation with the device work.
             self._flush_loss_log()
-            self._pending_log = (t.clone(), {k: v.clone() for k, v in weighted.items()})
+            self._stash_loss_log(t, weighted)
+
+    def _upload_async(self, dev, *host_tensors):
+        """All host inputs of a micro-step in ONE asynchronous copy from a pinned staging ring: a pageable
+        ``.to(device)`` blocks the host until the GPU has drained the previous step, which would serialise batch
+        preparation with the device work."""
+        ring = self.__dict__.setdefault("_stage_ring", {"slots": [], "next": 0})
+        sizes = [(x.numel() * x.element_size() + 15) // 16 * 16 for x in host_tensors]
+        total = sum(sizes)
+        if not ring["slots"] or ring["slots"][0][0].numel() < total:
+            ring["slots"] = [[th.empty(total, dtype=th.uint8).pin_memory(), None] for _ in range(4)]
+            ring["next"] = 0
+        slot = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % len(ring["slots"])
+        if slot[1] is not None:
+            slot[1].synchronize()              # copy issued 4 micro-steps ago: long finished
+        stage, off, views = slot[0], 0, []
+        for x, n in zip(host_tensors, sizes):
+            nb = x.numel() * x.element_size()
+            stage[off:off + nb].view(x.dtype).copy_(x.reshape(-1))
+            views.append((off, nb, x.dtype, tuple(x.shape)))
+            off += n
+        dbuf = stage[:total].to(dev, non_blocking=True)
+        slot[1] = th.cuda.Event()
+        slot[1].record()
+        return tuple(dbuf[o:o + nb].view(dt).view(shape) for o, nb, dt, shape in views)
+
+    def _stash_loss_log(self, t, weighted):
+        """Queue the per-sample loss terms for logging without stalling this stream: a side stream copies them
+        into pinned memory once they are computed; ``_flush_loss_log`` reads them one micro-step later."""
+        keys = list(weighted.keys())
+        if not t.is_cuda:
+            self._pending_log = (keys, th.stack([weighted[k].detach().float() for k in keys] + [t.float()]), None)
+            return
+        packed = th.stack([weighted[k].detach().float() for k in keys] + [t.float()])
+        side = self.__dict__.setdefault("_log_stream", th.cuda.Stream())
+        ready = th.cuda.Event()
+        ready.record()
+        ring = self.__dict__.setdefault("_log_ring", {"bufs": [], "next": 0})
+        if not ring["bufs"] or ring["bufs"][0].shape != packed.shape:
+            ring["bufs"] = [th.empty(packed.shape, dtype=th.float32).pin_memory() for _ in range(4)]
+        host = ring["bufs"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % 4
+        with th.cuda.stream(side):
+            side.wait_event(ready)
+            host.copy_(packed, non_blocking=True)
+            packed.record_stream(side)
+            done = th.cuda.Event()
+            done.record(side)
+        self._pending_log = (keys, host, done)
 
     def _flush_loss_log(self):
         if self._flush_loss_log not in logger.pre_dump_hooks:
@@ -333,7 +387,11 @@ class TrainLoop:
             logger.pre_dump_hooks.append(self._flush_loss_log)
         pending, self._pending_log = getattr(self, "_pending_log", None), None
         if pending is not None:
-            log_loss_dict(self.diffusion, pending[0], pending[1])
+            keys, host, done = pending
+            if done is not None:
+                done.synchronize()
+            vals = host.numpy()
+            log_loss_dict(self.diffusion, vals[-1], {k: vals[i] for i, k in enumerate(keys)})
 
     def optimize_normal(self):
         """All-reduce (once) + fused AdamW/EMA/grad-norm (reference train_util.py:346-357)."""
@@ -537,8 +595,11 @@ def log_loss_dict(diffusion, ts, losses):
     """Mean and per-timestep-quartile means of every loss term (reference train_util.py:530-536), with a
     single device->host transfer."""
     keys = list(losses.keys())
-    stacked = th.stack([losses[k].detach().float() for k in keys]).cpu().numpy()
-    ts_np = ts.cpu().numpy()
+    if isinstance(ts, np.ndarray):       # already on the host (TrainLoop's deferred logging)
+        stacked, ts_np = np.stack([np.asarray(losses[k], dtype=np.float32) for k in keys]), ts
+    else:
+        stacked = th.stack([losses[k].detach().float() for k in keys]).cpu().numpy()
+        ts_np = ts.cpu().numpy()
     for key, values in zip(keys, stacked):
         logger.logkv_mean(key, float(values.mean()))
         for sub_t, sub_loss in zip(ts_np, values):
