@@ -69,8 +69,10 @@ def conv_flops(a):
     return 2.0 * M * a.Cout * K
 
 
-def kernel_breakdown(plan, reps=20):
-    """Per-launch HIP-event timing of every step of the forward plan (eager, same stream)."""
+def kernel_breakdown(plan, reps=10, inner=4):
+    """Per-launch HIP-event timing of every step of the forward plan (eager, on the stream the kernels are launched
+    on).  Each step is launched `inner` times back to back between one event pair, which amortises the ~5 us that
+    an event pair adds around a single launch, so the figure tracks the kernel duration rocprofv3 reports."""
     import ctypes as C
     from improved_diffusion import _native as nat
     L = nat.lib()
@@ -81,12 +83,13 @@ def kernel_breakdown(plan, reps=20):
     for rep in range(reps + 2):
         for i, (fn, args) in enumerate(plan.steps):
             ev[i][0].record()
-            fn(*args, s)
+            for _ in range(inner):
+                fn(*args, s)
             ev[i][1].record()
         th.cuda.synchronize()
         if rep >= 2:
             for i in range(n):
-                tot[i] += ev[i][0].elapsed_time(ev[i][1])
+                tot[i] += ev[i][0].elapsed_time(ev[i][1]) / inner
     groups = {}
     for i, (fn, args) in enumerate(plan.steps):
         name = fn.__name__

@@ -8,11 +8,18 @@ HIP kernels for the heavy work of the reference's ``loss.backward()`` (train_uti
     the zero-insertion gather), weight/bias gradient ``lfvdm_conv_wgrad`` (fp32 MFMA, the fused
     GroupNorm/FiLM/SiLU operand is recomputed on the fly, never stored);
   * GroupNorm(+FiLM)(+SiLU): ``lfvdm_gn_coef_stats`` forward, ``lfvdm_gn_bwd_stats/apply`` backward;
-    temporal GroupNorm ``lfvdm_gn_temporal(_bwd)``; attention cores forward ``lfvdm_attn_*``.
+    temporal GroupNorm ``lfvdm_gn_temporal(_bwd)``;
+  * attention cores: forward ``lfvdm_attn_spatial`` (saves the log-sum-exp) / ``lfvdm_attn_temporal``, backward
+    ``lfvdm_attn_spatial_bwd`` (flash style dq / dk,dv kernels) and ``lfvdm_attn_temporal_bwd`` (rows / cols /
+    rpe kernels: dqkv and the three R gradients, no atomics);
+  * the C x C output layer of every RPE network on the same GEMM / wgrad kernels.
 
-Round-1 interim (documented in DESIGN.md): the small-M pieces (time-embedding MLP, FiLM projections, RPE
-networks: < 2 % of the FLOPs) and the backward of the two attention CORES run on library batched GEMMs
-(rocBLAS through torch.matmul/einsum) plus elementwise softmax-backward ops; all on the GPU, no CPU path.
+3x3 weight gradients accumulate in packed [Cout][tap][Cin] buffers and are folded into the OIHW ``.grad`` tensors
+by ONE grouped kernel at the end of each backward pass (``_PackedGrads``).  Launch shapes are tuned on first sight
+(``_native.tuned_code``).  What is left on library ops (all on the GPU, no CPU path): the (B x 4ch) time-embedding /
+FiLM projections and the 3-feature / time projections inside the RPE networks - a few (2..800)-row GEMMs per
+block, < 1 % of the FLOPs - plus their elementwise glue (SiLU, log1p features) and GroupNorm parameter-gradient
+reductions.
 """
 import torch as th
 import torch.nn as nn
