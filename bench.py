@@ -260,10 +260,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not th.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    local %= max(th.cuda.device_count(), 1)   # (rehearsals of N > 1 on a one-GPU box share the card)
     th.cuda.set_device(local)
     dev = th.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("LFVDM_BENCH_BACKEND", "nccl")   # "gloo" only for such rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B, T = 2, 20
     model, diffusion = make_model_and_diffusion(64, dev)

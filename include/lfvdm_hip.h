@@ -258,6 +258,10 @@ int lfvdm_p_sample(const float* x, const float* eps, const float* noise, const i
                    const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* coef1,
                    const float* coef2, const float* log_var, int clip, float* sample, float* pred_xstart,
                    float* mean_out, int B, int inner, void* stream);
+/* Sampler clock of the captured denoising step (the loop `for i in indices: t = th.tensor([i]*B)` of
+ * gaussian_diffusion.py:509-512 and _WrappedModel's timestep map, respace.py:117-122, kept on the device):
+ * t[b] <- max(t[b] - 1, 0);  model_t[b] <- model_timestep_table[t[b]]. */
+int lfvdm_sampler_tick(int64_t* t, const float* model_timestep_table, float* model_t, int B, void* stream);
 /* masked mean of squared error, :787-788 + nn.py:86-92: out[b] = mean_inner((a-b)^2 * mask[b,frame]).
  * mask is (B, T) (broadcast over the per-frame block of `frame_inner` elements) or NULL. */
 int lfvdm_masked_mse(const float* a, const float* b, const float* mask, float* out, int B, int T,

@@ -82,6 +82,27 @@ extern "C" int lfvdm_q_sample(const float* x0, const float* noise, const int64_t
     return LFVDM_OK;
 }
 
+namespace {
+// one thread per batch element: t <- max(t - 1, 0); model_t <- table[t]
+__global__ void sampler_tick_kernel(int64_t* __restrict__ t, const float* __restrict__ table, float* __restrict__ model_t, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int64_t v = t[b] - 1;
+    v = v < 0 ? 0 : v;
+    t[b] = v;
+    model_t[b] = table[v];
+}
+
+}  // namespace
+
+extern "C" int lfvdm_sampler_tick(int64_t* t, const float* model_timestep_table, float* model_t, int B, void* stream) {
+    if (B <= 0 || !t || !model_timestep_table || !model_t) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(sampler_tick_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, t, model_timestep_table,
+                       model_t, B);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
 extern "C" int lfvdm_p_sample(const float* x, const float* eps, const float* noise, const int64_t* t,
                               const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* coef1,
                               const float* coef2, const float* log_var, int clip, float* sample, float* pred_xstart,

@@ -397,13 +397,14 @@ class GraphSampler:
 
     def _step_body(self):
         pl, tb = self.plan, self.tb
-        pl.tin[:pl.B].copy_(self.ts_table[self.t_buf])
+        # device-side clock: t <- max(t - 1, 0), model timestep <- table[t]  (t_buf holds "previous t")
+        nat.check(nat.lib().lfvdm_sampler_tick(self.t_buf.data_ptr(), self.ts_table.data_ptr(), pl.tin.data_ptr(), pl.B,
+                                               nat.stream()), "lfvdm_sampler_tick")
         pl.launch()
         self.noise.normal_()
         nat.p_sample(pl.x_in, pl.out, self.noise, self.t_buf, tb["sqrt_recip_alphas_cumprod"],
                      tb["sqrt_recipm1_alphas_cumprod"], tb["posterior_mean_coef1"], tb["posterior_mean_coef2"],
                      tb["model_log_variance"], self.clip, pl.x_in, self.pred, None)
-        self.t_buf.sub_(1).clamp_(min=0)
 
     def begin(self, img, model_kwargs):
         pl = self.plan
@@ -425,7 +426,7 @@ class GraphSampler:
                     pl.x_in.copy_(saved0)
                 # warm-up on a side stream (sets kernel attributes, fills caches), then capture
                 saved = pl.x_in.clone()
-                self.t_buf.fill_(self.diffusion.num_timesteps - 1)
+                self.t_buf.fill_(self.diffusion.num_timesteps)
                 s = th.cuda.Stream()
                 s.wait_stream(th.cuda.current_stream())
                 with th.cuda.stream(s):
@@ -438,12 +439,12 @@ class GraphSampler:
                 pl.x_in.copy_(saved)
                 th.cuda.synchronize()
                 th.cuda.set_rng_state(rng_state, pl.dev)
-            self.t_buf.fill_(self.diffusion.num_timesteps - 1)
+            self.t_buf.fill_(self.diffusion.num_timesteps)     # the step pre-decrements
         self.expected_t = self.diffusion.num_timesteps - 1
 
     def step(self, i):
         if i != self.expected_t:  # arbitrary order requested: reset the device-side counter
-            self.t_buf.fill_(i)
+            self.t_buf.fill_(i + 1)
         self.graph.replay()
         self.expected_t = max(i - 1, 0)
         return {"sample": self.plan.x_in, "pred_xstart": self.pred, "attn": None}
