@@ -6,7 +6,8 @@ namespace {
 
 // -------------------------------------------------------------------------------------
 // gn_coef: one workgroup per (sample n, slice of 8 groups).  Two exact passes (mean, then
-// centred variance) like ATen's CPU GroupNorm; the slice is re-read from L2 for pass 2.
+// centred variance) like ATen's CPU GroupNorm; small slices (<= 8 float4 per thread, i.e. every level of the
+// 16x16 latent configs) stay in registers between the passes, larger ones are re-read from L2 for pass 2.
 // Thread (pl, q): pixel lane pl strides over the P positions, q = float4 channel quad.
 // -------------------------------------------------------------------------------------
 constexpr int GN_GPW = 8;        // groups per workgroup
@@ -39,6 +40,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
     __shared__ float gmean[GN_GPW], grstd[GN_GPW];
 
     const size_t pos0 = (size_t)n * P;
+    constexpr int KEEP = 8;
+    const bool cached = P <= KEEP * PL;       // workgroup-uniform
+    f32x4 keep[KEEP];
     for (int pass = 0; pass < 2; ++pass) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (active) {
@@ -47,9 +51,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
                 mu.x = gmean[(q * 4 + 0) / cg]; mu.y = gmean[(q * 4 + 1) / cg];
                 mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg];
             }
-            for (int p = pl; p < P; p += PL) {
-                f32x4 v = ld_cat(s0, s1, C0, C1, pos0 + p, c);
-                if (pass) { v = v - mu; s += v * v; } else { s += v; }
+            if (cached) {
+#pragma unroll
+                for (int i = 0; i < KEEP; ++i) {
+                    const int p = pl + i * PL;
+                    if (pass == 0) {
+                        keep[i] = (p < P) ? ld_cat(s0, s1, C0, C1, pos0 + p, c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        s += keep[i];
+                    } else if (p < P) {
+                        const f32x4 v = keep[i] - mu;
+                        s += v * v;
+                    }
+                }
+            } else {
+                for (int p = pl; p < P; p += PL) {
+                    f32x4 v = ld_cat(s0, s1, C0, C1, pos0 + p, c);
+                    if (pass) { v = v - mu; s += v * v; } else { s += v; }
+                }
             }
             st4(part + (pl * Q + q) * 4, s);
         }
