@@ -167,6 +167,10 @@ int lfvdm_gn_bwd_stats(const float* da, const float* src0, const float* src1, in
 int lfvdm_gn_bwd_apply(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
                        const float* coefA, const float* coefB, const float* stats, const float* sums, int act,
                        float* out0, float* out1, int acc0, int acc1, void* stream);
+/* GroupNorm(+FiLM) parameter gradients from the sums of lfvdm_gn_bwd_stats: dgamma / dbeta [C] are ACCUMULATED
+ * (+=, fixed order), dfilm [N/T][2C] (d scale | d shift of unet.py:199-203) is written when film != NULL. */
+int lfvdm_gn_param_grads(const float* sums, const float* gamma, const float* beta, const float* film, int T,
+                         float* dgamma, float* dbeta, float* dfilm, int N, int C, void* stream);
 /* Temporal GroupNorm backward: dx from dy; dgamma/dbeta [C] are ACCUMULATED with float atomics. */
 int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* dgamma,
                           float* dbeta, int B, int T, int P, int C, int accumulate, void* stream);

@@ -237,6 +237,45 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
     }
 }
 
+// Parameter gradients of a (FiLM-modulated) GroupNorm from the per-(sample, channel) sums of gn_bwd_stats
+// (sums[n][c] = {sum dz, sum dz*xhat}); one thread per channel, fixed summation order (deterministic):
+//   dgamma[c] += sum_n s2 * (1 + scale[n/T][c]);  dbeta[c] += sum_n s1 * (1 + scale);
+//   dfilm[b][c] = sum_t (s2 * gamma[c] + s1 * beta[c]);  dfilm[b][C + c] = sum_t s1        (FiLM only)
+__global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ film,
+                                                             int T, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ dfilm, int N, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float dg = 0.f, db = 0.f;
+    if (film) {
+        const float g = gamma[c], be = beta[c];
+        const int B = N / T;
+        for (int b = 0; b < B; ++b) {
+            const float sc1 = 1.0f + film[(size_t)b * 2 * C + c];
+            float dsc = 0.f, dsh = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float* s = sums + ((size_t)(b * T + t) * C + c) * 2;
+                const float s1 = s[0], s2 = s[1];
+                dg += s2 * sc1;
+                db += s1 * sc1;
+                dsc += s2 * g + s1 * be;
+                dsh += s1;
+            }
+            dfilm[(size_t)b * 2 * C + c] = dsc;
+            dfilm[(size_t)b * 2 * C + C + c] = dsh;
+        }
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const float* s = sums + ((size_t)n * C + c) * 2;
+            db += s[0];
+            dg += s[1];
+        }
+    }
+    dgamma[c] += dg;
+    dbeta[c] += db;
+}
+
 }  // namespace
 
 extern "C" int lfvdm_gn_bwd_stats(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
@@ -268,6 +307,16 @@ extern "C" int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const floa
     const long samples = (long)B * P;
     hipLaunchKernelGGL(gn_temporal_bwd_kernel, dim3((unsigned)((samples + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, dy,
                        gamma, eps, dx, dgamma, dbeta, B, T, P, C, accumulate);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_param_grads(const float* sums, const float* gamma, const float* beta, const float* film, int T,
+                                    float* dgamma, float* dbeta, float* dfilm, int N, int C, void* stream) {
+    if (!sums || !dgamma || !dbeta || N <= 0 || C <= 0) return LFVDM_E_SHAPE;
+    if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T)) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, film, T,
+                       dgamma, dbeta, dfilm, N, C);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -237,6 +237,13 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
     dxb = _new(N * P, C1, like=da) if C1 else None
     nat.check(L.lfvdm_gn_bwd_apply(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
                                    nat.ptr(sums), act, nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.stream()), "lfvdm_gn_bwd_apply")
+    if gamma.is_leaf and beta.is_leaf:
+        # parameter gradients accumulated in place by one small kernel (no reductions / AccumulateGrad adds)
+        dfilm = _new(N // T, 2 * C, like=da) if film is not None else None
+        nat.check(L.lfvdm_gn_param_grads(nat.ptr(sums), nat.ptr(gamma), nat.ptr(beta), nat.ptr(film), T,
+                                         nat.ptr(_grad_of(gamma)), nat.ptr(_grad_of(beta)), nat.ptr(dfilm), N, C,
+                                         nat.stream()), "lfvdm_gn_param_grads")
+        return dxa, dxb, None, None, dfilm
     s1, s2 = sums[..., 0], sums[..., 1]              # [N][C]: sum dz, sum dz*xhat
     if film is not None:
         B = N // T
@@ -387,6 +394,7 @@ class TemporalAttnFn(th.autograd.Function):
                        ldo=C)
         ctx.save_for_backward(x, gn_w, wqkv, wproj, Rq, Rk, Rv, mask, xn, qkv, o)
         ctx.params = (wqkv, bqkv, wproj, bproj)
+        ctx.gn_b = gn_b
         ctx.geom = (B, T, P, heads)
         return y
 
@@ -413,9 +421,14 @@ class TemporalAttnFn(th.autograd.Function):
         nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
                        ldo=C, **one)
         dx = th.empty_like(x)
-        dg, db = th.zeros(C, device=x.device), th.zeros(C, device=x.device)
-        nat.check(nat.lib().lfvdm_gn_temporal_bwd(nat.ptr(x), nat.ptr(dxn), nat.ptr(gn_w), _EPS, nat.ptr(dx), nat.ptr(dg),
-                                                  nat.ptr(db), B, T, P, C, 0, nat.stream()), "lfvdm_gn_temporal_bwd")
+        gn_b = ctx.gn_b
+        if gn_w.is_leaf and gn_b.is_leaf:      # accumulate straight into the parameter gradients
+            dg, db, tg, tb = None, None, _grad_of(gn_w), _grad_of(gn_b)
+        else:
+            dg, db = th.zeros(C, device=x.device), th.zeros(C, device=x.device)
+            tg, tb = dg, db
+        nat.check(nat.lib().lfvdm_gn_temporal_bwd(nat.ptr(x), nat.ptr(dxn), nat.ptr(gn_w), _EPS, nat.ptr(dx), nat.ptr(tg),
+                                                  nat.ptr(tb), B, T, P, C, 0, nat.stream()), "lfvdm_gn_temporal_bwd")
         return dx, dg, db, dwq, dbq, dwp, dbp, dRq, dRk, dRv, None, None, None, None, None
 
 
