@@ -123,6 +123,16 @@ int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream);
 int lfvdm_pack_conv_weight_t(const float* w_oihw, float* w_packed_t, int Cout, int Cin, int ksize, void* stream);
 int lfvdm_unpack_conv_grad(const float* g_packed, float* g_oihw, int Cout, int Cin, int ksize, int accumulate, void* stream);
 
+/* Grouped weight packing (one launch per training step instead of two per convolution): job = one OIHW weight ->
+ * [Cout][k*k][Cin] (transposed = 0, as lfvdm_pack_conv_weight) or [Cin][k*k][Cout] flipped (transposed = 1, as
+ * lfvdm_pack_conv_weight_t).  blk0 = first workgroup of the job (1024 elements per workgroup), jobs sorted by blk0. */
+typedef struct lfvdm_pack_job {
+    const float* src;
+    float* dst;
+    int32_t Cout, Cin, taps, transposed, blk0, pad_;
+} lfvdm_pack_job;
+int lfvdm_pack_conv_weights(const lfvdm_pack_job* jobs_dev, int njobs, int total_blocks, void* stream);
+
 /* Grouped version for a training step: every job folds one packed gradient [Cout][k*k][Cin] into the OIHW
  * parameter gradient (g += unpack(gp)) and zeroes gp for the next step.  row0 = first workgroup (filter row) of
  * the job, jobs sorted by row0; total_rows = sum of Cout; max_row_floats = max k*k*Cin (<= 16384). */

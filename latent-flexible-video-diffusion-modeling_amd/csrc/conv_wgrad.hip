@@ -401,7 +401,46 @@ __global__ __launch_bounds__(256) void unpack_conv_grads_kernel(const lfvdm_unpa
     }
 }
 
+// Grouped weight packing for a training step: every job packs one OIHW weight into the forward operand layout
+// [Cout][tap][Cin] (transposed = 0) or the data-gradient layout [Cin][tap][Cout] with flipped taps (transposed = 1);
+// a workgroup handles 1024 consecutive output elements of one job.
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const lfvdm_pack_job* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                       // last job with blk0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const lfvdm_pack_job J = jobs[lo];
+    const size_t total = (size_t)J.Cout * J.Cin * J.taps;
+    const size_t i0 = (size_t)(blockIdx.x - J.blk0) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = i0 + 256 * k;
+        if (i >= total) break;
+        if (J.transposed) {
+            const int co = (int)(i % J.Cout);
+            const size_t t2 = i / J.Cout;
+            const int t = (int)(t2 % J.taps);
+            const int ci = (int)(t2 / J.taps);
+            J.dst[i] = J.src[((size_t)co * J.Cin + ci) * J.taps + (J.taps - 1 - t)];
+        } else {
+            const int ci = (int)(i % J.Cin);
+            const size_t t2 = i / J.Cin;
+            const int tap = (int)(t2 % J.taps);
+            const int co = (int)(t2 / J.taps);
+            J.dst[i] = J.src[((size_t)co * J.Cin + ci) * J.taps + tap];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int lfvdm_pack_conv_weights(const lfvdm_pack_job* jobs_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
 
 extern "C" int lfvdm_unpack_conv_grads(const lfvdm_unpack_job* jobs_dev, int njobs, int total_rows, int max_row_floats,
                                        void* stream) {

@@ -36,20 +36,72 @@ def _new(*shape, like):
 
 
 # ----------------------------------------------------------------------------- packed weights
+class _WeightPacks:
+    """Persistent packed copies of the conv weights of leaf parameters: forward layout [Cout][tap][Cin] and
+    data-gradient layout [Cin][tap][Cout] (flipped taps).  All of them are refreshed by ONE grouped launch the first
+    time any is requested after the parameters changed (optimizer step / load_state_dict) instead of two small
+    launches per convolution per step."""
+
+    def __init__(self):
+        self.ent = {}           # (data_ptr, shape, transposed) -> [source view, packed, stamp, transposed]
+        self.table = None
+
+    @staticmethod
+    def _stamp(w4):
+        base = w4._base if w4._base is not None else w4
+        return (nat.param_epoch[0], base._version)
+
+    def get(self, w4, transposed):
+        base = w4._base if w4._base is not None else w4
+        Cout, Cin, k, _ = w4.shape
+        if not isinstance(base, nn.Parameter) or not w4.is_contiguous():
+            out = _new(*((Cin, k * k, Cout) if transposed else (Cout, k * k, Cin)), like=w4)     # derived weight: pack now
+            (nat.pack_conv_weight_t if transposed else nat.pack_conv_weight)(w4.contiguous(), out)
+            return out
+        key = (w4.data_ptr(), tuple(w4.shape), bool(transposed))
+        e = self.ent.get(key)
+        if e is None:
+            out = _new(*((Cin, k * k, Cout) if transposed else (Cout, k * k, Cin)), like=w4)
+            (nat.pack_conv_weight_t if transposed else nat.pack_conv_weight)(w4, out)
+            self.ent[key] = [w4, out, self._stamp(w4), bool(transposed)]
+            self.table = None
+            return out
+        if e[2] != self._stamp(w4):
+            self.refresh_all()
+        return e[1]
+
+    def refresh_all(self):
+        ents = list(self.ent.values())
+        if self.table is None:
+            if th.cuda.is_current_stream_capturing():      # cannot upload a job table now: pack one by one
+                for w4, out, _, tr in ents:
+                    (nat.pack_conv_weight_t if tr else nat.pack_conv_weight)(w4, out)
+                for e in ents:
+                    e[2] = self._stamp(e[0])
+                return
+            jobs, blk = [], 0
+            for (ptr_, shape, tr), (w4, out, _, _tr) in self.ent.items():
+                Cout, Cin, k, _k = shape
+                jobs.append(nat.PackJob(w4.data_ptr(), out.data_ptr(), Cout, Cin, k * k, int(tr), blk, 0))
+                blk += (Cout * Cin * k * k + 1023) // 1024
+            self.table, self.blocks, self.njobs = nat.jobs_to_device(jobs, ents[0][1].device), blk, len(jobs)
+        nat.check(nat.lib().lfvdm_pack_conv_weights(self.table.data_ptr(), self.njobs, self.blocks, nat.stream()),
+                  "lfvdm_pack_conv_weights")
+        for e in ents:
+            e[2] = self._stamp(e[0])
+
+
+_packs = _WeightPacks()
+
+
 def _pack(w):
     """OIHW -> [Cout][taps][Cin] (forward operand layout)."""
-    Cout, Cin, k, _ = w.shape
-    out = _new(Cout, k * k, Cin, like=w)
-    nat.pack_conv_weight(w.contiguous(), out)
-    return out
+    return _packs.get(w, False)
 
 
 def _pack_t(w4):
     """OIHW (or [O][I] as [O][I][1][1]) -> [Cin][taps][Cout], taps flipped (data-gradient operand)."""
-    Cout, Cin, k, _ = w4.shape
-    out = _new(Cin, k * k, Cout, like=w4)
-    nat.pack_conv_weight_t(w4.contiguous(), out)
-    return out
+    return _packs.get(w4, True)
 
 
 def _grad_of(p):

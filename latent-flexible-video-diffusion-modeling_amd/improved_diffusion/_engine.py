@@ -387,6 +387,7 @@ class Engine:
     def invalidate(self):
         """Parameters were rewritten behind torch's back: repack the conv weights on next use."""
         self.epoch += 1
+        nat.param_epoch[0] += 1
 
     def forward(self, x, x0, timesteps, frame_indices, obs_mask, latent_mask, return_attn_weights=False):
         B, T, Cx, H, W = x.shape

@@ -50,6 +50,15 @@ class RowdotJob(C.Structure):
                 ("row0", C.c_int32), ("pad_", C.c_int32)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("src", c_fp), ("dst", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32),
+                ("transposed", C.c_int32), ("blk0", C.c_int32), ("pad_", C.c_int32)]
+
+
+# bumped by code that rewrites parameters through raw pointers (the fused AdamW): cached packed weights are stale
+param_epoch = [0]
+
+
 class UnpackJob(C.Structure):
     _fields_ = [("gp", c_fp), ("g", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("row0", C.c_int32)]
 
@@ -69,6 +78,7 @@ _SIGS = {
     "lfvdm_pack_conv_weight_t": ([c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_unpack_conv_grad": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_unpack_conv_grads": ([c_fp, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_pack_conv_weights": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_conv_in": ([c_fp] * 6 + [c_i] * 5 + [c_fp], c_i),
     "lfvdm_gn_coef": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp], c_i),
     "lfvdm_gn_coef_stats": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp, c_fp], c_i),

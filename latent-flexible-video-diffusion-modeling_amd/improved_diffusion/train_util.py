@@ -418,6 +418,7 @@ class TrainLoop:
             logger.logkv_mean("grad_norm", float(np.sqrt(self.grad_sqsum.item())))
 
     def _invalidate_engine(self):
+        nat.param_epoch[0] += 1          # cached packed weights (sampler plans, training path) are stale now
         eng = getattr(self.model, "_engine", None)
         if eng is not None:
             eng.invalidate()
