@@ -230,6 +230,15 @@ typedef struct lfvdm_rpe_job {
 int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, const int64_t* frame_indices_i64,
                    int B, int T, void* stream);
 
+/* Hidden layer of one RPENet for the training path (rpe.py:20-31 before the output layer) and its backward:
+ *   act[r][c] = silu(tproj[b][c] + Wd[c][0..2] . feats[r][0..2] + bd[c]),  rows r = (b, t, s), rows_per_b = T*T,
+ *   tproj = embed_diffusion_time(emb) [B][C], feats [B*T*T][3] (log1p(relu(d)), log1p(relu(-d)), d == 0).
+ * bwd: dtproj [B][C], dWd [C][3] and dbd [C] are ACCUMULATED with float atomics (dtproj must be zeroed). */
+int lfvdm_rpe_front(const float* tproj, const float* feats, const float* Wd, const float* bd, float* act, int B,
+                    int rows_per_b, int C, void* stream);
+int lfvdm_rpe_front_bwd(const float* tproj, const float* feats, const float* Wd, const float* bd, const float* d_act,
+                        float* dtproj, float* dWd, float* dbd, int B, int rows_per_b, int C, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Attention cores (rpe.py:143-169).  qkv rows are token-major [M][3C] with the reference's
  * channel order [3][heads][F]; o rows are [M][C].

@@ -439,6 +439,69 @@ void attn_temporal_bwd_rpe_kernel(const float* __restrict__ qkv, const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------ RPE net
+// Hidden layer of an RPENet in the training path (rpe.py:20-31 up to the output layer):
+//   act[r][c] = silu(tproj[b][c] + Wd[c][:] . feats[r][:] + bd[c]),  r = (b, t, s), feats = 3 distance features.
+__global__ __launch_bounds__(256) void rpe_front_fwd_kernel(const float* __restrict__ tproj, const float* __restrict__ feats,
+                                                            const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                            float* __restrict__ act, long rows, int rows_per_b, int C) {
+    const int Q = C / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * Q) return;
+    const long r = i / Q;
+    const int c = (int)(i - r * Q) * 4;
+    const int b = (int)(r / rows_per_b);
+    const float f0 = feats[r * 3 + 0], f1 = feats[r * 3 + 1], f2 = feats[r * 3 + 2];
+    const f32x4 tp = ld4(tproj + (size_t)b * C + c), bb = ld4(bd + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* w = Wd + (size_t)(c + k) * 3;
+        o[k] = silu_f(tp[k] + bb[k] + w[0] * f0 + w[1] * f1 + w[2] * f2);
+    }
+    st4(act + r * C + c, o);
+}
+
+// Backward: dhid = d_act * silu'(hid) (hid recomputed); dtproj[b][c] += sum_rows dhid, dWd[c][j] += sum dhid*feats[j],
+// dbd[c] += sum dhid.  grid (C/64, B, row chunks), block = 4 row lanes x 64 channels; float atomics for the sums.
+__global__ __launch_bounds__(256) void rpe_front_bwd_kernel(const float* __restrict__ tproj, const float* __restrict__ feats,
+                                                            const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                            const float* __restrict__ d_act, float* __restrict__ dtproj,
+                                                            float* __restrict__ dWd, float* __restrict__ dbd, int rows_per_b,
+                                                            int C, int chunk) {
+    __shared__ float red[4][64][4];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.z * chunk;
+    const int r1 = min(r0 + chunk, rows_per_b);
+    float s = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        const float tp = tproj[(size_t)b * C + c] + bd[c];
+        const float w0 = Wd[(size_t)c * 3], w1 = Wd[(size_t)c * 3 + 1], w2 = Wd[(size_t)c * 3 + 2];
+        for (int rr = r0 + rl; rr < r1; rr += 4) {
+            const size_t r = (size_t)b * rows_per_b + rr;
+            const float f0 = feats[r * 3], f1 = feats[r * 3 + 1], f2 = feats[r * 3 + 2];
+            const float h = tp + w0 * f0 + w1 * f1 + w2 * f2;
+            const float sg = 1.0f / (1.0f + __expf(-h));
+            const float d = d_act[r * C + c] * sg * (1.0f + h * (1.0f - sg));
+            s += d; s0 += d * f0; s1 += d * f1; s2 += d * f2;
+        }
+    }
+    red[rl][cl][0] = s; red[rl][cl][1] = s0; red[rl][cl][2] = s1; red[rl][cl][3] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = red[0][cl][k] + red[1][cl][k] + red[2][cl][k] + red[3][cl][k];
+        atomicAdd(dtproj + (size_t)b * C + c, t[0]);
+        atomicAdd(dbd + c, t[0]);
+        atomicAdd(dWd + (size_t)c * 3 + 0, t[1]);
+        atomicAdd(dWd + (size_t)c * 3 + 1, t[2]);
+        atomicAdd(dWd + (size_t)c * 3 + 2, t[3]);
+    }
+}
+
 template <int TMAX, int FC>
 int launch_tb(const float* qkv, const float* d_o, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* Pg,
               float* dSg, float* dqkv, int B, int T, int P, int C, int heads, hipStream_t s) {
@@ -495,6 +558,28 @@ extern "C" int lfvdm_attn_temporal_bwd(const float* qkv, const float* d_o, const
     if (rc != LFVDM_OK) return rc;
     hipLaunchKernelGGL(attn_temporal_bwd_rpe_kernel, dim3((unsigned)T, (unsigned)heads, (unsigned)B), dim3(256), 0, s, qkv, d_o,
                        ws_p, ws_ds, dRq, dRk, dRv, T, P, C, heads);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_rpe_front(const float* tproj, const float* feats, const float* Wd, const float* bd, float* act, int B,
+                               int rows_per_b, int C, void* stream) {
+    if (!tproj || !feats || !Wd || !bd || !act || B <= 0 || rows_per_b <= 0 || C <= 0 || C % 4) return LFVDM_E_SHAPE;
+    const long rows = (long)B * rows_per_b;
+    const long n = rows * (C / 4);
+    hipLaunchKernelGGL(rpe_front_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tproj, feats, Wd,
+                       bd, act, rows, rows_per_b, C);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_rpe_front_bwd(const float* tproj, const float* feats, const float* Wd, const float* bd, const float* d_act,
+                                   float* dtproj, float* dWd, float* dbd, int B, int rows_per_b, int C, void* stream) {
+    if (!tproj || !feats || !Wd || !bd || !d_act || !dtproj || !dWd || !dbd || B <= 0 || rows_per_b <= 0 || C <= 0)
+        return LFVDM_E_SHAPE;
+    const int chunk = 32;
+    hipLaunchKernelGGL(rpe_front_bwd_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B, (unsigned)((rows_per_b + chunk - 1) / chunk)),
+                       dim3(256), 0, (hipStream_t)stream, tproj, feats, Wd, bd, d_act, dtproj, dWd, dbd, rows_per_b, C, chunk);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

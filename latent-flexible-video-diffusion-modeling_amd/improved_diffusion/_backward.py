@@ -531,15 +531,49 @@ class SpatialAttnFn(th.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- whole network
-def _rpe_R(net, temb_b, rel, B, T):
+def _rpe_feats(rel):
+    """Distance features of rpe.py:22-27, shared by all RPE networks of a forward pass."""
+    relf = rel.to(th.float32)
+    return th.stack([th.log1p(relf.clamp(min=0)), th.log1p((-relf).clamp(min=0)), (rel == 0).to(th.float32)], dim=-1).contiguous()
+
+
+class RpeFrontFn(th.autograd.Function):
+    """act = silu(tproj[b] + embed_distances(feats)) on rows (b, t, s): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, tproj, feats, wd, bd, B, TT):
+        C = tproj.shape[1]
+        tproj = tproj.contiguous()
+        act = _new(B * TT, C, like=tproj)
+        nat.check(nat.lib().lfvdm_rpe_front(nat.ptr(tproj), nat.ptr(feats), nat.ptr(wd), nat.ptr(bd), nat.ptr(act), B, TT, C,
+                                            nat.stream()), "lfvdm_rpe_front")
+        ctx.save_for_backward(tproj, feats, wd, bd)
+        ctx.geom = (B, TT, C)
+        return act
+
+    @staticmethod
+    def backward(ctx, d_act):
+        tproj, feats, wd, bd = ctx.saved_tensors
+        B, TT, C = ctx.geom
+        leaf = wd.is_leaf and bd.is_leaf
+        dtproj = th.zeros(B, C, device=tproj.device, dtype=th.float32)
+        dwd = _grad_of(wd) if leaf else th.zeros_like(wd)
+        dbd = _grad_of(bd) if leaf else th.zeros_like(bd)
+        nat.check(nat.lib().lfvdm_rpe_front_bwd(nat.ptr(tproj), nat.ptr(feats), nat.ptr(wd), nat.ptr(bd),
+                                                nat.ptr(d_act.contiguous()), nat.ptr(dtproj), nat.ptr(dwd), nat.ptr(dbd), B, TT, C,
+                                                nat.stream()), "lfvdm_rpe_front_bwd")
+        return dtproj, None, (None if leaf else dwd), (None if leaf else dbd), None, None
+
+
+def _rpe_R(net, temb_b, feats, B, T):
     """RPENet (rpe.py:20-31) on device: the 3-feature / time-embedding projections are tiny library ops, the
     C x C output layer runs on the HIP GEMM kernels."""
-    relf = rel.to(th.float32)
-    feats = th.stack([th.log1p(relf.clamp(min=0)), th.log1p((-relf).clamp(min=0)), (rel == 0).to(th.float32)], dim=-1)
+    C = net.out.weight.shape[0]
+    if C % 32 == 0:   # hidden layer fused in one launch; C x C output layer on the GEMM / wgrad kernels (rows = B*T*T)
+        act = RpeFrontFn.apply(net.embed_diffusion_time(temb_b), feats.view(B * T * T, 3), net.embed_distances.weight,
+                               net.embed_distances.bias, B, T * T)
+        return LinearFn.apply(act, net.out.weight, net.out.bias, None).view(B, T, T, C)
     hid = net.embed_diffusion_time(temb_b).view(B, 1, 1, -1) + net.embed_distances(feats)
-    C = hid.shape[-1]
-    if C % 32 == 0:   # the C x C output layer on the implicit-GEMM / wgrad kernels (rows = B*T*T)
-        return LinearFn.apply(F.silu(hid).reshape(B * T * T, C), net.out.weight, net.out.bias, None).view(B, T, T, C)
     return net.out(F.silu(hid)).contiguous()       # B, T, T, C
 
 
@@ -565,7 +599,7 @@ class UNetFunction:
         temb = th.cat([th.cos(args), th.sin(args)], dim=-1)
         emb = m.time_embed[2](F.silu(m.time_embed[0](temb)))            # (B, 4ch)
         semb = F.silu(emb)
-        rel = frame_indices.unsqueeze(-1) - frame_indices.unsqueeze(-2)
+        feats = _rpe_feats(frame_indices.unsqueeze(-1) - frame_indices.unsqueeze(-2))
         # --- input compositing + first conv (reference unet.py:441-450): 5 -> 32 zero-padded channels
         comp = th.cat([x * (1 - obs) + x0 * obs, th.ones_like(x[:, :, :1]) * obs], dim=2)
         rows = th.zeros(N * H * W, 32, device=x.device, dtype=th.float32)
@@ -591,7 +625,7 @@ class UNetFunction:
                     b = None
                 elif isinstance(layer, FactorizedAttentionBlock):
                     ta, sa = layer.temporal_attention, layer.spatial_attention
-                    R = [_rpe_R(r.rpe_net, emb, rel, B, T) for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v)]
+                    R = [_rpe_R(r.rpe_net, emb, feats, B, T) for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v)]
                     h = TemporalAttnFn.apply(h, ta.norm.weight, ta.norm.bias, ta.qkv.weight, ta.qkv.bias, ta.proj_out.weight,
                                              ta.proj_out.bias, R[0], R[1], R[2], mask, B, T, Hc * Wc, layer.num_heads)
                     h = SpatialAttnFn.apply(h, sa.norm.weight, sa.norm.bias, sa.qkv.weight, sa.qkv.bias, sa.proj_out.weight,
