@@ -178,9 +178,10 @@ int lfvdm_gn_bwd_apply(const float* da, const float* src0, const float* src1, in
                        const float* coefA, const float* coefB, const float* stats, const float* sums, int act,
                        float* out0, float* out1, int acc0, int acc1, void* stream);
 /* GroupNorm(+FiLM) parameter gradients from the sums of lfvdm_gn_bwd_stats: dgamma / dbeta [C] are ACCUMULATED
- * (+=, fixed order), dfilm [N/T][2C] (d scale | d shift of unet.py:199-203) is written when film != NULL. */
-int lfvdm_gn_param_grads(const float* sums, const float* gamma, const float* beta, const float* film, int T,
-                         float* dgamma, float* dbeta, float* dfilm, int N, int C, void* stream);
+ * (+=, fixed order), dfilm [N/T][2C] (d scale | d shift of unet.py:199-203; row strides film_ld / dfilm_ld) is
+ * written when film != NULL. */
+int lfvdm_gn_param_grads(const float* sums, const float* gamma, const float* beta, const float* film, int film_ld, int T,
+                         float* dgamma, float* dbeta, float* dfilm, int dfilm_ld, int N, int C, void* stream);
 /* Temporal GroupNorm backward: dx from dy; dgamma/dbeta [C] are ACCUMULATED with float atomics. */
 int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* dgamma,
                           float* dbeta, int B, int T, int P, int C, int accumulate, void* stream);
@@ -211,6 +212,21 @@ typedef struct lfvdm_rowdot_job {
 
 int lfvdm_rowdot(const lfvdm_rowdot_job* jobs_dev, int njobs, int total_rows, void* stream);
 
+/* Backward of the same grouped linears (autograd of nn.Linear, train_util.py:328): per job
+ *   dW[o][k] += sum_m dout[m][o] * actin(in[m][k]);  db[o] += sum_m dout[m][o]   (single writer, plain +=)
+ *   din[m][k] += sum_o dout[m][o] * W[o][k]   (gradient w.r.t. the ACTIVATED input, float atomics; NULL = skip)
+ * One wave per 32 output rows: task0 = first task of the job (prefix sum of ceil(O/32)), K % 4 == 0. */
+typedef struct lfvdm_rowdot_bwd_job {
+    const float* W;    /* [O][K] */
+    const float* in;   /* as in the forward job */
+    const float* dout; /* [M][lddout] */
+    float* dW;         /* [O][K] accumulated */
+    float* db;         /* [O] accumulated, or NULL */
+    float* din;        /* [M][lddin] accumulated, or NULL */
+    int32_t K, O, M, ldin, lddout, lddin, in_mode, task0;
+} lfvdm_rowdot_bwd_job;
+int lfvdm_rowdot_bwd(const lfvdm_rowdot_bwd_job* jobs_dev, int njobs, int total_tasks, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * All RPENet output projections of one forward in one launch (rpe.py:20-31):
  *   R[b,t,s,:] = Wout * SiLU(tproj[b,:] + Wd * feats(fi[b,t]-fi[b,s]) + bd) + bout
@@ -233,11 +249,13 @@ int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, co
 /* Hidden layer of one RPENet for the training path (rpe.py:20-31 before the output layer) and its backward:
  *   act[r][c] = silu(tproj[b][c] + Wd[c][0..2] . feats[r][0..2] + bd[c]),  rows r = (b, t, s), rows_per_b = T*T,
  *   tproj = embed_diffusion_time(emb) [B][C], feats [B*T*T][3] (log1p(relu(d)), log1p(relu(-d)), d == 0).
+ * tproj / dtproj have row strides tproj_ld / dtproj_ld.
  * bwd: dtproj [B][C], dWd [C][3] and dbd [C] are ACCUMULATED with float atomics (dtproj must be zeroed). */
-int lfvdm_rpe_front(const float* tproj, const float* feats, const float* Wd, const float* bd, float* act, int B,
+int lfvdm_rpe_front(const float* tproj, int tproj_ld, const float* feats, const float* Wd, const float* bd, float* act, int B,
                     int rows_per_b, int C, void* stream);
-int lfvdm_rpe_front_bwd(const float* tproj, const float* feats, const float* Wd, const float* bd, const float* d_act,
-                        float* dtproj, float* dWd, float* dbd, int B, int rows_per_b, int C, void* stream);
+int lfvdm_rpe_front_bwd(const float* tproj, int tproj_ld, const float* feats, const float* Wd, const float* bd,
+                        const float* d_act, float* dtproj, int dtproj_ld, float* dWd, float* dbd, int B, int rows_per_b,
+                        int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Attention cores (rpe.py:143-169).  qkv rows are token-major [M][3C] with the reference's

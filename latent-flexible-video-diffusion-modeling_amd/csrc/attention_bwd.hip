@@ -442,7 +442,7 @@ void attn_temporal_bwd_rpe_kernel(const float* __restrict__ qkv, const float* __
 // ------------------------------------------------------------------------------------------------ RPE net
 // Hidden layer of an RPENet in the training path (rpe.py:20-31 up to the output layer):
 //   act[r][c] = silu(tproj[b][c] + Wd[c][:] . feats[r][:] + bd[c]),  r = (b, t, s), feats = 3 distance features.
-__global__ __launch_bounds__(256) void rpe_front_fwd_kernel(const float* __restrict__ tproj, const float* __restrict__ feats,
+__global__ __launch_bounds__(256) void rpe_front_fwd_kernel(const float* __restrict__ tproj, int tld, const float* __restrict__ feats,
                                                             const float* __restrict__ Wd, const float* __restrict__ bd,
                                                             float* __restrict__ act, long rows, int rows_per_b, int C) {
     const int Q = C / 4;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void rpe_front_fwd_kernel(const float* __restr
     const int c = (int)(i - r * Q) * 4;
     const int b = (int)(r / rows_per_b);
     const float f0 = feats[r * 3 + 0], f1 = feats[r * 3 + 1], f2 = feats[r * 3 + 2];
-    const f32x4 tp = ld4(tproj + (size_t)b * C + c), bb = ld4(bd + c);
+    const f32x4 tp = ld4(tproj + (size_t)b * tld + c), bb = ld4(bd + c);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -464,9 +464,9 @@ __global__ __launch_bounds__(256) void rpe_front_fwd_kernel(const float* __restr
 
 // Backward: dhid = d_act * silu'(hid) (hid recomputed); dtproj[b][c] += sum_rows dhid, dWd[c][j] += sum dhid*feats[j],
 // dbd[c] += sum dhid.  grid (C/64, B, row chunks), block = 4 row lanes x 64 channels; float atomics for the sums.
-__global__ __launch_bounds__(256) void rpe_front_bwd_kernel(const float* __restrict__ tproj, const float* __restrict__ feats,
+__global__ __launch_bounds__(256) void rpe_front_bwd_kernel(const float* __restrict__ tproj, int tld, const float* __restrict__ feats,
                                                             const float* __restrict__ Wd, const float* __restrict__ bd,
-                                                            const float* __restrict__ d_act, float* __restrict__ dtproj,
+                                                            const float* __restrict__ d_act, float* __restrict__ dtproj, int dtld,
                                                             float* __restrict__ dWd, float* __restrict__ dbd, int rows_per_b,
                                                             int C, int chunk) {
     __shared__ float red[4][64][4];
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void rpe_front_bwd_kernel(const float* __restr
     const int r1 = min(r0 + chunk, rows_per_b);
     float s = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if (c < C) {
-        const float tp = tproj[(size_t)b * C + c] + bd[c];
+        const float tp = tproj[(size_t)b * tld + c] + bd[c];
         const float w0 = Wd[(size_t)c * 3], w1 = Wd[(size_t)c * 3 + 1], w2 = Wd[(size_t)c * 3 + 2];
         for (int rr = r0 + rl; rr < r1; rr += 4) {
             const size_t r = (size_t)b * rows_per_b + rr;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void rpe_front_bwd_kernel(const float* __restr
         float t[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] = red[0][cl][k] + red[1][cl][k] + red[2][cl][k] + red[3][cl][k];
-        atomicAdd(dtproj + (size_t)b * C + c, t[0]);
+        atomicAdd(dtproj + (size_t)b * dtld + c, t[0]);
         atomicAdd(dbd + c, t[0]);
         atomicAdd(dWd + (size_t)c * 3 + 0, t[1]);
         atomicAdd(dWd + (size_t)c * 3 + 1, t[2]);
@@ -562,24 +562,28 @@ extern "C" int lfvdm_attn_temporal_bwd(const float* qkv, const float* d_o, const
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_rpe_front(const float* tproj, const float* feats, const float* Wd, const float* bd, float* act, int B,
-                               int rows_per_b, int C, void* stream) {
-    if (!tproj || !feats || !Wd || !bd || !act || B <= 0 || rows_per_b <= 0 || C <= 0 || C % 4) return LFVDM_E_SHAPE;
+extern "C" int lfvdm_rpe_front(const float* tproj, int tproj_ld, const float* feats, const float* Wd, const float* bd, float* act,
+                               int B, int rows_per_b, int C, void* stream) {
+    if (!tproj || !feats || !Wd || !bd || !act || B <= 0 || rows_per_b <= 0 || C <= 0 || C % 4 || tproj_ld < C || tproj_ld % 4)
+        return LFVDM_E_SHAPE;
     const long rows = (long)B * rows_per_b;
     const long n = rows * (C / 4);
-    hipLaunchKernelGGL(rpe_front_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tproj, feats, Wd,
-                       bd, act, rows, rows_per_b, C);
+    hipLaunchKernelGGL(rpe_front_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tproj, tproj_ld, feats,
+                       Wd, bd, act, rows, rows_per_b, C);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_rpe_front_bwd(const float* tproj, const float* feats, const float* Wd, const float* bd, const float* d_act,
-                                   float* dtproj, float* dWd, float* dbd, int B, int rows_per_b, int C, void* stream) {
-    if (!tproj || !feats || !Wd || !bd || !d_act || !dtproj || !dWd || !dbd || B <= 0 || rows_per_b <= 0 || C <= 0)
+extern "C" int lfvdm_rpe_front_bwd(const float* tproj, int tproj_ld, const float* feats, const float* Wd, const float* bd,
+                                   const float* d_act, float* dtproj, int dtproj_ld, float* dWd, float* dbd, int B,
+                                   int rows_per_b, int C, void* stream) {
+    if (!tproj || !feats || !Wd || !bd || !d_act || !dtproj || !dWd || !dbd || B <= 0 || rows_per_b <= 0 || C <= 0 ||
+        tproj_ld < C || dtproj_ld < C)
         return LFVDM_E_SHAPE;
     const int chunk = 32;
     hipLaunchKernelGGL(rpe_front_bwd_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B, (unsigned)((rows_per_b + chunk - 1) / chunk)),
-                       dim3(256), 0, (hipStream_t)stream, tproj, feats, Wd, bd, d_act, dtproj, dWd, dbd, rows_per_b, C, chunk);
+                       dim3(256), 0, (hipStream_t)stream, tproj, tproj_ld, feats, Wd, bd, d_act, dtproj, dtproj_ld, dWd, dbd, rows_per_b, C,
+                       chunk);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

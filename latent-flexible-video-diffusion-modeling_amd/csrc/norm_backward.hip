@@ -243,8 +243,9 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
 //   dfilm[b][c] = sum_t (s2 * gamma[c] + s1 * beta[c]);  dfilm[b][C + c] = sum_t s1        (FiLM only)
 __global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ film,
-                                                             int T, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ dfilm, int N, int C) {
+                                                             int film_ld, int T, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dfilm, int dfilm_ld,
+                                                             int N, int C) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float dg = 0.f, db = 0.f;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __rest
         const float g = gamma[c], be = beta[c];
         const int B = N / T;
         for (int b = 0; b < B; ++b) {
-            const float sc1 = 1.0f + film[(size_t)b * 2 * C + c];
+            const float sc1 = 1.0f + film[(size_t)b * film_ld + c];
             float dsc = 0.f, dsh = 0.f;
             for (int t = 0; t < T; ++t) {
                 const float* s = sums + ((size_t)(b * T + t) * C + c) * 2;
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __rest
                 dsc += s2 * g + s1 * be;
                 dsh += s1;
             }
-            dfilm[(size_t)b * 2 * C + c] = dsc;
-            dfilm[(size_t)b * 2 * C + C + c] = dsh;
+            dfilm[(size_t)b * dfilm_ld + c] = dsc;
+            dfilm[(size_t)b * dfilm_ld + C + c] = dsh;
         }
     } else {
         for (int n = 0; n < N; ++n) {
@@ -311,12 +312,12 @@ extern "C" int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const floa
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_gn_param_grads(const float* sums, const float* gamma, const float* beta, const float* film, int T,
-                                    float* dgamma, float* dbeta, float* dfilm, int N, int C, void* stream) {
+extern "C" int lfvdm_gn_param_grads(const float* sums, const float* gamma, const float* beta, const float* film, int film_ld,
+                                    int T, float* dgamma, float* dbeta, float* dfilm, int dfilm_ld, int N, int C, void* stream) {
     if (!sums || !dgamma || !dbeta || N <= 0 || C <= 0) return LFVDM_E_SHAPE;
-    if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T)) return LFVDM_E_SHAPE;
-    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, film, T,
-                       dgamma, dbeta, dfilm, N, C);
+    if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T || film_ld < 2 * C || dfilm_ld < 2 * C)) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, film,
+                       film_ld, T, dgamma, dbeta, dfilm, dfilm_ld, N, C);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -273,7 +273,87 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const lfvdm_rowdot_job* __r
     }
 }
 
+// Backward of the grouped small-M linears: one wave per block of 32 output rows of one job.
+//   dW[o][k] += sum_m dout[m][o] * actin(in[m][k]);  db[o] += sum_m dout[m][o];
+//   din[m][k] += sum_o dout[m][o] * W[o][k]        (gradient w.r.t. the ACTIVATED input; float atomics, may be NULL)
+// Every W row is read once; the din partial of the 32 rows lives in registers and is added once per wave.
+constexpr int RDB_ROWS = 32;
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_job* __restrict__ jobs, int njobs, int total_tasks) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= total_tasks) return;
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].task0 <= task) ++j;
+    const lfvdm_rowdot_bwd_job J = jobs[j];
+    const int o0 = (task - J.task0) * RDB_ROWS;
+    const int o1 = min(o0 + RDB_ROWS, J.O);
+    for (int m0 = 0; m0 < J.M; m0 += 4) {
+        const int mc = min(4, J.M - m0);
+        for (int k = lane * 4; k < J.K; k += 256) {
+            f32x4 inv[4], accD[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                accD[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                inv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (i < mc) {
+                    if (J.in_mode == 2) {
+                        const float t = J.in[m0 + i];
+                        const float* fr = J.in + J.ldin;
+                        const int half = J.K >> 1;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int kk = k + u;
+                            inv[i][u] = kk < half ? cosf(t * fr[kk]) : sinf(t * fr[kk - half]);
+                        }
+                    } else {
+                        f32x4 v = ld4(J.in + (size_t)(m0 + i) * J.ldin + k);
+                        if (J.in_mode == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                        inv[i] = v;
+                    }
+                }
+            }
+            for (int o = o0; o < o1; ++o) {
+                const f32x4 wv = ld4(J.W + (size_t)o * J.K + k);
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < mc) {
+                        const float d = J.dout[(size_t)(m0 + i) * J.lddout + o];
+                        g += inv[i] * d;
+                        accD[i] += wv * d;
+                    }
+                }
+                float* gw = J.dW + (size_t)o * J.K + k;
+                st4(gw, ld4(gw) + g);
+            }
+            if (J.din) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < mc) {
+                        float* dst = J.din + (size_t)(m0 + i) * J.lddin + k;
+                        atomicAdd(dst + 0, accD[i].x); atomicAdd(dst + 1, accD[i].y);
+                        atomicAdd(dst + 2, accD[i].z); atomicAdd(dst + 3, accD[i].w);
+                    }
+                }
+            }
+        }
+    }
+    if (J.db && lane < o1 - o0) {
+        float t = 0.f;
+        for (int m = 0; m < J.M; ++m) t += J.dout[(size_t)m * J.lddout + o0 + lane];
+        J.db[o0 + lane] += t;
+    }
+}
+
 }  // namespace
+
+extern "C" int lfvdm_rowdot_bwd(const lfvdm_rowdot_bwd_job* jobs_dev, int njobs, int total_tasks, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_tasks <= 0) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((total_tasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs,
+                       total_tasks);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
 
 extern "C" int lfvdm_gn_coef_stats(const float* src0, const float* src1, int C0, int C1, int N, int P, const float* gamma,
                                    const float* beta, const float* film, int film_div, int film_ld, float eps,

@@ -273,12 +273,13 @@ def _gn_forward(a, b, C0, C1, N, P, gamma, beta, film, T):
     C = C0 + C1
     cA, cB, stats = _new(N, C, like=a), _new(N, C, like=a), _new(N, 32, 2, like=a)
     nat.check(nat.lib().lfvdm_gn_coef_stats(
-        nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(gamma), nat.ptr(beta), nat.ptr(film), T if film is not None else 1,
-        (2 * C) if film is not None else 0, _EPS, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats), nat.stream()), "lfvdm_gn_coef_stats")
+        nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(gamma), nat.ptr(beta), film.data_ptr() if film is not None else None,
+        T if film is not None else 1, film.stride(0) if film is not None else 0, _EPS, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
+        nat.stream()), "lfvdm_gn_coef_stats")
     return cA, cB, stats
 
 
-def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, T, want_dx=(True, True)):
+def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, T, want_dx=(True, True), dfilm_out=None):
     """Returns (dx_a, dx_b, dgamma, dbeta, dfilm).  da: [N*P][C] gradient w.r.t. act(GN(x))."""
     C = C0 + C1
     sums = _new(N, C, 2, like=da)
@@ -291,12 +292,17 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
                                    nat.ptr(sums), act, nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.stream()), "lfvdm_gn_bwd_apply")
     if gamma.is_leaf and beta.is_leaf:
         # parameter gradients accumulated in place by one small kernel (no reductions / AccumulateGrad adds)
-        dfilm = _new(N // T, 2 * C, like=da) if film is not None else None
-        nat.check(L.lfvdm_gn_param_grads(nat.ptr(sums), nat.ptr(gamma), nat.ptr(beta), nat.ptr(film), T,
-                                         nat.ptr(_grad_of(gamma)), nat.ptr(_grad_of(beta)), nat.ptr(dfilm), N, C,
-                                         nat.stream()), "lfvdm_gn_param_grads")
-        return dxa, dxb, None, None, dfilm
+        dfilm = None
+        if film is not None:       # written into the caller's slot (the embedding network's gradient buffer) if given
+            dfilm = dfilm_out if dfilm_out is not None else _new(N // T, 2 * C, like=da)
+        nat.check(L.lfvdm_gn_param_grads(nat.ptr(sums), nat.ptr(gamma), nat.ptr(beta),
+                                         film.data_ptr() if film is not None else None, film.stride(0) if film is not None else 0,
+                                         T, nat.ptr(_grad_of(gamma)), nat.ptr(_grad_of(beta)),
+                                         dfilm.data_ptr() if dfilm is not None else None,
+                                         dfilm.stride(0) if dfilm is not None else 0, N, C, nat.stream()), "lfvdm_gn_param_grads")
+        return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
     s1, s2 = sums[..., 0], sums[..., 1]              # [N][C]: sum dz, sum dz*xhat
+    assert dfilm_out is None, "gradient slots need leaf GroupNorm parameters"
     if film is not None:
         B = N // T
         sc1 = 1.0 + film[:, :C].repeat_interleave(T, dim=0)   # (1 + scale) per (n, c)
@@ -315,7 +321,7 @@ class ResBlockFn(th.autograd.Function):
     """reference unet.py:194-207 with use_scale_shift_norm=True, on a virtual concat input (a | b)."""
 
     @staticmethod
-    def forward(ctx, a, b, film, g1, be1, w1, b1, g2, be2, w2, b2, ws, bs, N, H, W, T):
+    def forward(ctx, a, b, film, g1, be1, w1, b1, g2, be2, w2, b2, ws, bs, N, H, W, T, dfilm_slot=None):
         C0 = a.shape[1]
         C1 = b.shape[1] if b is not None else 0
         Cin, Cout, P = C0 + C1, w1.shape[0], H * W
@@ -334,6 +340,7 @@ class ResBlockFn(th.autograd.Function):
         nat.conv_igemm(**kw)
         ctx.save_for_backward(a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2)
         ctx.params = (w1, b1, w2, b2, ws, bs)
+        ctx.dfilm_slot = dfilm_slot
         ctx.geom = (N, H, W, T, C0, C1, Cout)
         return out
 
@@ -350,7 +357,10 @@ class ResBlockFn(th.autograd.Function):
         dw2 = db2 = None
         da2 = _new(N * P, Cout, like=a)
         nat.conv_igemm(src0=dout, C0=Cout, W=_pack_t(w2), Cout=Cout, out=da2, ldo=Cout, **geo)
-        dh1, _, dg2, dbe2, dfilm = _gn_backward(da2, h1, None, Cout, 0, N, P, cA2, cB2, st2, nat.ACT_SILU, g2, be2, film, T)
+        if ctx.dfilm_slot is not None:
+            _embed.ensure_backward_queued()
+        dh1, _, dg2, dbe2, dfilm = _gn_backward(da2, h1, None, Cout, 0, N, P, cA2, cB2, st2, nat.ACT_SILU, g2, be2, film, T,
+                                                dfilm_out=ctx.dfilm_slot)
         # conv1
         _wgrad_accumulate(pw1, pb1, src0=a, src1=b, C0=C0, C1=C1, coefA=cA1, coefB=cB1, act=nat.ACT_SILU, res=dh1,
                           ldr=Cout, **geo)
@@ -369,7 +379,7 @@ class ResBlockFn(th.autograd.Function):
             dxa = dxa + dsk[:, :C0]
             if dxb is not None:
                 dxb = dxb + dsk[:, C0:]
-        return (dxa, dxb, dfilm, dg1, dbe1, dw1, db1, dg2, dbe2, dw2, db2, dws, dbs, None, None, None, None)
+        return (dxa, dxb, dfilm, dg1, dbe1, dw1, db1, dg2, dbe2, dw2, db2, dws, dbs, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------- output head
@@ -530,6 +540,116 @@ class SpatialAttnFn(th.autograd.Function):
         return dx, dg, db, dwq, dbq, dwp, dbp, None, None, None
 
 
+# ----------------------------------------------------------------------------- embedding network
+class _EmbedNet:
+    """Everything that depends on the diffusion timestep only - sinusoid, time_embed MLP (unet.py:303-308), the
+    FiLM projection of every ResBlock (unet.py:157-163) and embed_diffusion_time of every RPE network
+    (rpe.py:29) - as THREE grouped launches forward and three backward, differentiated by hand outside the
+    autograd tape.  Consumers (ResBlockFn / RpeFrontFn) read strided views of one flat output buffer and write the
+    gradients of those views into the matching slots of one flat gradient buffer; the backward runs once, as an
+    end-of-backward callback, and accumulates straight into the parameters' ``.grad``."""
+
+    def __init__(self):
+        self.state = None
+        self.queued = False
+
+    def _build(self, m, B, dev):
+        from .unet import ResBlock, FactorizedAttentionBlock
+        ch = m.model_channels
+        ted = 4 * ch
+        half = ch // 2
+        Bp = (B + 3) // 4 * 4
+        lin0, lin1 = m.time_embed[0], m.time_embed[2]
+        heads = []         # (module key, weight, bias, in_mode)
+        for blk in list(m.input_blocks) + [m.middle_block] + list(m.output_blocks):
+            for layer in blk:
+                if isinstance(layer, ResBlock):
+                    heads.append((layer, layer.emb_layers[1].weight, layer.emb_layers[1].bias, 1))
+                elif isinstance(layer, FactorizedAttentionBlock):
+                    ta = layer.temporal_attention
+                    for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v):
+                        lin = r.rpe_net.embed_diffusion_time
+                        heads.append((r.rpe_net, lin.weight, lin.bias, 0))
+        params = [lin0.weight, lin0.bias, lin1.weight, lin1.bias] + [t for _, w, b, _ in heads for t in (w, b)]
+        if not all(p.is_leaf for p in params):
+            return None
+        total = sum(w.shape[0] for _, w, _, _ in heads)
+        z = lambda *shape: th.zeros(*shape, device=dev, dtype=th.float32)
+        st = dict(B=B, dev=dev, params=params, tin=z(Bp + half), h0=z(B, ted), emb=z(B, ted), flat=z(B, total),
+                  grads=z(B, total + 3 * ted), total=total, ted=ted)
+        st["tin"][Bp:] = timestep_freqs(ch).to(dev)
+        g = st["grads"]
+        st["dflat"], st["demb_act"], st["demb_raw"], st["dh0_act"] = (
+            g[:, :total], g[:, total:total + ted], g[:, total + ted:total + 2 * ted], g[:, total + 2 * ted:])
+        ld = g.stride(0)
+        P = lambda t: t.data_ptr()
+        G = lambda p: _grad_of(p).data_ptr()
+        fwd0 = [nat.RowdotJob(P(lin0.weight), P(lin0.bias), P(st["tin"]), P(st["h0"]), ch, ted, B, Bp, ted, 2, 0, 0)]
+        fwd1 = [nat.RowdotJob(P(lin1.weight), P(lin1.bias), P(st["h0"]), P(st["emb"]), ted, ted, B, ted, ted, 1, 0, 0)]
+        fwdg, bwdg, views, off, task0 = [], [], {}, 0, 0
+        for key, w, b, mode in heads:
+            O = w.shape[0]
+            fwdg.append(nat.RowdotJob(P(w), P(b), P(st["emb"]), P(st["flat"]) + 4 * off, ted, O, B, ted, total, mode, off, 0))
+            din = st["demb_act"] if mode == 1 else st["demb_raw"]
+            bwdg.append(nat.RowdotBwdJob(P(w), P(st["emb"]), P(st["dflat"]) + 4 * off, G(w), G(b), P(din), ted, O, B, ted, ld, ld,
+                                         mode, task0))
+            views[key] = (st["flat"][:, off:off + O], st["dflat"][:, off:off + O])
+            off += O
+            task0 += (O + 31) // 32
+        st["demb"] = z(B, ted)
+        st["dh0"] = z(B, ted)
+        bwd1 = [nat.RowdotBwdJob(P(lin1.weight), P(st["h0"]), P(st["demb"]), G(lin1.weight), G(lin1.bias), P(st["dh0_act"]), ted,
+                                 ted, B, ted, ted, ld, 1, 0)]
+        bwd0 = [nat.RowdotBwdJob(P(lin0.weight), P(st["tin"]), P(st["dh0"]), G(lin0.weight), G(lin0.bias), None, ch, ted, B, Bp,
+                                 ted, 0, 2, 0)]
+        J = lambda jobs: nat.jobs_to_device(jobs, dev)
+        st.update(views=views, j_f0=J(fwd0), j_f1=J(fwd1), j_fg=J(fwdg), n_g=len(fwdg), j_bg=J(bwdg), tasks_g=task0, j_b1=J(bwd1),
+                  j_b0=J(bwd0), tasks_t=(ted + 31) // 32,
+                  key=(id(m), B, str(dev), tuple(p.data_ptr() for p in params), tuple(_grad_of(p).data_ptr() for p in params)))
+        return st
+
+    def forward(self, m, timesteps, B, dev):
+        """-> {module: (output view, gradient slot)} or None if the grouped path does not apply."""
+        st = self.state
+        if st is not None:
+            ps = st["params"]
+            if st["key"] != (id(m), B, str(dev), tuple(p.data_ptr() for p in ps),
+                             tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in ps)):
+                st = None
+        if st is None:
+            if th.cuda.is_current_stream_capturing():
+                return None             # job tables cannot be uploaded now: per-layer path
+            st = self.state = self._build(m, B, dev)
+            if st is None:
+                return None
+        L, s = nat.lib(), nat.stream()
+        st["tin"][:B].copy_(timesteps)
+        st["grads"].zero_()
+        nat.check(L.lfvdm_rowdot(st["j_f0"].data_ptr(), 1, st["ted"], s), "lfvdm_rowdot")
+        nat.check(L.lfvdm_rowdot(st["j_f1"].data_ptr(), 1, st["ted"], s), "lfvdm_rowdot")
+        nat.check(L.lfvdm_rowdot(st["j_fg"].data_ptr(), st["n_g"], st["total"], s), "lfvdm_rowdot")
+        return st["views"]
+
+    def ensure_backward_queued(self):
+        if not self.queued:
+            self.queued = True
+            th.autograd.Variable._execution_engine.queue_callback(self.backward)
+
+    def backward(self):
+        self.queued = False
+        st = self.state
+        L, s = nat.lib(), nat.stream()
+        nat.check(L.lfvdm_rowdot_bwd(st["j_bg"].data_ptr(), st["n_g"], st["tasks_g"], s), "lfvdm_rowdot_bwd")
+        # d emb = (through the RPE projections) + (through silu in front of the FiLM projections)
+        th.add(st["demb_raw"], th.ops.aten.silu_backward(st["demb_act"], st["emb"]), out=st["demb"])
+        nat.check(L.lfvdm_rowdot_bwd(st["j_b1"].data_ptr(), 1, st["tasks_t"], s), "lfvdm_rowdot_bwd")
+        st["dh0"].copy_(th.ops.aten.silu_backward(st["dh0_act"], st["h0"]))
+        nat.check(L.lfvdm_rowdot_bwd(st["j_b0"].data_ptr(), 1, st["tasks_t"], s), "lfvdm_rowdot_bwd")
+
+
+_embed = _EmbedNet()
+
+
 # ----------------------------------------------------------------------------- whole network
 def _rpe_feats(rel):
     """Distance features of rpe.py:22-27, shared by all RPE networks of a forward pass."""
@@ -541,13 +661,13 @@ class RpeFrontFn(th.autograd.Function):
     """act = silu(tproj[b] + embed_distances(feats)) on rows (b, t, s): one launch forward, one backward."""
 
     @staticmethod
-    def forward(ctx, tproj, feats, wd, bd, B, TT):
+    def forward(ctx, tproj, feats, wd, bd, B, TT, dtproj_slot=None):
         C = tproj.shape[1]
-        tproj = tproj.contiguous()
         act = _new(B * TT, C, like=tproj)
-        nat.check(nat.lib().lfvdm_rpe_front(nat.ptr(tproj), nat.ptr(feats), nat.ptr(wd), nat.ptr(bd), nat.ptr(act), B, TT, C,
-                                            nat.stream()), "lfvdm_rpe_front")
+        nat.check(nat.lib().lfvdm_rpe_front(tproj.data_ptr(), tproj.stride(0), nat.ptr(feats), nat.ptr(wd), nat.ptr(bd),
+                                            nat.ptr(act), B, TT, C, nat.stream()), "lfvdm_rpe_front")
         ctx.save_for_backward(tproj, feats, wd, bd)
+        ctx.slot = dtproj_slot
         ctx.geom = (B, TT, C)
         return act
 
@@ -556,22 +676,28 @@ class RpeFrontFn(th.autograd.Function):
         tproj, feats, wd, bd = ctx.saved_tensors
         B, TT, C = ctx.geom
         leaf = wd.is_leaf and bd.is_leaf
-        dtproj = th.zeros(B, C, device=tproj.device, dtype=th.float32)
+        if ctx.slot is not None:      # accumulate into the embedding network's (zeroed) gradient buffer
+            _embed.ensure_backward_queued()
+            dtproj = ctx.slot
+        else:
+            dtproj = th.zeros(B, C, device=tproj.device, dtype=th.float32)
         dwd = _grad_of(wd) if leaf else th.zeros_like(wd)
         dbd = _grad_of(bd) if leaf else th.zeros_like(bd)
-        nat.check(nat.lib().lfvdm_rpe_front_bwd(nat.ptr(tproj), nat.ptr(feats), nat.ptr(wd), nat.ptr(bd),
-                                                nat.ptr(d_act.contiguous()), nat.ptr(dtproj), nat.ptr(dwd), nat.ptr(dbd), B, TT, C,
-                                                nat.stream()), "lfvdm_rpe_front_bwd")
-        return dtproj, None, (None if leaf else dwd), (None if leaf else dbd), None, None
+        nat.check(nat.lib().lfvdm_rpe_front_bwd(tproj.data_ptr(), tproj.stride(0), nat.ptr(feats), nat.ptr(wd), nat.ptr(bd),
+                                                nat.ptr(d_act.contiguous()), dtproj.data_ptr(), dtproj.stride(0), nat.ptr(dwd),
+                                                nat.ptr(dbd), B, TT, C, nat.stream()), "lfvdm_rpe_front_bwd")
+        return (None if ctx.slot is not None else dtproj), None, (None if leaf else dwd), (None if leaf else dbd), None, None, None
 
 
-def _rpe_R(net, temb_b, feats, B, T):
+def _rpe_R(net, temb_b, feats, B, T, tproj=None, slot=None):
     """RPENet (rpe.py:20-31) on device: the 3-feature / time-embedding projections are tiny library ops, the
     C x C output layer runs on the HIP GEMM kernels."""
     C = net.out.weight.shape[0]
     if C % 32 == 0:   # hidden layer fused in one launch; C x C output layer on the GEMM / wgrad kernels (rows = B*T*T)
-        act = RpeFrontFn.apply(net.embed_diffusion_time(temb_b), feats.view(B * T * T, 3), net.embed_distances.weight,
-                               net.embed_distances.bias, B, T * T)
+        if tproj is None:
+            tproj = net.embed_diffusion_time(temb_b)
+        act = RpeFrontFn.apply(tproj, feats.view(B * T * T, 3), net.embed_distances.weight, net.embed_distances.bias, B, T * T,
+                               slot)
         return LinearFn.apply(act, net.out.weight, net.out.bias, None).view(B, T, T, C)
     hid = net.embed_diffusion_time(temb_b).view(B, 1, 1, -1) + net.embed_distances(feats)
     return net.out(F.silu(hid)).contiguous()       # B, T, T, C
@@ -592,13 +718,17 @@ class UNetFunction:
         obs = obs_mask.reshape(B, T, 1, 1, 1).to(th.float32)
         mask = (obs_mask.reshape(B, T) + latent_mask.reshape(B, T)).clamp(max=1).to(th.float32).contiguous()
         # --- embeddings (per batch element: rows of the reference's (B*T, 4ch) emb are equal within b)
-        freqs = getattr(engine, "_freqs", None)
-        if freqs is None or freqs.device != x.device:
-            freqs = engine._freqs = timestep_freqs(ch).to(x.device)     # uploaded once (graph capture safe)
-        args = timesteps.to(th.float32)[:, None] * freqs[None]
-        temb = th.cat([th.cos(args), th.sin(args)], dim=-1)
-        emb = m.time_embed[2](F.silu(m.time_embed[0](temb)))            # (B, 4ch)
-        semb = F.silu(emb)
+        views = _embed.forward(m, timesteps.to(th.float32), B, x.device) if x.is_cuda else None
+        if views is None:        # per-layer library path (non-leaf parameters, or first call under capture)
+            freqs = getattr(engine, "_freqs", None)
+            if freqs is None or freqs.device != x.device:
+                freqs = engine._freqs = timestep_freqs(ch).to(x.device)     # uploaded once (graph capture safe)
+            args = timesteps.to(th.float32)[:, None] * freqs[None]
+            temb = th.cat([th.cos(args), th.sin(args)], dim=-1)
+            emb = m.time_embed[2](F.silu(m.time_embed[0](temb)))            # (B, 4ch)
+            semb = F.silu(emb)
+        else:
+            emb = semb = None
         feats = _rpe_feats(frame_indices.unsqueeze(-1) - frame_indices.unsqueeze(-2))
         # --- input compositing + first conv (reference unet.py:441-450): 5 -> 32 zero-padded channels
         comp = th.cat([x * (1 - obs) + x0 * obs, th.ones_like(x[:, :, :1]) * obs], dim=2)
@@ -615,17 +745,18 @@ class UNetFunction:
             b = skip
             for layer in blk:
                 if isinstance(layer, ResBlock):
-                    film = layer.emb_layers[1](semb)
+                    film, slot = views[layer] if views is not None else (layer.emb_layers[1](semb), None)
                     sk = layer.skip_connection
                     ws, bs = (None, None) if isinstance(sk, nn.Identity) else (sk.weight, sk.bias)
                     h = ResBlockFn.apply(h, b, film, layer.in_layers[0].weight, layer.in_layers[0].bias,
                                          layer.in_layers[2].weight, layer.in_layers[2].bias, layer.out_layers[0].weight,
                                          layer.out_layers[0].bias, layer.out_layers[3].weight, layer.out_layers[3].bias,
-                                         ws, bs, N, Hc, Wc, T)
+                                         ws, bs, N, Hc, Wc, T, slot)
                     b = None
                 elif isinstance(layer, FactorizedAttentionBlock):
                     ta, sa = layer.temporal_attention, layer.spatial_attention
-                    R = [_rpe_R(r.rpe_net, emb, feats, B, T) for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v)]
+                    R = [_rpe_R(r.rpe_net, emb, feats, B, T, *(views[r.rpe_net] if views is not None else (None, None)))
+                         for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v)]
                     h = TemporalAttnFn.apply(h, ta.norm.weight, ta.norm.bias, ta.qkv.weight, ta.qkv.bias, ta.proj_out.weight,
                                              ta.proj_out.bias, R[0], R[1], R[2], mask, B, T, Hc * Wc, layer.num_heads)
                     h = SpatialAttnFn.apply(h, sa.norm.weight, sa.norm.bias, sa.qkv.weight, sa.qkv.bias, sa.proj_out.weight,

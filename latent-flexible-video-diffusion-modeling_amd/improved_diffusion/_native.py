@@ -50,6 +50,12 @@ class RowdotJob(C.Structure):
                 ("row0", C.c_int32), ("pad_", C.c_int32)]
 
 
+class RowdotBwdJob(C.Structure):
+    _fields_ = [("W", c_fp), ("inp", c_fp), ("dout", c_fp), ("dW", c_fp), ("db", c_fp), ("din", c_fp), ("K", C.c_int32),
+                ("O", C.c_int32), ("M", C.c_int32), ("ldin", C.c_int32), ("lddout", C.c_int32), ("lddin", C.c_int32),
+                ("in_mode", C.c_int32), ("task0", C.c_int32)]
+
+
 class PackJob(C.Structure):
     _fields_ = [("src", c_fp), ("dst", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32),
                 ("transposed", C.c_int32), ("blk0", C.c_int32), ("pad_", C.c_int32)]
@@ -84,14 +90,15 @@ _SIGS = {
     "lfvdm_gn_coef_stats": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_stats": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_apply": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp], c_i),
-    "lfvdm_gn_param_grads": ([c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp], c_i),
+    "lfvdm_gn_param_grads": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_rowdot_bwd": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_temporal_bwd": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_temporal": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rowdot": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_nets": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_attn_spatial": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
-    "lfvdm_rpe_front": ([c_fp] * 5 + [c_i, c_i, c_i, c_fp], c_i),
-    "lfvdm_rpe_front_bwd": ([c_fp] * 8 + [c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_rpe_front": ([c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_rpe_front_bwd": ([c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_sampler_tick": ([c_fp, c_fp, c_fp, c_i, c_fp], c_i),
     "lfvdm_attn_temporal_bwd": ([c_fp] * 12 + [c_i] * 5 + [c_fp], c_i),
     "lfvdm_attn_spatial_bwd": ([c_fp] * 6 + [c_i, c_i, c_i, c_i, c_fp], c_i),
