@@ -231,6 +231,52 @@ def bench_long_video(dev, max_windows):
             "finite": bool(th.isfinite(samples).all())}
 
 
+def bench_pixel(dev, steps):
+    """BASELINE.json configs[4]: pixel-space stress, 128x128x3 frames, max_frames=20, num_channels=128 (reference
+    defaults: num_res_blocks=2, channel_mult (1,1,2,3,4), attention at 16x16 and 8x8), batch 1; denoising steps of
+    the captured sampler plus the conv roofline of that step."""
+    from improved_diffusion import script_util as su
+    kw = su.model_and_diffusion_defaults()
+    kw.update(image_size=128, in_channels=3, num_channels=128, num_res_blocks=2, num_heads=4, attention_resolutions="16,8",
+              diffusion_steps=1000, timestep_respacing="",
+              diffusion_space_kwargs={"diffusion_space": "pixel", "pre_encoded": False, "pre_encoded_stats_dict": None})
+    model, diffusion = su.create_model_and_diffusion(**kw)
+    g = th.Generator().manual_seed(7)
+    with th.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 1:
+                p.copy_((1.0 if name.endswith("weight") else 0.0) + 0.1 * th.randn(p.shape, generator=g))
+            else:
+                p.copy_(th.randn(p.shape, generator=g) / math.sqrt(p[0].numel()))
+    model = model.to(dev).eval()
+    B, T = 1, 20
+    shape = (B, T, 3, 128, 128)
+    g = th.Generator().manual_seed(11)
+    obs = th.zeros(B, T, 1, 1, 1)
+    obs[:, :T // 3] = 1.0
+    inputs = {k: v.to(dev) for k, v in dict(x0=th.randn(*shape, generator=g).clamp(-1, 1), frame_indices=th.arange(T)[None],
+                                            obs_mask=obs, latent_mask=1.0 - obs).items()}
+    sampler = diffusion._graph_sampler(model, shape, True)
+    th.manual_seed(3)
+    sampler.begin(th.randn(*shape, device=dev), inputs)
+    for _ in range(2):
+        sampler.step(sampler.expected_t)
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sampler.step(sampler.expected_t)
+    th.cuda.synchronize()
+    el = time.perf_counter() - t0
+    groups = kernel_breakdown(sampler.plan, reps=2, inner=1)
+    convs = {k: v for k, v in groups.items() if k.startswith("conv_igemm")}
+    fl, ms = sum(v["flops"] for v in convs.values()), sum(v["ms"] for v in convs.values())
+    return {"workload": "pixel space 128x128x3, 20 frames, batch 1, num_channels=128, num_res_blocks=2 (BASELINE.json configs[4])",
+            "steps": steps, "ms_per_step": round(1000 * el / steps, 2), "steps_per_s": round(steps / el, 2),
+            "params": sum(p.numel() for p in model.parameters()), "conv_gemm_gflop_per_step": round(fl / 1e9, 1),
+            "conv_gemm_tflops": round(fl / (ms * 1e-3) / 1e12, 1), "conv_gemm_frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 3),
+            "whole_step_tflops": round(fl / (el / steps) / 1e12, 1), "finite": bool(th.isfinite(sampler.plan.x_in).all())}
+
+
 def pmc_traffic(kernel_name):
     """HBM-side bytes per launch of one kernel from the committed rocprofv3 counter passes
     (profiles/r01_pmc_traffic.json, produced by tools_pmc_target.py + tools_pmc_summarize.py); None if absent."""
@@ -251,6 +297,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10, help="timed optimizer steps of the training leg (0 = skip)")
+    ap.add_argument("--pixel-steps", type=int, default=0, help="also time this many steps of the pixel-space stress config (0 = skip)")
     ap.add_argument("--long-video-windows", type=int, default=0,
                     help="also run the hierarchy-2 long-video leg with at most this many windows (97 = full; 0 = skip)")
     args = ap.parse_args()
@@ -323,6 +370,8 @@ def main():
         out["train"] = train
     if args.long_video_windows > 0 and rank == 0:
         out["long_video"] = bench_long_video(dev, args.long_video_windows)
+    if args.pixel_steps > 0 and rank == 0:
+        out["pixel"] = bench_pixel(dev, args.pixel_steps)
     if rank == 0:
         if not args.no_breakdown:
             groups = kernel_breakdown(sampler.plan)
