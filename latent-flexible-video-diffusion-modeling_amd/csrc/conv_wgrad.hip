@@ -345,7 +345,8 @@ static void launch_wgrad_coop(const lfvdm_conv_args* a, hipStream_t s, int nchun
     const int NKG = a->ksize * a->ksize * (Cin / (32 * KT));
     const int NCG = (a->Cout + 32 * COT - 1) / (32 * COT);
     const long tiles = (long)NKG * NCG;
-    long msplit = (512 + tiles - 1) / tiles;           // about two workgroups per CU
+    static const long target = getenv("LFVDM_WGRAD_WGS") ? atol(getenv("LFVDM_WGRAD_WGS")) : 384;
+    long msplit = (target + tiles - 1) / tiles;        // 1.5 workgroups per CU measured best (tile traffic vs bytes of atomics)
     if (msplit > nchunks / 2) msplit = nchunks / 2;    // at least two chunks per slice (the prefetch needs a successor)
     if (msplit < 1) msplit = 1;
     hipLaunchKernelGGL((conv_wgrad_coop_kernel<COT, KT>), dim3((unsigned)(tiles * msplit)), dim3(256), 0, s, *a, (int)msplit);
@@ -463,10 +464,18 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
     const long M = (long)a->N * a->Ho * a->Wo;
     const int nchunks = (int)((M + 31) / 32);
     {   // wide layers: cooperative workgroup tiles (the channel group must not straddle the two sources)
-        const int cot = a->Cout >= 128 ? 4 : a->Cout >= 64 ? 2 : 0;
+        // tile shape (measured on the cfg-C layers): 128 filters x 64 channels for the big 3x3 layers, 64 x 64 for
+        // 1x1 / linear layers and the low-resolution levels (smaller tiles = fewer bytes of atomics per workgroup)
+        const bool big3 = a->ksize == 3 && M >= 2560;
+        int cot = (a->Cout >= 128 && big3) ? 4 : a->Cout >= 64 ? 2 : 0;
         int kt = 0;
-        for (int k : {4, 2})
+        for (int k : {2})
             if (kt == 0 && Cin % (32 * k) == 0 && a->C0 % (32 * k) == 0) kt = k;
+        if (const char* f = getenv("LFVDM_WGRAD_TILE")) {   // tuning aid: "<cot><kt>", e.g. 22
+            const int v = atoi(f);
+            if (cot >= v / 10) cot = v / 10;
+            if (kt >= v % 10) kt = v % 10;
+        }
         if (cot && kt && !getenv("LFVDM_WGRAD_WAVE")) {
             hipStream_t s = (hipStream_t)stream;
             if (cot == 4 && kt == 4) launch_wgrad_coop<4, 4>(a, s, nchunks);
