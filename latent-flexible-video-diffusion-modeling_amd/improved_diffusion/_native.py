@@ -168,8 +168,23 @@ def conv_igemm(**kw):
     a.W2 = ptr(kw.get("W2")); a.bias2 = ptr(kw.get("bias2"))
     a.res = ptr(kw.get("res")); a.ldr = kw.get("ldr", kw["Cout"]); a.resA = ptr(kw.get("resA")); a.resB = ptr(kw.get("resB"))
     a.out = ptr(kw["out"]); a.ldo = kw["ldo"]; a.out_mode = kw.get("out_mode", OUT_ROWS)
+    ws, cnt = splitk_workspace(kw["out"].device)
+    a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
     a.tune = tuned_code(a)
     check(lib().lfvdm_conv_igemm(C.byref(a), stream()), "lfvdm_conv_igemm")
+
+
+_splitk = {}
+
+
+def splitk_workspace(device):
+    """Per-device split-K workspace shared by all eager launches (they are stream-ordered): 8 MiB of slabs and
+    zero-initialised, self-cleaning arrival tickets."""
+    ent = _splitk.get(device)
+    if ent is None:
+        ent = _splitk[device] = (torch.empty(2 * 1024 * 1024, device=device, dtype=torch.float32),
+                                 torch.zeros(4096, device=device, dtype=torch.int32))
+    return ent
 
 
 # ------------------------------------------------------------------------------------------- launch tuning
