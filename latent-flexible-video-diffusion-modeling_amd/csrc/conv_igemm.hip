@@ -210,7 +210,7 @@ __device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs
 }
 
 template <int WM, int WN, int WK, int NT, int KCH, int PRO>
-__global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfvdm_conv_args p_in) {
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfvdm_conv_args p_in, int hyb_nfull, int hyb_kz) {
     const lfvdm_conv_args p = p_in;   // private SSA copy: helpers take it by reference (keeps it out of scratch)
     using CF = Cfg<WM, WN, WK, NT, KCH>;
     constexpr int BM = CF::BM, BN = CF::BN, KC = CF::KC, LDR = CF::LDR;
@@ -227,10 +227,31 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     const int wmn = wave - wk * (WM * WN);
     const int wm = wmn / WN, wn = wmn - wm * WN;
     const int gt = tid - wk * CF::GT;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
     const int HoWo = p.Ho * p.Wo;
     const int M = p.N * HoWo;
+    // Workgroup -> (output tile, K slice).  Plain launches: grid (m tiles, n tiles, KZ slices).  "Tail split"
+    // launches (hyb_kz > 0, flat grid): the first hyb_nfull tiles - a multiple of the CU count - are computed whole,
+    // each remaining tile by hyb_kz workgroups, so that the last, partial wave of tiles does not cost a full tile time.
+    int bx = blockIdx.x, by = blockIdx.y, KZ = gridDim.z, kz = blockIdx.z;
+    size_t tile_id = (size_t)by * gridDim.x + bx;          // ticket / slab index of this tile
+    if (hyb_kz > 0) {
+        const int MT = (M + BM - 1) / BM;
+        const int b = blockIdx.x;
+        int tile = b;
+        KZ = 1;
+        kz = 0;
+        if (b >= hyb_nfull) {
+            const int r = b - hyb_nfull;
+            tile = hyb_nfull + r / hyb_kz;
+            kz = r - (r / hyb_kz) * hyb_kz;
+            KZ = hyb_kz;
+        }
+        by = tile / MT;
+        bx = tile - by * MT;
+        tile_id = (size_t)(tile - hyb_nfull);
+    }
+    const int m0 = bx * BM;
+    const int n0 = by * BN;
     const int Cin = p.C0 + p.C1;
     const int taps = p.ksize * p.ksize;
     const int NK1 = taps * (Cin / KC);
@@ -243,7 +264,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     // partial tiles are combined with float atomics into the zero-initialised output), then over the
     // k-groups of the workgroup.  Every group runs `iters` iterations (same barrier count); a group that
     // owns fewer chunks replays its last chunk with everything masked to zero.
-    const int KZ = gridDim.z, kz = blockIdx.z;
     const int zbeg = (int)(((long)NK * kz) / KZ), zend = (int)(((long)NK * (kz + 1)) / KZ);
     const int NKz = zend - zbeg;
     const int kbeg = zbeg + (int)(((long)NKz * wk) / WK);
@@ -384,7 +404,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     bool do_epilogue = true;
     if (KZ > 1) {
         constexpr int QNs = BN / 4;
-        const size_t tile_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
         float* slab = p.splitk_ws + (tile_id * KZ + kz) * (size_t)(BM * BN);
         for (int e = tid; e < BM * QNs; e += CF::NTHREADS) {
             const int row = e / QNs, c4 = (e - row * QNs) * 4;
@@ -508,6 +527,19 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// "tail split": tiles beyond the last full wave of workgroups (a multiple of the CU count) are K-split
+constexpr int kHybridKz = 16;      // pseudo kz value selecting the tail-split launch (tune code l = 4)
+constexpr long kNumCUs = 256;      // MI355X
+struct HybridPlan { long nfull, tail; int kz; };
+inline HybridPlan hybrid_plan(long tiles) {
+    HybridPlan h;
+    h.nfull = (tiles / kNumCUs) * kNumCUs;
+    h.tail = tiles - h.nfull;
+    long k = h.tail > 0 ? kNumCUs / h.tail : 1;
+    h.kz = (int)(k < 2 ? 2 : k > 8 ? 8 : k);
+    return h;
+}
+
 template <int WM, int WN, int WK, int NT, int KCH, int PRO>
 int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
     using CF = Cfg<WM, WN, WK, NT, KCH>;
@@ -518,8 +550,16 @@ int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
             return LFVDM_E_LAUNCH;
         attr_set = true;
     }
-    const dim3 grid((unsigned)((M + CF::BM - 1) / CF::BM), (unsigned)((a->Cout + CF::BN - 1) / CF::BN), (unsigned)kz);
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a);
+    const long MT = (M + CF::BM - 1) / CF::BM, NT2 = (a->Cout + CF::BN - 1) / CF::BN;
+    if (kz == kHybridKz) {   // tail split (see the kernel): flat grid
+        const HybridPlan h = hybrid_plan(MT * NT2);
+        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>), dim3((unsigned)(h.nfull + h.tail * h.kz)),
+                           dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, (int)h.nfull, h.kz);
+        LFVDM_CHECK_LAUNCH();
+        return LFVDM_OK;
+    }
+    const dim3 grid((unsigned)MT, (unsigned)NT2, (unsigned)kz);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
@@ -590,7 +630,7 @@ inline int encode_tune(int id, int kch, int kz) {
 // is (id, kch, kz) a legal configuration for these arguments?
 bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz) {
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
-    if (id < 0 || id >= kNumCfgs || id == 7 || (kch != 32 && kch != 64) || kz < 1 || kz > 8) return false;
+    if (id < 0 || id >= kNumCfgs || id == 7 || (kch != 32 && kch != 64) || kz < 1 || (kz > 8 && kz != kHybridKz)) return false;
     const TileCfg c = kCfgs[id];
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
     if (a->Cout <= 32 && BN > 32) return false;
@@ -601,10 +641,17 @@ bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz) {
     if ((double)c.WK * 2.0 * (BM + BN) * (kch + 4) * 4.0 > 160.0 * 1024.0) return false;
     // split-K over workgroups needs the caller's workspace (slabs + tile tickets) and the rows layout
     if (kz > 1) {
-        if (!a->splitk_ws || !a->splitk_cnt || a->out_mode != LFVDM_OUT_ROWS || NK < kz * c.WK) return false;
+        if (!a->splitk_ws || !a->splitk_cnt || a->out_mode != LFVDM_OUT_ROWS) return false;
         const long M = (long)a->N * a->Ho * a->Wo;
         const long tiles = ((M + BM - 1) / BM) * ((a->Cout + BN - 1) / BN);
-        if (tiles * kz * (long)(BM * BN) > a->splitk_ws_floats || tiles > a->splitk_cnt_ints) return false;
+        if (kz == kHybridKz) {
+            const HybridPlan h = hybrid_plan(tiles);
+            if (h.nfull == 0 || h.tail == 0 || 4 * h.tail > 3 * kNumCUs || NK < h.kz * c.WK) return false;
+            if (h.tail * h.kz * (long)(BM * BN) > a->splitk_ws_floats || h.tail > a->splitk_cnt_ints) return false;
+        } else {
+            if (NK < kz * c.WK) return false;
+            if (tiles * kz * (long)(BM * BN) > a->splitk_ws_floats || tiles > a->splitk_cnt_ints) return false;
+        }
     }
     return true;
 }
@@ -700,7 +747,7 @@ extern "C" int lfvdm_conv_igemm_candidates(const lfvdm_conv_args* a, int* codes,
     int n = 0;
     for (int id = 0; id < kNumCfgs; ++id)
         for (int kch = 32; kch <= 64; kch += 32)
-            for (int kz = 1; kz <= 8; kz *= 2)
+            for (int kz = 1; kz <= kHybridKz; kz *= 2)
                 if (cfg_valid(a, id, kch, kz) && n < max_codes) codes[n++] = encode_tune(id, kch, kz);
     return n;
 }
@@ -717,4 +764,4 @@ extern "C" int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* n
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_abi_version(void) { return 2; }
+extern "C" int lfvdm_abi_version(void) { return 3; }
