@@ -413,8 +413,8 @@ void attn_temporal_bwd_rpe_kernel(const float* __restrict__ qkv, const float* __
         const size_t a0 = (term == 2) ? (size_t)row0 * T + i : (size_t)i * T + row0;
         const size_t a1 = (term == 2) ? (size_t)row1 * T + i : (size_t)i * T + row1;
         const bool two = T > 16;
-#pragma unroll 8
-        for (int pb = 0; pb < P; pb += 4) {
+#pragma unroll 32
+        for (int pb = 0; pb < P; pb += 4) {   // deep unroll: the loop is a chain of dependent-latency loads otherwise
             const int p = pb + kk;
             const bool pok = p < P;
             const float bv = (pok && colok) ? Bsrc[(size_t)p * bstride] : 0.f;

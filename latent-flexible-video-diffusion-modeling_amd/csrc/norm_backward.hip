@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
 }
 
 // Parameter gradients of a (FiLM-modulated) GroupNorm from the per-(sample, channel) sums of gn_bwd_stats
-// (sums[n][c] = {sum dz, sum dz*xhat}); one thread per channel, fixed summation order (deterministic):
+// (sums[n][c] = {sum dz, sum dz*xhat}).  Block = 64 channels x 4 sample lanes, fixed summation order (deterministic):
 //   dgamma[c] += sum_n s2 * (1 + scale[n/T][c]);  dbeta[c] += sum_n s1 * (1 + scale);
 //   dfilm[b][c] = sum_t (s2 * gamma[c] + s1 * beta[c]);  dfilm[b][C + c] = sum_t s1        (FiLM only)
 __global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
@@ -246,35 +246,58 @@ __global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __rest
                                                              int film_ld, int T, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ dfilm, int dfilm_ld,
                                                              int N, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[4][64][4];
+    const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool ok = c < C;
     float dg = 0.f, db = 0.f;
     if (film) {
-        const float g = gamma[c], be = beta[c];
+        const float g = ok ? gamma[c] : 0.f, be = ok ? beta[c] : 0.f;
         const int B = N / T;
         for (int b = 0; b < B; ++b) {
-            const float sc1 = 1.0f + film[(size_t)b * film_ld + c];
-            float dsc = 0.f, dsh = 0.f;
-            for (int t = 0; t < T; ++t) {
-                const float* s = sums + ((size_t)(b * T + t) * C + c) * 2;
-                const float s1 = s[0], s2 = s[1];
-                dg += s2 * sc1;
-                db += s1 * sc1;
-                dsc += s2 * g + s1 * be;
-                dsh += s1;
+            const float sc1 = ok ? 1.0f + film[(size_t)b * film_ld + c] : 0.f;
+            float dsc = 0.f, dsh = 0.f, g1 = 0.f, b1 = 0.f;
+            if (ok)
+                for (int t = nl; t < T; t += 4) {
+                    const float* s = sums + ((size_t)(b * T + t) * C + c) * 2;
+                    const float s1 = s[0], s2 = s[1];
+                    g1 += s2;
+                    b1 += s1;
+                    dsc += s2 * g + s1 * be;
+                    dsh += s1;
+                }
+            red[nl][cl][0] = dsc; red[nl][cl][1] = dsh; red[nl][cl][2] = g1; red[nl][cl][3] = b1;
+            __syncthreads();
+            if (nl == 0 && ok) {
+                float t4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t4[k] = red[0][cl][k] + red[1][cl][k] + red[2][cl][k] + red[3][cl][k];
+                dfilm[(size_t)b * dfilm_ld + c] = t4[0];
+                dfilm[(size_t)b * dfilm_ld + C + c] = t4[1];
+                dg += t4[2] * sc1;
+                db += t4[3] * sc1;
             }
-            dfilm[(size_t)b * dfilm_ld + c] = dsc;
-            dfilm[(size_t)b * dfilm_ld + C + c] = dsh;
+            __syncthreads();
         }
     } else {
-        for (int n = 0; n < N; ++n) {
-            const float* s = sums + ((size_t)n * C + c) * 2;
-            db += s[0];
-            dg += s[1];
+        float g1 = 0.f, b1 = 0.f;
+        if (ok)
+            for (int n = nl; n < N; n += 4) {
+                const float* s = sums + ((size_t)n * C + c) * 2;
+                b1 += s[0];
+                g1 += s[1];
+            }
+        red[nl][cl][0] = g1; red[nl][cl][1] = b1;
+        __syncthreads();
+        if (nl == 0) {
+            dg = red[0][cl][0] + red[1][cl][0] + red[2][cl][0] + red[3][cl][0];
+            db = red[0][cl][1] + red[1][cl][1] + red[2][cl][1] + red[3][cl][1];
         }
     }
-    dgamma[c] += dg;
-    dbeta[c] += db;
+    if (nl == 0 && ok) {
+        dgamma[c] += dg;
+        dbeta[c] += db;
+    }
 }
 
 }  // namespace
@@ -316,7 +339,7 @@ extern "C" int lfvdm_gn_param_grads(const float* sums, const float* gamma, const
                                     int T, float* dgamma, float* dbeta, float* dfilm, int dfilm_ld, int N, int C, void* stream) {
     if (!sums || !dgamma || !dbeta || N <= 0 || C <= 0) return LFVDM_E_SHAPE;
     if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T || film_ld < 2 * C || dfilm_ld < 2 * C)) return LFVDM_E_SHAPE;
-    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, film,
+    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, film,
                        film_ld, T, dgamma, dbeta, dfilm, dfilm_ld, N, C);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
