@@ -21,6 +21,8 @@ FiLM projections and the 3-feature / time projections inside the RPE networks - 
 block, < 1 % of the FLOPs - plus their elementwise glue (SiLU, log1p features) and GroupNorm parameter-gradient
 reductions.
 """
+import weakref
+
 import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
@@ -40,16 +42,21 @@ class _WeightPacks:
     """Persistent packed copies of the conv weights of leaf parameters: forward layout [Cout][tap][Cin] and
     data-gradient layout [Cin][tap][Cout] (flipped taps).  All of them are refreshed by ONE grouped launch the first
     time any is requested after the parameters changed (optimizer step / load_state_dict) instead of two small
-    launches per convolution per step."""
+    launches per convolution per step.  Parameters are held weakly: entries of freed models are dropped."""
 
     def __init__(self):
-        self.ent = {}           # (data_ptr, shape, transposed) -> [source view, packed, stamp, transposed]
+        self.ent = {}           # (data_ptr, shape, transposed) -> [weakref(base param), packed, stamp]
         self.table = None
 
     @staticmethod
-    def _stamp(w4):
-        base = w4._base if w4._base is not None else w4
+    def _stamp(base):
         return (nat.param_epoch[0], base._version)
+
+    @staticmethod
+    def _pack_one(key, out):
+        ptr_, (Cout, Cin, k, _), tr = key
+        fn = nat.lib().lfvdm_pack_conv_weight_t if tr else nat.lib().lfvdm_pack_conv_weight
+        nat.check(fn(ptr_, out.data_ptr(), Cout, Cin, k, nat.stream()), "lfvdm_pack_conv_weight")
 
     def get(self, w4, transposed):
         base = w4._base if w4._base is not None else w4
@@ -60,35 +67,38 @@ class _WeightPacks:
             return out
         key = (w4.data_ptr(), tuple(w4.shape), bool(transposed))
         e = self.ent.get(key)
-        if e is None:
+        if e is None or e[0]() is not base:       # new weight (or the address was re-used by another parameter)
             out = _new(*((Cin, k * k, Cout) if transposed else (Cout, k * k, Cin)), like=w4)
-            (nat.pack_conv_weight_t if transposed else nat.pack_conv_weight)(w4, out)
-            self.ent[key] = [w4, out, self._stamp(w4), bool(transposed)]
+            self._pack_one(key, out)
+            self.ent[key] = [weakref.ref(base), out, self._stamp(base)]
             self.table = None
             return out
-        if e[2] != self._stamp(w4):
+        if e[2] != self._stamp(base):
             self.refresh_all()
         return e[1]
 
     def refresh_all(self):
-        ents = list(self.ent.values())
+        dead = [k for k, e in self.ent.items() if e[0]() is None]
+        for k in dead:
+            del self.ent[k]
+        if dead:
+            self.table = None
         if self.table is None:
             if th.cuda.is_current_stream_capturing():      # cannot upload a job table now: pack one by one
-                for w4, out, _, tr in ents:
-                    (nat.pack_conv_weight_t if tr else nat.pack_conv_weight)(w4, out)
-                for e in ents:
-                    e[2] = self._stamp(e[0])
+                for key, e in self.ent.items():
+                    self._pack_one(key, e[1])
+                    e[2] = self._stamp(e[0]())
                 return
             jobs, blk = [], 0
-            for (ptr_, shape, tr), (w4, out, _, _tr) in self.ent.items():
-                Cout, Cin, k, _k = shape
-                jobs.append(nat.PackJob(w4.data_ptr(), out.data_ptr(), Cout, Cin, k * k, int(tr), blk, 0))
+            for (ptr_, (Cout, Cin, k, _k), tr), e in self.ent.items():
+                jobs.append(nat.PackJob(ptr_, e[1].data_ptr(), Cout, Cin, k * k, int(tr), blk, 0))
                 blk += (Cout * Cin * k * k + 1023) // 1024
-            self.table, self.blocks, self.njobs = nat.jobs_to_device(jobs, ents[0][1].device), blk, len(jobs)
+            dev = next(iter(self.ent.values()))[1].device
+            self.table, self.blocks, self.njobs = nat.jobs_to_device(jobs, dev), blk, len(jobs)
         nat.check(nat.lib().lfvdm_pack_conv_weights(self.table.data_ptr(), self.njobs, self.blocks, nat.stream()),
                   "lfvdm_pack_conv_weights")
-        for e in ents:
-            e[2] = self._stamp(e[0])
+        for e in self.ent.values():
+            e[2] = self._stamp(e[0]())
 
 
 _packs = _WeightPacks()
@@ -118,16 +128,16 @@ class _PackedGrads:
     grouped kernel folds all of them into the OIHW ``.grad`` tensors and zeroes them again."""
 
     def __init__(self):
-        self.bufs = {}          # id(param) -> (param, packed buffer)
+        self.bufs = {}          # id(param) -> (weakref(param), packed buffer)
         self.table = None
         self.table_key = None
         self.queued = False
 
     def buffer(self, w):
         ent = self.bufs.get(id(w))
-        if ent is None or ent[0] is not w or ent[1].device != w.device:
+        if ent is None or ent[0]() is not w or ent[1].device != w.device:
             Cout, Cin, k, _ = w.shape
-            ent = (w, th.zeros(Cout, k * k, Cin, device=w.device, dtype=th.float32))
+            ent = (weakref.ref(w), th.zeros(Cout, k * k, Cin, device=w.device, dtype=th.float32))
             self.bufs[id(w)] = ent
             self.table = None
         if not self.queued:     # fold at the end of the running backward pass (also under graph capture)
@@ -137,7 +147,11 @@ class _PackedGrads:
 
     def flush(self):
         self.queued = False
-        live = [(w, gp) for w, gp in self.bufs.values() if w.grad is not None and w.grad.is_cuda]
+        for k in [k for k, (r, _) in self.bufs.items() if r() is None]:     # parameters of freed models
+            del self.bufs[k]
+            self.table = None
+        live = [(r(), gp) for r, gp in self.bufs.values()]
+        live = [(w, gp) for w, gp in live if w is not None and w.grad is not None and w.grad.is_cuda]
         if not live:
             return
         key = tuple((gp.data_ptr(), w.grad.data_ptr()) for w, gp in live)
