@@ -163,7 +163,15 @@ int lfvdm_gn_coef(const float* src0, const float* src1, int C0, int C1, int N, i
                   const float* gamma, const float* beta, const float* film, int film_div, int film_ld,
                   float eps, float* coefA, float* coefB, void* stream);
 
-/* Same, additionally writing (mean, rstd) per (sample, group) to stats[N][32][2] for the backward. */
+/* GroupNorm(+FiLM)(+activation) APPLIED: out[n][p][c] = act(x * A + B) as one contiguous [N*P][C0+C1] tensor (the
+ * virtual concat is materialised), nn.py:17-19 + SiLU nn.py:12-14 + unet.py:199-203.  coefA/coefB/stats are
+ * optional outputs (NULL to skip).  On gfx950 fp32 MFMA and VALU share the vector ALUs, so evaluating the
+ * normalisation/activation once here is cheaper than re-evaluating it per tap inside the consuming GEMM. */
+int lfvdm_gn_apply(const float* src0, const float* src1, int C0, int C1, int N, int P,
+                   const float* gamma, const float* beta, const float* film, int film_div, int film_ld,
+                   float eps, int act, float* out, float* coefA, float* coefB, float* stats, void* stream);
+
+/* Same as lfvdm_gn_coef, additionally writing (mean, rstd) per (sample, group) to stats[N][32][2] for the backward. */
 int lfvdm_gn_coef_stats(const float* src0, const float* src1, int C0, int C1, int N, int P,
                         const float* gamma, const float* beta, const float* film, int film_div, int film_ld,
                         float eps, float* coefA, float* coefB, float* stats, void* stream);

@@ -21,7 +21,8 @@ __device__ __forceinline__ f32x4 ld_cat(const float* s0, const float* s1, int C0
 __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
     const float* __restrict__ s0, const float* __restrict__ s1, int C0, int C1, int P,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
-    int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats) {
+    int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats,
+    float* __restrict__ act_out, int act_mode) {
     const int C = C0 + C1;
     const int cg = C / 32;
     const int CW = GN_GPW * cg;       // channels handled here
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
     __shared__ float part[GN_THREADS * 4];  // [pl][CW] partial channel sums
     __shared__ float chs[GN_MAXCW];
     __shared__ float gmean[GN_GPW], grstd[GN_GPW];
+    __shared__ __attribute__((aligned(16))) float shA[GN_MAXCW], shB[GN_MAXCW];
 
     const size_t pos0 = (size_t)n * P;
     constexpr int KEEP = 8;
@@ -102,8 +104,37 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
             A *= sc;
             B = B * sc + f[C + ch];
         }
-        coefA[(size_t)n * C + ch] = A;
-        coefB[(size_t)n * C + ch] = B;
+        if (coefA) {
+            coefA[(size_t)n * C + ch] = A;
+            coefB[(size_t)n * C + ch] = B;
+        }
+        shA[cc] = A;
+        shB[cc] = B;
+    }
+    if (act_out == nullptr) return;
+    // materialise act(x*A + B) as ONE contiguous [N*P][C] tensor (the virtual concat becomes a real one): on gfx950
+    // the fp32 MFMAs run on the vector ALUs, so a prologue fused into the consuming implicit GEMM - re-evaluated for
+    // every tap and every filter tile - sits on the GEMM's critical path; evaluating it once here is cheaper.
+    __syncthreads();
+    if (active) {
+        const f32x4 a4 = ld4(shA + q * 4), b4 = ld4(shB + q * 4);
+        if (cached) {
+#pragma unroll
+            for (int i = 0; i < KEEP; ++i) {
+                const int p = pl + i * PL;
+                if (p < P) {
+                    f32x4 v = keep[i] * a4 + b4;
+                    if (act_mode == LFVDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                    st4(act_out + (pos0 + p) * C + c, v);
+                }
+            }
+        } else {
+            for (int p = pl; p < P; p += PL) {
+                f32x4 v = ld_cat(s0, s1, C0, C1, pos0 + p, c) * a4 + b4;
+                if (act_mode == LFVDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                st4(act_out + (pos0 + p) * C + c, v);
+            }
+        }
     }
 }
 
@@ -363,7 +394,21 @@ extern "C" int lfvdm_gn_coef_stats(const float* src0, const float* src1, int C0,
     if (C1 > 0 && !src1) return LFVDM_E_SHAPE;
     if (film && film_div <= 0) return LFVDM_E_SHAPE;
     hipLaunchKernelGGL(gn_coef_kernel, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0, C1,
-                       P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats);
+                       P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, (float*)nullptr, 0);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_apply(const float* src0, const float* src1, int C0, int C1, int N, int P, const float* gamma,
+                              const float* beta, const float* film, int film_div, int film_ld, float eps, int act,
+                              float* out, float* coefA, float* coefB, float* stats, void* stream) {
+    const int C = C0 + C1;
+    if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024 || !out) return LFVDM_E_SHAPE;
+    if (C1 > 0 && !src1) return LFVDM_E_SHAPE;
+    if (film && film_div <= 0) return LFVDM_E_SHAPE;
+    if ((coefA == nullptr) != (coefB == nullptr)) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0, C1,
+                       P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, out, act);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

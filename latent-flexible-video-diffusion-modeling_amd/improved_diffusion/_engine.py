@@ -28,6 +28,10 @@ def _p(t):
     return t.data_ptr()
 
 
+# LFVDM_FUSED_GN=1 restores the older plan that folds GroupNorm/FiLM/SiLU into the operand load of the consuming GEMM
+FUSED_GN = os.environ.get("LFVDM_FUSED_GN", "0") == "1"
+
+
 class Plan:
     """Launch sequence + workspaces for one (B, T, H, W)."""
 
@@ -48,6 +52,22 @@ class Plan:
         t = th.empty(*shape, device=self.dev, dtype=dtype)
         self.keep.append(t)
         return t
+
+    def scratch(self, key, rows, cols):
+        """Shared scratch tensor [rows][cols] (launches are stream-ordered; a larger request replaces the buffer for
+        later steps, earlier steps keep theirs)."""
+        pool = self.__dict__.setdefault("_scratch", {})
+        t = pool.get(key)
+        if t is None or t.numel() < rows * cols:
+            t = pool[key] = self.buf(rows * cols)
+        return t[:rows * cols].view(rows, cols)
+
+    def gn_apply(self, a, b, C0, C1, N, P, gn, film, act, key):
+        out = self.scratch(key, N * P, C0 + C1)
+        self.add(nat.lib().lfvdm_gn_apply, _p(a), _p(b) if b is not None else None, C0, C1, N, P, _p(gn.weight), _p(gn.bias),
+                 _p(film) if film is not None else None, self.T if film is not None else 1,
+                 2 * (C0 + C1) if film is not None else 0, gn.eps, act, _p(out), None, None, None)
+        return out
 
     def packed(self, weight):
         Cout, Cin, k, _ = weight.shape
@@ -201,12 +221,17 @@ class Plan:
         # head: GN + SiLU + 3x3 conv straight into the (B,T,C,H,W) layout
         (hb, hc), = cur["parts"]
         gn, conv = m.out[0], m.out[2]
-        self.add(L.lfvdm_gn_coef, _p(hb), None, hc, 0, N, H * W, _p(gn.weight), _p(gn.bias), None, 1, 0, gn.eps,
-                 _p(self.s_cA), _p(self.s_cB))
         self.out = self.buf(B, T, m.out_channels, H, W)
-        self.add_conv(src0=hb, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA, coefB=self.s_cB, act=nat.ACT_SILU,
-                      W=self.packed(conv.weight), bias=conv.bias, Cout=m.out_channels, out=self.out,
-                      ldo=m.out_channels, out_mode=nat.OUT_NCHW)
+        if FUSED_GN:
+            self.add(L.lfvdm_gn_coef, _p(hb), None, hc, 0, N, H * W, _p(gn.weight), _p(gn.bias), None, 1, 0, gn.eps,
+                     _p(self.s_cA), _p(self.s_cB))
+            self.add_conv(src0=hb, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA, coefB=self.s_cB, act=nat.ACT_SILU,
+                          W=self.packed(conv.weight), bias=conv.bias, Cout=m.out_channels, out=self.out,
+                          ldo=m.out_channels, out_mode=nat.OUT_NCHW)
+        else:
+            act = self.gn_apply(hb, None, hc, 0, N, H * W, gn, None, nat.ACT_SILU, "act1")
+            self.add_conv(src0=act, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv.weight), bias=conv.bias,
+                          Cout=m.out_channels, out=self.out, ldo=m.out_channels, out_mode=nat.OUT_NCHW)
 
     def _stage(self, blk, cur):
         from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
@@ -237,17 +262,27 @@ class Plan:
         gn1, conv1 = rb.in_layers[0], rb.in_layers[2]
         gn2, conv2 = rb.out_layers[0], rb.out_layers[3]
         pb = _p(b) if b is not None else None
-        self.add(L.lfvdm_gn_coef, _p(a), pb, C0, C1, N, P, _p(gn1.weight), _p(gn1.bias), None, 1, 0, gn1.eps,
-                 _p(self.s_cA), _p(self.s_cB))
         h1 = self.buf(N * P, Cout)
-        self.add_conv(src0=a, src1=b, C0=C0, C1=C1, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA, coefB=self.s_cB,
-                      act=nat.ACT_SILU, W=self.packed(conv1.weight), bias=conv1.bias, Cout=Cout, out=h1, ldo=Cout)
         film = self.film[rb]
-        self.add(L.lfvdm_gn_coef, _p(h1), None, Cout, 0, N, P, _p(gn2.weight), _p(gn2.bias), _p(film), self.T, 2 * Cout,
-                 gn2.eps, _p(self.s_cA2), _p(self.s_cB2))
         out = self.buf(N * P, Cout)
-        kw = dict(src0=h1, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA2, coefB=self.s_cB2, act=nat.ACT_SILU,
-                  W=self.packed(conv2.weight), bias=conv2.bias, Cout=Cout, out=out, ldo=Cout)
+        if FUSED_GN:
+            self.add(L.lfvdm_gn_coef, _p(a), pb, C0, C1, N, P, _p(gn1.weight), _p(gn1.bias), None, 1, 0, gn1.eps,
+                     _p(self.s_cA), _p(self.s_cB))
+            self.add_conv(src0=a, src1=b, C0=C0, C1=C1, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA, coefB=self.s_cB,
+                          act=nat.ACT_SILU, W=self.packed(conv1.weight), bias=conv1.bias, Cout=Cout, out=h1, ldo=Cout)
+            self.add(L.lfvdm_gn_coef, _p(h1), None, Cout, 0, N, P, _p(gn2.weight), _p(gn2.bias), _p(film), self.T, 2 * Cout,
+                     gn2.eps, _p(self.s_cA2), _p(self.s_cB2))
+            kw = dict(src0=h1, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA2, coefB=self.s_cB2, act=nat.ACT_SILU,
+                      W=self.packed(conv2.weight), bias=conv2.bias, Cout=Cout, out=out, ldo=Cout)
+        else:
+            # GroupNorm(+FiLM)+SiLU evaluated ONCE into a scratch tensor (the concat of the two sources becomes
+            # real); the implicit GEMMs then stage raw operands (see lfvdm_gn_apply for why this wins on gfx950)
+            act1 = self.gn_apply(a, b, C0, C1, N, P, gn1, None, nat.ACT_SILU, "act1")
+            self.add_conv(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight), bias=conv1.bias,
+                          Cout=Cout, out=h1, ldo=Cout)
+            act2 = self.gn_apply(h1, None, Cout, 0, N, P, gn2, film, nat.ACT_SILU, "act2")
+            kw = dict(src0=act2, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv2.weight), bias=conv2.bias,
+                      Cout=Cout, out=out, ldo=Cout)
         if isinstance(rb.skip_connection, nn.Identity):
             assert b is None
             kw.update(res=a, ldr=Cout)
@@ -280,18 +315,27 @@ class Plan:
         self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.proj_out.weight,
                       bias=ta.proj_out.bias, Cout=Cc, res=self.s_xn, ldr=Cc, out=yt, ldo=Cc)
         # --- spatial: GN over (C/32 x HW) per frame, folded into the qkv GEMM operand and the residual
-        self.add(L.lfvdm_gn_coef, _p(yt), None, Cc, 0, N, P, _p(sa.norm.weight), _p(sa.norm.bias), None, 1, 0, sa.norm.eps,
-                 _p(self.s_cA), _p(self.s_cB))
-        self.add_conv(src0=yt, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=self.s_cA, coefB=self.s_cB,
-                      W=sa.qkv.weight, bias=sa.qkv.bias, Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
+        if FUSED_GN:
+            self.add(L.lfvdm_gn_coef, _p(yt), None, Cc, 0, N, P, _p(sa.norm.weight), _p(sa.norm.bias), None, 1, 0, sa.norm.eps,
+                     _p(self.s_cA), _p(self.s_cB))
+            self.add_conv(src0=yt, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=self.s_cA, coefB=self.s_cB,
+                          W=sa.qkv.weight, bias=sa.qkv.bias, Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
+        else:
+            ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
+            self.add_conv(src0=ysn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.qkv.weight, bias=sa.qkv.bias,
+                          Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
         asp = None
         if self.want_attn:
             asp = self.buf(N, heads, P, P)
             self.attn_s.append(asp)
         self.add(L.lfvdm_attn_spatial, _p(self.s_qkv), _p(self.s_o), _p(asp) if asp is not None else None, None, N, P, Cc, heads)
         ys = self.buf(M, Cc)
-        self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
-                      bias=sa.proj_out.bias, Cout=Cc, res=yt, ldr=Cc, resA=self.s_cA, resB=self.s_cB, out=ys, ldo=Cc)
+        if FUSED_GN:
+            self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
+                          bias=sa.proj_out.bias, Cout=Cc, res=yt, ldr=Cc, resA=self.s_cA, resB=self.s_cB, out=ys, ldo=Cc)
+        else:
+            self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
+                          bias=sa.proj_out.bias, Cout=Cc, res=ysn, ldr=Cc, out=ys, ldo=Cc)
         return dict(parts=[(ys, Cc)], H=H, W=W)
 
     def _resample(self, conv, cur, down):

@@ -88,6 +88,7 @@ _SIGS = {
     "lfvdm_conv_in": ([c_fp] * 6 + [c_i] * 5 + [c_fp], c_i),
     "lfvdm_gn_coef": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp], c_i),
     "lfvdm_gn_coef_stats": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp, c_fp], c_i),
+    "lfvdm_gn_apply": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_i, c_fp, c_fp, c_fp, c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_stats": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_apply": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_param_grads": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
