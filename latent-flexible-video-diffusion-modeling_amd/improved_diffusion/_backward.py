@@ -7,7 +7,8 @@ HIP kernels for the heavy work of the reference's ``loss.backward()`` (train_uti
     ``lfvdm_conv_igemm`` on transposed-flipped weights (``lfvdm_pack_conv_weight_t``; stride-2 convs use
     the zero-insertion gather), weight/bias gradient ``lfvdm_conv_wgrad`` (fp32 MFMA, the fused
     GroupNorm/FiLM/SiLU operand is recomputed on the fly, never stored);
-  * GroupNorm(+FiLM)(+SiLU): ``lfvdm_gn_coef_stats`` forward, ``lfvdm_gn_bwd_stats/apply`` backward;
+  * GroupNorm(+FiLM)(+SiLU): ``lfvdm_gn_apply`` forward (normalised + activated tensor materialised once and
+    saved: it is the raw operand of the GEMM and of the weight-gradient kernel), ``lfvdm_gn_bwd_stats/apply`` backward;
     temporal GroupNorm ``lfvdm_gn_temporal(_bwd)``;
   * attention cores: forward ``lfvdm_attn_spatial`` (saves the log-sum-exp) / ``lfvdm_attn_temporal``, backward
     ``lfvdm_attn_spatial_bwd`` (flash style dq / dk,dv kernels) and ``lfvdm_attn_temporal_bwd`` (rows / cols /
@@ -283,6 +284,19 @@ class LinearFn(th.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- GroupNorm helpers
+def _gn_apply(a, b, C0, C1, N, P, gamma, beta, film, T, act):
+    """GroupNorm(+FiLM)(+SiLU) applied once: -> (activated [N*P][C] tensor, coefA, coefB, stats).  The activated
+    tensor feeds the implicit GEMM and (saved) the weight-gradient kernel as a raw operand (lfvdm_gn_apply)."""
+    C = C0 + C1
+    out = _new(N * P, C, like=a)
+    cA, cB, stats = _new(N, C, like=a), _new(N, C, like=a), _new(N, 32, 2, like=a)
+    nat.check(nat.lib().lfvdm_gn_apply(
+        nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(gamma), nat.ptr(beta), film.data_ptr() if film is not None else None,
+        T if film is not None else 1, film.stride(0) if film is not None else 0, _EPS, act, nat.ptr(out), nat.ptr(cA),
+        nat.ptr(cB), nat.ptr(stats), nat.stream()), "lfvdm_gn_apply")
+    return out, cA, cB, stats
+
+
 def _gn_forward(a, b, C0, C1, N, P, gamma, beta, film, T):
     C = C0 + C1
     cA, cB, stats = _new(N, C, like=a), _new(N, C, like=a), _new(N, 32, 2, like=a)
@@ -339,20 +353,18 @@ class ResBlockFn(th.autograd.Function):
         C0 = a.shape[1]
         C1 = b.shape[1] if b is not None else 0
         Cin, Cout, P = C0 + C1, w1.shape[0], H * W
-        cA1, cB1, st1 = _gn_forward(a, b, C0, C1, N, P, g1, be1, None, T)
+        act1, cA1, cB1, st1 = _gn_apply(a, b, C0, C1, N, P, g1, be1, None, T, nat.ACT_SILU)
         h1 = _new(N * P, Cout, like=a)
-        nat.conv_igemm(src0=a, src1=b, C0=C0, C1=C1, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=cA1, coefB=cB1, act=nat.ACT_SILU,
-                       W=_pack(w1), bias=b1, Cout=Cout, out=h1, ldo=Cout)
-        cA2, cB2, st2 = _gn_forward(h1, None, Cout, 0, N, P, g2, be2, film, T)
+        nat.conv_igemm(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=_pack(w1), bias=b1, Cout=Cout, out=h1, ldo=Cout)
+        act2, cA2, cB2, st2 = _gn_apply(h1, None, Cout, 0, N, P, g2, be2, film, T, nat.ACT_SILU)
         out = _new(N * P, Cout, like=a)
-        kw = dict(src0=h1, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=cA2, coefB=cB2, act=nat.ACT_SILU, W=_pack(w2),
-                  bias=b2, Cout=Cout, out=out, ldo=Cout)
+        kw = dict(src0=act2, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=_pack(w2), bias=b2, Cout=Cout, out=out, ldo=Cout)
         if ws is None:
             kw.update(res=a, ldr=Cout)
         else:
             kw.update(s2src0=a, s2src1=b, s2C0=C0, s2C1=C1, W2=ws.view(Cout, Cin), bias2=bs)
         nat.conv_igemm(**kw)
-        ctx.save_for_backward(a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2)
+        ctx.save_for_backward(a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2, act1, act2)
         ctx.params = (w1, b1, w2, b2, ws, bs)
         ctx.dfilm_slot = dfilm_slot
         ctx.geom = (N, H, W, T, C0, C1, Cout)
@@ -360,14 +372,14 @@ class ResBlockFn(th.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2 = ctx.saved_tensors
+        a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2, act1, act2 = ctx.saved_tensors
         N, H, W, T, C0, C1, Cout = ctx.geom
         Cin, P = C0 + C1, H * W
         dout = dout.contiguous()
         geo = dict(N=N, Hs=H, Ws=W, Ho=H, Wo=W)
         pw1, pb1, pw2, pb2, pws, pbs = ctx.params
         # conv2: weight grad on the fused operand act(GN2(h1)) (accumulated in place), data grad -> da2
-        _wgrad_accumulate(pw2, pb2, src0=h1, C0=Cout, coefA=cA2, coefB=cB2, act=nat.ACT_SILU, res=dout, ldr=Cout, **geo)
+        _wgrad_accumulate(pw2, pb2, src0=act2, C0=Cout, res=dout, ldr=Cout, **geo)
         dw2 = db2 = None
         da2 = _new(N * P, Cout, like=a)
         nat.conv_igemm(src0=dout, C0=Cout, W=_pack_t(w2), Cout=Cout, out=da2, ldo=Cout, **geo)
@@ -376,8 +388,7 @@ class ResBlockFn(th.autograd.Function):
         dh1, _, dg2, dbe2, dfilm = _gn_backward(da2, h1, None, Cout, 0, N, P, cA2, cB2, st2, nat.ACT_SILU, g2, be2, film, T,
                                                 dfilm_out=ctx.dfilm_slot)
         # conv1
-        _wgrad_accumulate(pw1, pb1, src0=a, src1=b, C0=C0, C1=C1, coefA=cA1, coefB=cB1, act=nat.ACT_SILU, res=dh1,
-                          ldr=Cout, **geo)
+        _wgrad_accumulate(pw1, pb1, src0=act1, C0=Cin, res=dh1, ldr=Cout, **geo)
         dw1 = db1 = None
         da1 = _new(N * P, Cin, like=a)
         nat.conv_igemm(src0=dh1, C0=Cout, W=_pack_t(w1), Cout=Cin, out=da1, ldo=Cin, **geo)
@@ -403,17 +414,17 @@ class HeadFn(th.autograd.Function):
     @staticmethod
     def forward(ctx, h, g, be, w, b, N, H, W):
         C, Cout, P = h.shape[1], w.shape[0], H * W
-        cA, cB, st = _gn_forward(h, None, C, 0, N, P, g, be, None, 1)
+        act, cA, cB, st = _gn_apply(h, None, C, 0, N, P, g, be, None, 1, nat.ACT_SILU)
         out = _new(N, Cout, H, W, like=h)
-        nat.conv_igemm(src0=h, C0=C, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=cA, coefB=cB, act=nat.ACT_SILU, W=_pack(w), bias=b,
-                       Cout=Cout, out=out, ldo=Cout, out_mode=nat.OUT_NCHW)
-        ctx.save_for_backward(h, g, be, w, cA, cB, st)
+        nat.conv_igemm(src0=act, C0=C, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=_pack(w), bias=b, Cout=Cout, out=out, ldo=Cout,
+                       out_mode=nat.OUT_NCHW)
+        ctx.save_for_backward(h, g, be, w, cA, cB, st, act)
         ctx.geom = (N, H, W)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        h, g, be, w, cA, cB, st = ctx.saved_tensors
+        h, g, be, w, cA, cB, st, act = ctx.saved_tensors
         N, H, W = ctx.geom
         C, Cout, P = h.shape[1], w.shape[0], H * W
         # rows [M][32]: the data-gradient GEMM reduces over Cout, padded to one 32-channel chunk
@@ -423,7 +434,7 @@ class HeadFn(th.autograd.Function):
         geo = dict(N=N, Hs=H, Ws=W, Ho=H, Wo=W)
         gp = th.zeros(CP, 9, C, device=h.device, dtype=th.float32)
         dbp = th.zeros(CP, device=h.device, dtype=th.float32)
-        nat.conv_wgrad(src0=h, C0=C, coefA=cA, coefB=cB, act=nat.ACT_SILU, res=drows, ldr=CP, out=gp, bias=dbp, Cout=CP, **geo)
+        nat.conv_wgrad(src0=act, C0=C, res=drows, ldr=CP, out=gp, bias=dbp, Cout=CP, **geo)
         dw = gp[:Cout].view(Cout, 3, 3, C).permute(0, 3, 1, 2).contiguous()
         wt = th.zeros(C, 9, CP, device=h.device, dtype=th.float32)      # Wt[ci][t][co] = W[co][ci][8-t]
         wt[:, :, :Cout] = w.flip(2, 3).reshape(Cout, C, 9).permute(1, 2, 0)
@@ -515,24 +526,23 @@ class SpatialAttnFn(th.autograd.Function):
     def forward(ctx, x, gn_w, gn_b, wqkv, bqkv, wproj, bproj, N, P, heads):
         C = x.shape[1]
         M = N * P
-        cA, cB, st = _gn_forward(x, None, C, 0, N, P, gn_w, gn_b, None, 1)
+        xn, cA, cB, st = _gn_apply(x, None, C, 0, N, P, gn_w, gn_b, None, 1, nat.ACT_NONE)   # also the residual
         qkv = _new(M, 3 * C, like=x)
-        nat.conv_igemm(src0=x, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=cA, coefB=cB, W=wqkv, bias=bqkv, Cout=3 * C,
-                       out=qkv, ldo=3 * C)
+        nat.conv_igemm(src0=xn, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=wqkv, bias=bqkv, Cout=3 * C, out=qkv, ldo=3 * C)
         o = _new(M, C, like=x)
         lse = _new(N * heads, P, like=x)
         nat.attn_spatial(qkv, o, None, N, P, C, heads, lse=lse)
         y = _new(M, C, like=x)
-        nat.conv_igemm(src0=o, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=wproj, bias=bproj, Cout=C, res=x, ldr=C, resA=cA,
-                       resB=cB, out=y, ldo=C)
-        ctx.save_for_backward(x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o, lse)
+        nat.conv_igemm(src0=o, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=wproj, bias=bproj, Cout=C, res=xn, ldr=C, out=y,
+                       ldo=C)
+        ctx.save_for_backward(x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o, lse, xn)
         ctx.params = (wqkv, bqkv, wproj, bproj)
         ctx.geom = (N, P, heads)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o, lse = ctx.saved_tensors
+        x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o, lse, xn = ctx.saved_tensors
         N, P, heads = ctx.geom
         C = x.shape[1]
         M, Fh = N * P, C // heads
@@ -546,7 +556,7 @@ class SpatialAttnFn(th.autograd.Function):
         # core backward: flash-style HIP kernels (S, P recomputed from q, k and the saved log-sum-exp)
         dqkv = _new(M, 3 * C, like=x)
         nat.attn_spatial_bwd(qkv, o, do, lse, _new(N * heads, P, like=x), dqkv, N, P, C, heads)
-        _wgrad_accumulate(pwq, pbq, src0=x, C0=C, ksize=1, coefA=cA, coefB=cB, res=dqkv, ldr=3 * C, **geo)
+        _wgrad_accumulate(pwq, pbq, src0=xn, C0=C, ksize=1, res=dqkv, ldr=3 * C, **geo)
         dxn = _new(M, C, like=x)   # gradient w.r.t. the normalised tensor: qkv path + residual
         nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
                        ldo=C, **geo)
