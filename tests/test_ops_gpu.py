@@ -427,3 +427,163 @@ def test_conv_splitk_is_exact_and_deterministic(nat):
         first = out.clone()
         nat.conv_igemm_struct(a)
         assert torch.equal(out, first), f"tune code {code} is not reproducible"
+
+
+# ------------------------------------------------------------------------------------------- round-1 additions
+@pytest.mark.parametrize("N,P,C0,C1,film,act", [(4, 256, 64, 0, False, 1), (6, 64, 128, 64, False, 1), (4, 16, 128, 0, True, 1),
+                                                (3, 4, 256, 128, False, 1), (2, 256, 64, 0, False, 0), (2, 2500, 96, 32, True, 1)])
+def test_gn_apply(nat, N, P, C0, C1, film, act):
+    """lfvdm_gn_apply: act(GroupNorm32(cat(a, b)) * (1 + scale) + shift) materialised (nn.py:17-19, unet.py:199-203)
+    plus the coefficient / statistics side outputs, vs torch group_norm in fp64."""
+    C, T = C0 + C1, 2
+    a = rnd("ga/a", N * P, C0) * 1.3 + 0.2
+    b = rnd("ga/b", N * P, C1) if C1 else None
+    gamma, beta = 1 + 0.1 * rnd("ga/g", C), 0.1 * rnd("ga/be", C)
+    fm = 0.3 * rnd("ga/film", N // T, 2 * C) if film else None
+    x = torch.cat([a] + ([b] if C1 else []), dim=1).double().view(N, P, C).permute(0, 2, 1)           # N, C, P
+    ref = F.group_norm(x, 32, gamma.double(), beta.double(), eps=1e-5)
+    if film:
+        f = fm.double().repeat_interleave(T, dim=0)
+        ref = ref * (1 + f[:, :C, None]) + f[:, C:, None]
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(N * P, C)
+    out = torch.full((N * P, C), float("nan"), device="cuda")
+    cA, cB, st = torch.empty(N, C, device="cuda"), torch.empty(N, C, device="cuda"), torch.empty(N, 32, 2, device="cuda")
+    g = [t.cuda() if t is not None else None for t in (a, b, gamma, beta, fm)]
+    nat.check(nat.lib().lfvdm_gn_apply(nat.ptr(g[0]), nat.ptr(g[1]), C0, C1, N, P, nat.ptr(g[2]), nat.ptr(g[3]), nat.ptr(g[4]),
+                                       T if film else 1, 2 * C if film else 0, 1e-5, act, nat.ptr(out), nat.ptr(cA), nat.ptr(cB),
+                                       nat.ptr(st), nat.stream()), "lfvdm_gn_apply")
+    close(out, ref.float(), 3e-5)
+    mean = x.reshape(N, 32, -1).mean(-1)
+    close(st[..., 0], mean.float(), 1e-5)
+    # the coefficients reproduce the same affine map
+    pre = (x.permute(0, 2, 1) * cA.cpu().double()[:, None, :] + cB.cpu().double()[:, None, :]).reshape(N * P, C)
+    close(F.silu(pre) if act else pre, ref.float(), 5e-5)
+
+
+def test_rowdot_backward(nat):
+    """lfvdm_rowdot_bwd (grouped nn.Linear backward) vs autograd: two jobs sharing one input, one with SiLU in front."""
+    M, K = 3, 256
+    x = rnd("rb/x", M, K)
+    Ws = [0.1 * rnd("rb/w0", 96, K), 0.1 * rnd("rb/w1", 40, K)]
+    douts = [rnd("rb/d0", M, 96), rnd("rb/d1", M, 40)]
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in Ws]
+    act = F.silu(xr)
+    act.retain_grad()
+    y0, y1 = act @ wr[0].t(), xr @ wr[1].t()
+    (y0 * douts[0].double()).sum().backward(retain_graph=True, inputs=[act, wr[0]])
+    g_act = act.grad.clone()
+    (y1 * douts[1].double()).sum().backward(inputs=[xr, wr[1]])
+    dev = lambda t: t.cuda().contiguous()
+    xd, Wd, dd = dev(x), [dev(w) for w in Ws], [dev(d) for d in douts]
+    dW = [torch.zeros_like(w) for w in Wd]
+    db = [torch.zeros(w.shape[0], device="cuda") for w in Wd]
+    din = [torch.zeros(M, K, device="cuda"), torch.zeros(M, K, device="cuda")]
+    jobs = [nat.RowdotBwdJob(Wd[0].data_ptr(), xd.data_ptr(), dd[0].data_ptr(), dW[0].data_ptr(), db[0].data_ptr(),
+                             din[0].data_ptr(), K, 96, M, K, 96, K, 1, 0),
+            nat.RowdotBwdJob(Wd[1].data_ptr(), xd.data_ptr(), dd[1].data_ptr(), dW[1].data_ptr(), db[1].data_ptr(),
+                             din[1].data_ptr(), K, 40, M, K, 40, K, 0, 3)]
+    table = nat.jobs_to_device(jobs, "cuda")
+    nat.check(nat.lib().lfvdm_rowdot_bwd(table.data_ptr(), 2, 3 + 2, nat.stream()), "lfvdm_rowdot_bwd")
+    close(dW[0], wr[0].grad.float(), 2e-5)
+    close(dW[1], wr[1].grad.float(), 2e-5)
+    close(db[0], douts[0].sum(0), 1e-5)
+    close(db[1], douts[1].sum(0), 1e-5)
+    close(din[0], g_act.float(), 2e-5)          # gradient w.r.t. the ACTIVATED input of job 0
+    close(din[1], xr.grad.float(), 2e-5)
+
+
+def test_rpe_front_and_backward(nat):
+    """lfvdm_rpe_front(_bwd): hidden layer of an RPENet (rpe.py:20-31) with a strided time projection."""
+    B, T, C = 2, 5, 64
+    rows = B * T * T
+    tp_full = rnd("rf/tp", B, 3 * C)                      # the kernel reads columns [C, 2C) with row stride 3C
+    feats, wd, bd, d_act = rnd("rf/f", rows, 3).abs(), 0.5 * rnd("rf/wd", C, 3), 0.1 * rnd("rf/bd", C), rnd("rf/da", rows, C)
+    tpr = tp_full[:, C:2 * C].double().requires_grad_(True)
+    wdr, bdr = wd.double().requires_grad_(True), bd.double().requires_grad_(True)
+    hid = tpr.repeat_interleave(T * T, 0) + feats.double() @ wdr.t() + bdr
+    ref = F.silu(hid)
+    (ref * d_act.double()).sum().backward()
+    g = {k: v.cuda().contiguous() for k, v in dict(tp=tp_full, f=feats, wd=wd, bd=bd, da=d_act).items()}
+    tp_view = g["tp"][:, C:2 * C]
+    act = torch.empty(rows, C, device="cuda")
+    nat.check(nat.lib().lfvdm_rpe_front(tp_view.data_ptr(), tp_view.stride(0), nat.ptr(g["f"]), nat.ptr(g["wd"]), nat.ptr(g["bd"]),
+                                        nat.ptr(act), B, T * T, C, nat.stream()), "lfvdm_rpe_front")
+    close(act, ref.detach().float(), 2e-5)
+    dtp, dwd, dbd = torch.zeros(B, 2 * C, device="cuda"), torch.zeros(C, 3, device="cuda"), torch.zeros(C, device="cuda")
+    slot = dtp[:, C:]
+    nat.check(nat.lib().lfvdm_rpe_front_bwd(tp_view.data_ptr(), tp_view.stride(0), nat.ptr(g["f"]), nat.ptr(g["wd"]),
+                                            nat.ptr(g["bd"]), nat.ptr(g["da"]), slot.data_ptr(), slot.stride(0), nat.ptr(dwd),
+                                            nat.ptr(dbd), B, T * T, C, nat.stream()), "lfvdm_rpe_front_bwd")
+    close(slot, tpr.grad.float(), 1e-4)
+    close(dwd, wdr.grad.float(), 1e-4)
+    close(dbd, bdr.grad.float(), 1e-4)
+    assert float(dtp[:, :C].abs().max()) == 0.0
+
+
+def test_grouped_pack_and_unpack(nat):
+    """lfvdm_pack_conv_weights == per-weight packing; lfvdm_unpack_conv_grads folds and re-zeroes the accumulators."""
+    ws = [rnd("gp/w0", 64, 32, 3, 3).cuda(), rnd("gp/w1", 96, 64, 1, 1).cuda(), rnd("gp/w2", 32, 128, 3, 3).cuda()]
+    jobs, outs, blk = [], [], 0
+    for w in ws:
+        for tr in (0, 1):
+            Cout, Cin, k, _ = w.shape
+            o = torch.full((Cin, k * k, Cout) if tr else (Cout, k * k, Cin), float("nan"), device="cuda")
+            jobs.append(nat.PackJob(w.data_ptr(), o.data_ptr(), Cout, Cin, k * k, tr, blk, 0))
+            outs.append((w, o, tr))
+            blk += (w.numel() + 1023) // 1024
+    table = nat.jobs_to_device(jobs, "cuda")
+    nat.check(nat.lib().lfvdm_pack_conv_weights(table.data_ptr(), len(jobs), blk, nat.stream()), "lfvdm_pack_conv_weights")
+    for w, o, tr in outs:
+        ref = torch.empty_like(o)
+        (nat.pack_conv_weight_t if tr else nat.pack_conv_weight)(w, ref)
+        assert torch.equal(o, ref)
+        if not tr:
+            assert torch.equal(o, w.permute(0, 2, 3, 1).reshape(o.shape))
+    # unpack: g += unpack(gp); gp = 0
+    gps = [rnd("gp/g0", 64, 9, 32).cuda(), rnd("gp/g2", 32, 9, 128).cuda()]
+    gs = [rnd("gp/a0", 64, 32, 3, 3).cuda(), rnd("gp/a2", 32, 128, 3, 3).cuda()]
+    want = [g + gp.view(gp.shape[0], 3, 3, gp.shape[2]).permute(0, 3, 1, 2) for g, gp in zip(gs, gps)]
+    uj, row0 = [], 0
+    for g, gp in zip(gs, gps):
+        uj.append(nat.UnpackJob(gp.data_ptr(), g.data_ptr(), g.shape[0], g.shape[1], 9, row0))
+        row0 += g.shape[0]
+    ut = nat.jobs_to_device(uj, "cuda")
+    nat.check(nat.lib().lfvdm_unpack_conv_grads(ut.data_ptr(), 2, row0, 9 * 128, nat.stream()), "lfvdm_unpack_conv_grads")
+    for g, w_, gp in zip(gs, want, gps):
+        assert torch.allclose(g, w_, atol=1e-6) and float(gp.abs().max()) == 0.0
+
+
+def test_gn_param_grads(nat):
+    """lfvdm_gn_param_grads vs the closed-form sums it implements (FiLM and plain)."""
+    N, T, C = 6, 3, 96
+    sums, gamma, beta = rnd("gg/s", N, C, 2), 1 + 0.1 * rnd("gg/g", C), 0.1 * rnd("gg/b", C)
+    film = 0.3 * rnd("gg/f", N // T, 2 * C)
+    s1, s2 = sums[..., 0].double(), sums[..., 1].double()
+    sc1 = 1 + film[:, :C].double().repeat_interleave(T, 0)
+    for use_film in (True, False):
+        dg0, db0 = rnd("gg/dg", C), rnd("gg/db", C)
+        dg, db = dg0.cuda().clone(), db0.cuda().clone()
+        dfilm = torch.full((N // T, 2 * C), float("nan"), device="cuda") if use_film else None
+        g = [t.cuda() for t in (sums, gamma, beta, film)]
+        nat.check(nat.lib().lfvdm_gn_param_grads(nat.ptr(g[0]), nat.ptr(g[1]), nat.ptr(g[2]), nat.ptr(g[3]) if use_film else None,
+                                                 2 * C if use_film else 0, T, nat.ptr(dg), nat.ptr(db), nat.ptr(dfilm),
+                                                 2 * C if use_film else 0, N, C, nat.stream()), "lfvdm_gn_param_grads")
+        if use_film:
+            close(dg, (dg0.double() + (s2 * sc1).sum(0)).float(), 2e-5)
+            close(db, (db0.double() + (s1 * sc1).sum(0)).float(), 2e-5)
+            dsc = (s2 * gamma.double() + s1 * beta.double()).view(N // T, T, C).sum(1)
+            close(dfilm, torch.cat([dsc, s1.view(N // T, T, C).sum(1)], 1).float(), 2e-5)
+        else:
+            close(dg, (dg0.double() + s2.sum(0)).float(), 2e-5)
+            close(db, (db0.double() + s1.sum(0)).float(), 2e-5)
+
+
+def test_sampler_tick(nat):
+    t = torch.tensor([5, 0, 999], dtype=torch.int64, device="cuda")
+    table = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.25
+    mt = torch.zeros(3, device="cuda")
+    nat.check(nat.lib().lfvdm_sampler_tick(t.data_ptr(), table.data_ptr(), mt.data_ptr(), 3, nat.stream()), "lfvdm_sampler_tick")
+    assert t.tolist() == [4, 0, 998] and mt.tolist() == [1.0, 0.0, 249.5]
