@@ -383,7 +383,8 @@ def main():
                                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom_name), "kernel": dom_name,
                                "launches_per_step": dom["launches"],
                                "avg_launch_us": round(1000.0 * dom["ms"] / dom["launches"], 2),
-                               "note": "fp32 MFMA; achieved = algorithmic conv/GEMM FLOPs of these launches / their HIP-event time"}
+                               "note": "fp32 MFMA (shares the vector ALUs with VALU on gfx950: 157.3 TFLOP/s is the peak of both together); "
+                                       "achieved = algorithmic conv/GEMM FLOPs of these launches / their HIP-event time"}
             all_conv_flops = sum(g["flops"] for g in convs.values())
             all_conv_ms = sum(g["ms"] for g in convs.values())
             out["breakdown"] = {"eager_sum_ms": round(tot_ms, 4), "launches": len(sampler.plan.steps),
