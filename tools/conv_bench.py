@@ -1,6 +1,6 @@
 """Developer aid: steady-state throughput of the conv kernel on large problems + per-config sweep."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd"))
 import torch as th
 from improved_diffusion import _native as nat

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd"))
 sys.path.insert(0, ROOT)
 import torch as th  # noqa: E402

@@ -1,7 +1,7 @@
 """Developer aid: per-step wall clock of the training leg (cfg C), split into micro-step (graph replay or eager)
-and optimizer, for rocprofv3 / wall-clock inspection.  usage: python tools_train_profile.py [steps]"""
+and optimizer, for rocprofv3 / wall-clock inspection.  usage: python tools/train_profile.py [steps]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd"))
 sys.path.insert(0, ROOT)
 import argparse as ap

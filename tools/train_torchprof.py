@@ -1,7 +1,7 @@
 """Developer aid: attribute the remaining torch-library kernels of an eager training step to ATen ops (with shapes)."""
 import os, sys
 os.environ["LFVDM_TRAIN_GRAPH"] = "0"
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd"))
 sys.path.insert(0, ROOT)
 import argparse as ap

@@ -1,6 +1,6 @@
 """Developer aid: time lfvdm_conv_wgrad on the layer shapes of cfg C (graph replay of 10 launches)."""
 import os, sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd"))
 import torch as th
 from improved_diffusion import _native as nat
