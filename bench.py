@@ -279,7 +279,7 @@ def bench_pixel(dev, steps):
 
 def pmc_traffic(kernel_name):
     """HBM-side bytes per launch of one kernel from the committed rocprofv3 counter passes
-    (profiles/r01_pmc_traffic.json, produced by tools_pmc_target.py + tools_pmc_summarize.py); None if absent."""
+    (profiles/r01_pmc_traffic.json, produced by tools/pmc_target.py + tools/pmc_summarize.py); None if absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             return json.load(f)["kernels"].get(kernel_name, {}).get("hbm_bytes_per_launch")
