@@ -93,11 +93,14 @@ struct ChunkRegs {
 // for the padding iterations of k-groups that own fewer chunks than the others.  All per-lane
 // address arithmetic is 32-bit (element offsets < 2^31 is checked by the launcher); the chunk
 // parameters are wave-uniform and live in SGPRs.
-template <class CF>
+// SIMPLE = plain convolution (no fused skip segment, no upsampling, no GroupNorm coefficients): every wave-uniform
+// branch disappears, the whole body is one basic block that the scheduler can interleave with the MFMAs of the
+// chunk in flight (scalar address arithmetic and loads issue in the shadow of the matrix instructions).
+template <class CF, bool SIMPLE = false>
 __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bool live, int kfirst, int NK1, int taps,
                                             int Cin, const RowInfo (&ri)[CF::AE], const int (&wrow)[CF::WE], int col,
                                             ChunkRegs<CF::AE, CF::WE>& R) {
-    const bool main_seg = kc < NK1;
+    const bool main_seg = SIMPLE ? true : kc < NK1;
     // ---- wave-uniform chunk parameters (scalar selects, no divergent code) ----
     // (sel() takes its operands by value: a plain `c ? p.a : p.b` is an lvalue select, i.e. a load from
     // a selected ADDRESS, which pins the whole argument struct in scratch memory)
@@ -112,7 +115,7 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
     const float* src = sel(main_seg, sel(second, p.src1, p.src0), sel(second, p.s2src1, p.s2src0));
     const int Csrc = sel(main_seg, sel(second, p.C1, p.C0), sel(second, p.s2C1, p.s2C0));
     const int cl = second ? cc - c0 : cc;
-    const int upmode = sel(main_seg, p.up, 0);      // 0 none, 1 nearest x2, 2 zero-insertion x2 (transposed conv)
+    const int upmode = SIMPLE ? 0 : sel(main_seg, p.up, 0);   // 0 none, 1 nearest x2, 2 zero-insertion x2 (transposed conv)
     const int up = upmode ? 1 : 0;
     const int stride = sel(main_seg, p.stride, 1);
     const int Hst = sel(main_seg, p.Hs, p.Ho);      // stored source extent
@@ -123,8 +126,8 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
     const int wld = sel(main_seg, taps * Cin, p.s2C0 + p.s2C1);
 
     R.main_seg = main_seg;
-    R.coef_cc = (p.coefA && main_seg && live && (tap == 0 || kc == kfirst)) ? cc : -1;
-    if (ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH && R.coef_cc >= 0) {   // wave-uniform
+    R.coef_cc = (!SIMPLE && p.coefA && main_seg && live && (tap == 0 || kc == kfirst)) ? cc : -1;
+    if (!SIMPLE && ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH && R.coef_cc >= 0) {   // wave-uniform
 #pragma unroll
         for (int j = 0; j < CF::AE; ++j) {
             R.ca[j < (ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH ? CF::AE : 1) ? j : 0] = ld4(p.coefA + (unsigned)(ri[j].n * Cin + cc + col));
@@ -133,14 +136,14 @@ __device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bo
     }
     unsigned am = 0;
     const float* srcc = src + cl + col;
-    if (!main_seg) {
+    if (!SIMPLE && !main_seg) {
         // fused 1x1 skip segment: row m of a raw source at output resolution
 #pragma unroll
         for (int j = 0; j < CF::AE; ++j) {
             am |= ((live && ri[j].valid) ? 1u : 0u) << j;
             R.a[j] = ld4(srcc + (unsigned)__mul24(ri[j].m, Csrc));
         }
-    } else if (!up) {
+    } else if (SIMPLE || !up) {
         // common case: the tap is a wave-uniform pixel offset from the precomputed centre pixel
         const int tappix = dy * Wst + dx;
 #pragma unroll
@@ -209,7 +212,7 @@ __device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs
     }
 }
 
-template <int WM, int WN, int WK, int NT, int KCH, int PRO>
+template <int WM, int WN, int WK, int NT, int KCH, int PRO, bool SIMPLE>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfvdm_conv_args p_in, int hyb_nfull, int hyb_kz) {
     const lfvdm_conv_args p = p_in;   // private SSA copy: helpers take it by reference (keeps it out of scratch)
     using CF = Cfg<WM, WN, WK, NT, KCH>;
@@ -323,8 +326,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
 #pragma unroll
     for (int j = 0; j < CF::AE; ++j) { ca[j] = (f32x4){1.f, 1.f, 1.f, 1.f}; cb[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int klast = max(kend - 1, 0);
-    issue_chunk<CF>(p, min(kbeg, klast), kbeg < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R0);
-    issue_chunk<CF>(p, min(kbeg + 1, klast), kbeg + 1 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R1);
+    issue_chunk<CF, SIMPLE>(p, min(kbeg, klast), kbeg < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R0);
+    issue_chunk<CF, SIMPLE>(p, min(kbeg + 1, klast), kbeg + 1 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R1);
 
     STAMP(1);
     const int fra = (32 * wm + (lane & 31)) * LDR + (lane >> 5) * 4;                    // A fragment offset
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
 
 #define LFVDM_FINISH(ST_, R_) finish_chunk<CF, PRO>(p, R_, ca, cb, wmask, ri, Cin, (ST_), (ST_) + BM * LDR, gt)
 #define LFVDM_ISSUE(KC_, R_) \
-    issue_chunk<CF>(p, min((KC_) + 2, klast), (KC_) + 2 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R_)
+    issue_chunk<CF, SIMPLE>(p, min((KC_) + 2, klast), (KC_) + 2 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R_)
 #define LFVDM_MFMA(ST_)                                                                                        \
     do {                                                                                                       \
         const float* st_ = (ST_);                                                                              \
@@ -540,12 +543,12 @@ inline HybridPlan hybrid_plan(long tiles) {
     return h;
 }
 
-template <int WM, int WN, int WK, int NT, int KCH, int PRO>
+template <int WM, int WN, int WK, int NT, int KCH, int PRO, bool SIMPLE>
 int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
     using CF = Cfg<WM, WN, WK, NT, KCH>;
     static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::LDS_BYTES) != hipSuccess)
             return LFVDM_E_LAUNCH;
         attr_set = true;
@@ -553,22 +556,25 @@ int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
     const long MT = (M + CF::BM - 1) / CF::BM, NT2 = (a->Cout + CF::BN - 1) / CF::BN;
     if (kz == kHybridKz) {   // tail split (see the kernel): flat grid
         const HybridPlan h = hybrid_plan(MT * NT2);
-        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>), dim3((unsigned)(h.nfull + h.tail * h.kz)),
+        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE>), dim3((unsigned)(h.nfull + h.tail * h.kz)),
                            dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, (int)h.nfull, h.kz);
         LFVDM_CHECK_LAUNCH();
         return LFVDM_OK;
     }
     const dim3 grid((unsigned)MT, (unsigned)NT2, (unsigned)kz);
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
 
 template <int WM, int WN, int WK, int NT, int KCH>
 int launch_kc(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
-    if (!a->coefA) return launch_pro<WM, WN, WK, NT, KCH, 0>(a, s, M, kz);
-    if (a->act == LFVDM_ACT_SILU) return launch_pro<WM, WN, WK, NT, KCH, 2>(a, s, M, kz);
-    return launch_pro<WM, WN, WK, NT, KCH, 1>(a, s, M, kz);
+    if (!a->coefA) {
+        if (a->up == 0 && a->s2C0 + a->s2C1 == 0) return launch_pro<WM, WN, WK, NT, KCH, 0, true>(a, s, M, kz);
+        return launch_pro<WM, WN, WK, NT, KCH, 0, false>(a, s, M, kz);
+    }
+    if (a->act == LFVDM_ACT_SILU) return launch_pro<WM, WN, WK, NT, KCH, 2, false>(a, s, M, kz);
+    return launch_pro<WM, WN, WK, NT, KCH, 1, false>(a, s, M, kz);
 }
 
 template <int WM, int WN, int WK, int NT>
