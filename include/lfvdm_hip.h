@@ -223,7 +223,7 @@ int lfvdm_rowdot(const lfvdm_rowdot_job* jobs_dev, int njobs, int total_rows, vo
 /* Backward of the same grouped linears (autograd of nn.Linear, train_util.py:328): per job
  *   dW[o][k] += sum_m dout[m][o] * actin(in[m][k]);  db[o] += sum_m dout[m][o]   (single writer, plain +=)
  *   din[m][k] += sum_o dout[m][o] * W[o][k]   (gradient w.r.t. the ACTIVATED input, float atomics; NULL = skip)
- * One wave per 32 output rows: task0 = first task of the job (prefix sum of ceil(O/32)), K % 4 == 0. */
+ * One wave per 8 output rows: task0 = first task of the job (prefix sum of ceil(O/8)), K % 4 == 0. */
 typedef struct lfvdm_rowdot_bwd_job {
     const float* W;    /* [O][K] */
     const float* in;   /* as in the forward job */

@@ -413,16 +413,22 @@ void attn_temporal_bwd_rpe_kernel(const float* __restrict__ qkv, const float* __
         const size_t a0 = (term == 2) ? (size_t)row0 * T + i : (size_t)i * T + row0;
         const size_t a1 = (term == 2) ? (size_t)row1 * T + i : (size_t)i * T + row1;
         const bool two = T > 16;
-#pragma unroll 32
-        for (int pb = 0; pb < P; pb += 4) {   // deep unroll: the loop is a chain of dependent-latency loads otherwise
-            const int p = pb + kk;
-            const bool pok = p < P;
-            const float bv = (pok && colok) ? Bsrc[(size_t)p * bstride] : 0.f;
-            const float av0 = (pok && row0 < T) ? Asrc[(size_t)p * astride + a0] : 0.f;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv, acc[0], 0, 0, 0);
-            if (two) {
-                const float av1 = (pok && row1 < T) ? Asrc[(size_t)p * astride + a1] : 0.f;
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv, acc[1], 0, 0, 0);
+        // 8 k-steps (32 pixels) per iteration: all 24 loads are issued before the first MFMA needs one (the loop is a
+        // chain of dependent-latency loads otherwise)
+        for (int pb = 0; pb < P; pb += 32) {
+            float bv[8], av0[8], av1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = pb + 4 * u + kk;
+                const bool pok = p < P;
+                bv[u] = (pok && colok) ? Bsrc[(size_t)p * bstride] : 0.f;
+                av0[u] = (pok && row0 < T) ? Asrc[(size_t)p * astride + a0] : 0.f;
+                av1[u] = (two && pok && row1 < T) ? Asrc[(size_t)p * astride + a1] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[u], bv[u], acc[0], 0, 0, 0);
+                if (two) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[u], bv[u], acc[1], 0, 0, 0);
             }
         }
         float* out = (term == 0 ? dRk : term == 1 ? dRv : dRq) + ((size_t)(b * T + i) * T) * C + h * F + col;

@@ -304,11 +304,11 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const lfvdm_rowdot_job* __r
     }
 }
 
-// Backward of the grouped small-M linears: one wave per block of 32 output rows of one job.
+// Backward of the grouped small-M linears: one wave per block of RDB_ROWS output rows of one job.
 //   dW[o][k] += sum_m dout[m][o] * actin(in[m][k]);  db[o] += sum_m dout[m][o];
 //   din[m][k] += sum_o dout[m][o] * W[o][k]        (gradient w.r.t. the ACTIVATED input; float atomics, may be NULL)
-// Every W row is read once; the din partial of the 32 rows lives in registers and is added once per wave.
-constexpr int RDB_ROWS = 32;
+// Every W row is read once; the din partial of the wave's rows lives in registers and is added once per wave.
+constexpr int RDB_ROWS = 8;    // rows per wave: the dW read-modify-write chain of a wave is serial, so keep it short
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_job* __restrict__ jobs, int njobs, int total_tasks) {
     const int lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);

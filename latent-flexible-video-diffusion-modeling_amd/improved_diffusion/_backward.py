@@ -619,7 +619,7 @@ class _EmbedNet:
                                          mode, task0))
             views[key] = (st["flat"][:, off:off + O], st["dflat"][:, off:off + O])
             off += O
-            task0 += (O + 31) // 32
+            task0 += (O + 7) // 8
         st["demb"] = z(B, ted)
         st["dh0"] = z(B, ted)
         bwd1 = [nat.RowdotBwdJob(P(lin1.weight), P(st["h0"]), P(st["demb"]), G(lin1.weight), G(lin1.bias), P(st["dh0_act"]), ted,
@@ -628,7 +628,7 @@ class _EmbedNet:
                                  ted, 0, 2, 0)]
         J = lambda jobs: nat.jobs_to_device(jobs, dev)
         st.update(views=views, j_f0=J(fwd0), j_f1=J(fwd1), j_fg=J(fwdg), n_g=len(fwdg), j_bg=J(bwdg), tasks_g=task0, j_b1=J(bwd1),
-                  j_b0=J(bwd0), tasks_t=(ted + 31) // 32,
+                  j_b0=J(bwd0), tasks_t=(ted + 7) // 8,
                   key=(id(m), B, str(dev), tuple(p.data_ptr() for p in params), tuple(_grad_of(p).data_ptr() for p in params)))
         return st
 

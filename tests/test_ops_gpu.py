@@ -484,9 +484,9 @@ def test_rowdot_backward(nat):
     jobs = [nat.RowdotBwdJob(Wd[0].data_ptr(), xd.data_ptr(), dd[0].data_ptr(), dW[0].data_ptr(), db[0].data_ptr(),
                              din[0].data_ptr(), K, 96, M, K, 96, K, 1, 0),
             nat.RowdotBwdJob(Wd[1].data_ptr(), xd.data_ptr(), dd[1].data_ptr(), dW[1].data_ptr(), db[1].data_ptr(),
-                             din[1].data_ptr(), K, 40, M, K, 40, K, 0, 3)]
+                             din[1].data_ptr(), K, 40, M, K, 40, K, 0, 12)]
     table = nat.jobs_to_device(jobs, "cuda")
-    nat.check(nat.lib().lfvdm_rowdot_bwd(table.data_ptr(), 2, 3 + 2, nat.stream()), "lfvdm_rowdot_bwd")
+    nat.check(nat.lib().lfvdm_rowdot_bwd(table.data_ptr(), 2, 12 + 5, nat.stream()), "lfvdm_rowdot_bwd")
     close(dW[0], wr[0].grad.float(), 2e-5)
     close(dW[1], wr[1].grad.float(), 2e-5)
     close(db[0], douts[0].sum(0), 1e-5)
