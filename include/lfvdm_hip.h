@@ -125,7 +125,8 @@ int lfvdm_unpack_conv_grad(const float* g_packed, float* g_oihw, int Cout, int C
 
 /* Grouped weight packing (one launch per training step instead of two per convolution): job = one OIHW weight ->
  * [Cout][k*k][Cin] (transposed = 0, as lfvdm_pack_conv_weight) or [Cin][k*k][Cout] flipped (transposed = 1, as
- * lfvdm_pack_conv_weight_t).  blk0 = first workgroup of the job (1024 elements per workgroup), jobs sorted by blk0. */
+ * lfvdm_pack_conv_weight_t).  blk0 = first workgroup of the job (one workgroup per tile of 32 filters x 32 input
+ * channels: ceil(Cout/32)*ceil(Cin/32) per job), jobs sorted by blk0; k*k <= 9. */
 typedef struct lfvdm_pack_job {
     const float* src;
     float* dst;

@@ -403,33 +403,41 @@ __global__ __launch_bounds__(256) void unpack_conv_grads_kernel(const lfvdm_unpa
 }
 
 // Grouped weight packing for a training step: every job packs one OIHW weight into the forward operand layout
-// [Cout][tap][Cin] (transposed = 0) or the data-gradient layout [Cin][tap][Cout] with flipped taps (transposed = 1);
-// a workgroup handles 1024 consecutive output elements of one job.
+// [Cout][tap][Cin] (transposed = 0) or the data-gradient layout [Cin][tap][Cout] with flipped taps (transposed = 1).
+// A workgroup moves one tile of 32 filters x 32 input channels x all taps through LDS: the source is read in runs of
+// 32*taps contiguous floats, both destination layouts are written in runs of 32 contiguous floats.
 __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const lfvdm_pack_job* __restrict__ jobs, int njobs) {
+    __shared__ float tile[32 * (32 * 9 + 1)];
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {                       // last job with blk0 <= blockIdx.x
         const int mid = (lo + hi + 1) >> 1;
         if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const lfvdm_pack_job J = jobs[lo];
-    const size_t total = (size_t)J.Cout * J.Cin * J.taps;
-    const size_t i0 = (size_t)(blockIdx.x - J.blk0) * 1024 + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const size_t i = i0 + 256 * k;
-        if (i >= total) break;
-        if (J.transposed) {
-            const int co = (int)(i % J.Cout);
-            const size_t t2 = i / J.Cout;
-            const int t = (int)(t2 % J.taps);
-            const int ci = (int)(t2 / J.taps);
-            J.dst[i] = J.src[((size_t)co * J.Cin + ci) * J.taps + (J.taps - 1 - t)];
-        } else {
-            const int ci = (int)(i % J.Cin);
-            const size_t t2 = i / J.Cin;
-            const int tap = (int)(t2 % J.taps);
-            const int co = (int)(t2 / J.taps);
-            J.dst[i] = J.src[((size_t)co * J.Cin + ci) * J.taps + tap];
+    const int tci = (J.Cin + 31) / 32;
+    const int b = blockIdx.x - J.blk0;
+    const int co0 = (b / tci) * 32, ci0 = (b % tci) * 32;
+    const int nco = min(32, J.Cout - co0), nci = min(32, J.Cin - ci0);
+    const int taps = J.taps;
+    const int row = 32 * taps + 1;          // padded LDS stride between filters
+    const int run = nci * taps;             // contiguous source floats per filter
+    for (int e = threadIdx.x; e < nco * run; e += 256) {
+        const int c = e / run, r = e - c * run;
+        tile[c * row + r] = J.src[((size_t)(co0 + c) * J.Cin + ci0) * taps + r];
+    }
+    __syncthreads();
+    const int n = nco * nci * taps;
+    if (J.transposed) {
+        for (int e = threadIdx.x; e < n; e += 256) {          // (ci, t, co) with co fastest
+            const int c = e % nco, r = e / nco;
+            const int t = r % taps, i = r / taps;
+            J.dst[((size_t)(ci0 + i) * taps + t) * J.Cout + co0 + c] = tile[c * row + i * taps + (taps - 1 - t)];
+        }
+    } else {
+        for (int e = threadIdx.x; e < n; e += 256) {          // (co, t, ci) with ci fastest
+            const int i = e % nci, r = e / nci;
+            const int t = r % taps, c = r / taps;
+            J.dst[((size_t)(co0 + c) * taps + t) * J.Cin + ci0 + i] = tile[c * row + i * taps + t];
         }
     }
 }

@@ -148,8 +148,9 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
     __shared__ float gst_all[4][4][32];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long sample = (long)blockIdx.x * 4 + wave;
-    if (sample >= (long)B * P) return;
+    const long sample_raw = (long)blockIdx.x * 4 + wave;
+    const bool live = sample_raw < (long)B * P;        // (no early return: the workgroup meets at a barrier below)
+    const long sample = live ? sample_raw : 0;
     float* chx = ch_all[wave][0];   // per-channel sums (reused per pass)
     float* chd = ch_all[wave][1];
     float* chdx = ch_all[wave][2];
@@ -213,12 +214,22 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
         const float inv = 1.0f / (float)(cg * T);
         gS1[lane] = S1 * inv; gS2[lane] = S2 * inv;
     }
-    // parameter gradients: one atomic per (sample, channel)
-    for (int ch = lane; ch < C; ch += 64) {
-        atomicAdd(dgamma + ch, chdx[ch]);
-        atomicAdd(dbeta + ch, chd[ch]);
+    // parameter gradients: the four samples of the workgroup are summed first, then one atomic per channel
+    // (all B*P samples hit the same C addresses: fewer, fatter atomics)
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        float g = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if ((long)blockIdx.x * 4 + w < (long)B * P) {
+                g += ch_all[w][2][ch];
+                bsum += ch_all[w][1][ch];
+            }
+        }
+        atomicAdd(dgamma + ch, g);
+        atomicAdd(dbeta + ch, bsum);
     }
-    wave_lds_fence();
+    if (!live) return;
     const int E = T * Q;
     for (int e = lane; e < E; e += 64) {
         const int t = e / Q, q = e - t * Q;

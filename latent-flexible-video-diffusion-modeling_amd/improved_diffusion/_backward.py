@@ -93,7 +93,7 @@ class _WeightPacks:
             jobs, blk = [], 0
             for (ptr_, (Cout, Cin, k, _k), tr), e in self.ent.items():
                 jobs.append(nat.PackJob(ptr_, e[1].data_ptr(), Cout, Cin, k * k, int(tr), blk, 0))
-                blk += (Cout * Cin * k * k + 1023) // 1024
+                blk += ((Cout + 31) // 32) * ((Cin + 31) // 32)
             dev = next(iter(self.ent.values()))[1].device
             self.table, self.blocks, self.njobs = nat.jobs_to_device(jobs, dev), blk, len(jobs)
         nat.check(nat.lib().lfvdm_pack_conv_weights(self.table.data_ptr(), self.njobs, self.blocks, nat.stream()),

@@ -525,7 +525,8 @@ def test_rpe_front_and_backward(nat):
 
 def test_grouped_pack_and_unpack(nat):
     """lfvdm_pack_conv_weights == per-weight packing; lfvdm_unpack_conv_grads folds and re-zeroes the accumulators."""
-    ws = [rnd("gp/w0", 64, 32, 3, 3).cuda(), rnd("gp/w1", 96, 64, 1, 1).cuda(), rnd("gp/w2", 32, 128, 3, 3).cuda()]
+    ws = [rnd("gp/w0", 64, 32, 3, 3).cuda(), rnd("gp/w1", 96, 64, 1, 1).cuda(), rnd("gp/w2", 32, 128, 3, 3).cuda(),
+          rnd("gp/w3", 4, 40, 3, 3).cuda(), rnd("gp/w4", 72, 5, 3, 3).cuda()]
     jobs, outs, blk = [], [], 0
     for w in ws:
         for tr in (0, 1):
@@ -533,7 +534,7 @@ def test_grouped_pack_and_unpack(nat):
             o = torch.full((Cin, k * k, Cout) if tr else (Cout, k * k, Cin), float("nan"), device="cuda")
             jobs.append(nat.PackJob(w.data_ptr(), o.data_ptr(), Cout, Cin, k * k, tr, blk, 0))
             outs.append((w, o, tr))
-            blk += (w.numel() + 1023) // 1024
+            blk += ((Cout + 31) // 32) * ((Cin + 31) // 32)
     table = nat.jobs_to_device(jobs, "cuda")
     nat.check(nat.lib().lfvdm_pack_conv_weights(table.data_ptr(), len(jobs), blk, nat.stream()), "lfvdm_pack_conv_weights")
     for w, o, tr in outs:
