@@ -345,11 +345,22 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
 
 
 # ----------------------------------------------------------------------------- ResBlock
+dropout_log = None      # tests set this to a list to record the keep masks drawn by ResBlockFn
+
+
+def _dropout_keep(act, p):
+    """Inverted-dropout factors for nn.Dropout(p) in training mode (unet.py:166): 0 or 1/(1-p) per element."""
+    keep = (th.rand_like(act) >= p).to(act.dtype).mul_(1.0 / (1.0 - p))
+    if dropout_log is not None:
+        dropout_log.append(keep)
+    return keep
+
+
 class ResBlockFn(th.autograd.Function):
     """reference unet.py:194-207 with use_scale_shift_norm=True, on a virtual concat input (a | b)."""
 
     @staticmethod
-    def forward(ctx, a, b, film, g1, be1, w1, b1, g2, be2, w2, b2, ws, bs, N, H, W, T, dfilm_slot=None):
+    def forward(ctx, a, b, film, g1, be1, w1, b1, g2, be2, w2, b2, ws, bs, N, H, W, T, dfilm_slot=None, drop_p=0.0):
         C0 = a.shape[1]
         C1 = b.shape[1] if b is not None else 0
         Cin, Cout, P = C0 + C1, w1.shape[0], H * W
@@ -357,6 +368,10 @@ class ResBlockFn(th.autograd.Function):
         h1 = _new(N * P, Cout, like=a)
         nat.conv_igemm(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=_pack(w1), bias=b1, Cout=Cout, out=h1, ldo=Cout)
         act2, cA2, cB2, st2 = _gn_apply(h1, None, Cout, 0, N, P, g2, be2, film, T, nat.ACT_SILU)
+        keep = None
+        if drop_p > 0.0:
+            keep = _dropout_keep(act2, drop_p)
+            act2.mul_(keep)
         out = _new(N * P, Cout, like=a)
         kw = dict(src0=act2, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=_pack(w2), bias=b2, Cout=Cout, out=out, ldo=Cout)
         if ws is None:
@@ -364,7 +379,7 @@ class ResBlockFn(th.autograd.Function):
         else:
             kw.update(s2src0=a, s2src1=b, s2C0=C0, s2C1=C1, W2=ws.view(Cout, Cin), bias2=bs)
         nat.conv_igemm(**kw)
-        ctx.save_for_backward(a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2, act1, act2)
+        ctx.save_for_backward(a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2, act1, act2, keep)
         ctx.params = (w1, b1, w2, b2, ws, bs)
         ctx.dfilm_slot = dfilm_slot
         ctx.geom = (N, H, W, T, C0, C1, Cout)
@@ -372,7 +387,7 @@ class ResBlockFn(th.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2, act1, act2 = ctx.saved_tensors
+        a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2, act1, act2, keep = ctx.saved_tensors
         N, H, W, T, C0, C1, Cout = ctx.geom
         Cin, P = C0 + C1, H * W
         dout = dout.contiguous()
@@ -383,6 +398,8 @@ class ResBlockFn(th.autograd.Function):
         dw2 = db2 = None
         da2 = _new(N * P, Cout, like=a)
         nat.conv_igemm(src0=dout, C0=Cout, W=_pack_t(w2), Cout=Cout, out=da2, ldo=Cout, **geo)
+        if keep is not None:
+            da2.mul_(keep)
         if ctx.dfilm_slot is not None:
             _embed.ensure_backward_queued()
         dh1, _, dg2, dbe2, dfilm = _gn_backward(da2, h1, None, Cout, 0, N, P, cA2, cB2, st2, nat.ACT_SILU, g2, be2, film, T,
@@ -404,7 +421,7 @@ class ResBlockFn(th.autograd.Function):
             dxa = dxa + dsk[:, :C0]
             if dxb is not None:
                 dxb = dxb + dsk[:, C0:]
-        return (dxa, dxb, dfilm, dg1, dbe1, dw1, db1, dg2, dbe2, dw2, db2, dws, dbs, None, None, None, None, None)
+        return (dxa, dxb, dfilm, dg1, dbe1, dw1, db1, dg2, dbe2, dw2, db2, dws, dbs, None, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------- output head
@@ -770,12 +787,12 @@ class UNetFunction:
             for layer in blk:
                 if isinstance(layer, ResBlock):
                     film, slot = views[layer] if views is not None else (layer.emb_layers[1](semb), None)
-                    sk = layer.skip_connection
+                    sk, drop = layer.skip_connection, layer.out_layers[2]
                     ws, bs = (None, None) if isinstance(sk, nn.Identity) else (sk.weight, sk.bias)
                     h = ResBlockFn.apply(h, b, film, layer.in_layers[0].weight, layer.in_layers[0].bias,
                                          layer.in_layers[2].weight, layer.in_layers[2].bias, layer.out_layers[0].weight,
                                          layer.out_layers[0].bias, layer.out_layers[3].weight, layer.out_layers[3].bias,
-                                         ws, bs, N, Hc, Wc, T, slot)
+                                         ws, bs, N, Hc, Wc, T, slot, drop.p if drop.training else 0.0)
                     b = None
                 elif isinstance(layer, FactorizedAttentionBlock):
                     ta, sa = layer.temporal_attention, layer.spatial_attention

@@ -436,7 +436,8 @@ class Engine:
     def forward(self, x, x0, timesteps, frame_indices, obs_mask, latent_mask, return_attn_weights=False):
         B, T, Cx, H, W = x.shape
         grad_needed = th.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.model.parameters()))
-        if grad_needed:
+        # nn.Dropout is live in train() mode even without gradients (unet.py:166): the plan has no dropout stage
+        if grad_needed or (self.model.training and self.model.dropout > 0):
             from ._autograd import unet_apply
             return unet_apply(self, x, x0, timesteps, frame_indices, obs_mask, latent_mask, return_attn_weights)
         pl = self.plan(B, T, H, W, return_attn_weights)

@@ -149,8 +149,9 @@ def timestep_embedding(t, dim, max_period=10000.0, dtype=torch.float32):
     return emb
 
 
-def res_block(sd, p, x, emb, use_scale_shift_norm=True):
-    """ResBlock._forward, unet.py:194-207 (dropout is the identity at p=0 / eval)."""
+def res_block(sd, p, x, emb, use_scale_shift_norm=True, keep=None):
+    """ResBlock._forward, unet.py:194-207.  Dropout (unet.py:166) is the identity at p=0 / eval; in training mode
+    it multiplies SiLU(h) by ``keep`` (0 or 1/(1-p) per element, shape of h) - the caller supplies the draw."""
     h = group_norm32(x, sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"])
     h = F.conv2d(silu(h), sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"], padding=1)
     e = F.linear(silu(emb), sd[p + ".emb_layers.1.weight"], sd[p + ".emb_layers.1.bias"])[:, :, None, None]
@@ -160,7 +161,10 @@ def res_block(sd, p, x, emb, use_scale_shift_norm=True):
         h = group_norm32(h, gw, gb) * (1 + scale) + shift
     else:
         h = group_norm32(h + e, gw, gb)
-    h = F.conv2d(silu(h), sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
+    h = silu(h)
+    if keep is not None:
+        h = h * keep
+    h = F.conv2d(h, sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
     if (p + ".skip_connection.weight") in sd:
         x = F.conv2d(x, sd[p + ".skip_connection.weight"], sd[p + ".skip_connection.bias"])
     return x + h
@@ -238,9 +242,11 @@ def factorized_attention(sd, p, x, temb, attn_mask, T, frame_indices, heads, att
 
 # --------------------------------------------------------------------------- full forward
 def unet_forward(sd, cfg, x, x0, timesteps, frame_indices, obs_mask, latent_mask,
-                 return_attn_weights=False):
+                 return_attn_weights=False, dropout_keep=None):
     """UNetVideoModel.forward, unet.py:428-464.  x,x0: (B,T,C,H,W); timesteps (B,) (already
-    rescaled floats or ints); masks (B,T,1,1,1).  Returns (out (B,T,Cout,H,W), attns|None)."""
+    rescaled floats or ints); masks (B,T,1,1,1).  Returns (out (B,T,Cout,H,W), attns|None).
+    ``dropout_keep``: optional list of per-ResBlock dropout factors (N,C,H,W) in execution order (training mode)."""
+    keeps = list(dropout_keep) if dropout_keep is not None else None
     B, T, C, H, W = x.shape
     heads = cfg["num_heads"]
     ssn = cfg["use_scale_shift_norm"]
@@ -259,7 +265,7 @@ def unet_forward(sd, cfg, x, x0, timesteps, frame_indices, obs_mask, latent_mask
             if kind == "conv_in":
                 h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
             elif kind == "res":
-                h = res_block(sd, p, h, emb, ssn)
+                h = res_block(sd, p, h, emb, ssn, keep=keeps.pop(0) if keeps is not None else None)
             elif kind == "attn":
                 h = factorized_attention(sd, p, h, emb, attn_mask, T, frame_indices, heads, attns)
             elif kind == "down":  # unet.py:108-114

@@ -47,3 +47,59 @@ def test_parameter_gradients_match_oracle(name):
         assert abs(float(p.grad.double().norm()) - float(g["norms"][i])) < 3e-3 * (float(g["norms"][i]) + 1e-3 * gmax * np.sqrt(ref.numel())), k
     print(f"[{name}] worst relative gradient error vs oracle: {worst:.2e} ({worst_key})")
     assert worst < 2e-3, (worst, worst_key)
+
+
+def test_dropout_training_matches_oracle_with_the_same_draws():
+    """dropout > 0 (unet.py:166): the native training path draws its own keep masks; with those masks handed to the
+    oracle, outputs and gradients must agree; eval mode ignores dropout."""
+    from improved_diffusion import _backward as bw
+    name = "micro"
+    cfg, sd, inp = load_case(name)
+    model = build_native(dict(cfg, dropout=0.25), sd).train()
+    d = {k: v.cuda() for k, v in inp.items()}
+    kw = dict(x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"], obs_mask=d["obs_mask"],
+              latent_mask=d["latent_mask"])
+    probe = torch.from_numpy(recipe.gaussianish(name + "/probe", inp["x"].numel()).reshape(inp["x"].shape).astype(np.float32))
+    bw.dropout_log = []
+    try:
+        torch.manual_seed(5)
+        out, _ = model(d["x"], **kw)
+        keeps = list(bw.dropout_log)
+        with torch.no_grad():                       # train() mode without gradients still drops
+            bw.dropout_log = []
+            torch.manual_seed(5)
+            out_ng, _ = model(d["x"], **kw)
+            assert len(bw.dropout_log) == len(keeps) > 0
+    finally:
+        bw.dropout_log = None
+    assert torch.equal(out.detach(), out_ng)
+    frac = float(torch.cat([(k == 0).float().flatten() for k in keeps]).mean())
+    assert 0.2 < frac < 0.3, frac
+    assert all(bool(((k == 0) | ((k - 1 / 0.75).abs() < 1e-6)).all()) for k in keeps)
+    (out * probe.cuda()).sum().backward()
+    # oracle with the same draws: rows (n, y, x) x C  ->  (N, C, H, W)
+    B, T, _, H, W = inp["x"].shape
+    keeps_cpu, res = [], []
+    for k in keeps:
+        C = k.shape[1]
+        hw = k.shape[0] // (B * T)
+        side = int(round(hw ** 0.5))
+        keeps_cpu.append(k.cpu().view(B * T, side, side, C).permute(0, 3, 1, 2).contiguous())
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o, _ = uo.unet_forward(sdo, cfg, inp["x"], inp["x0"], inp["t"].float(), inp["frame_indices"], inp["obs_mask"],
+                           inp["latent_mask"], dropout_keep=keeps_cpu)
+    assert torch.allclose(out.detach().cpu(), o.detach(), atol=2e-4, rtol=1e-3), float((out.detach().cpu() - o).abs().max())
+    (o * probe).sum().backward()
+    gmax = max(float(v.grad.abs().max()) for v in sdo.values())
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref = sdo[k].grad
+        worst = max(worst, float((p.grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-3 * gmax))
+    assert worst < 2e-3, worst
+    # eval(): dropout is the identity
+    model.eval()
+    with torch.no_grad():
+        e1, _ = model(d["x"], **kw)
+    ref_eval, _ = uo.unet_forward(sd, cfg, inp["x"], inp["x0"], inp["t"].float(), inp["frame_indices"], inp["obs_mask"],
+                                  inp["latent_mask"])
+    assert torch.allclose(e1.cpu(), ref_eval, atol=2e-4, rtol=1e-3)

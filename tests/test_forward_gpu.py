@@ -21,7 +21,7 @@ def build_native(cfg, sd):
     from improved_diffusion.unet import UNetVideoModel
     m = UNetVideoModel(in_channels=cfg["in_channels"], model_channels=cfg["model_channels"],
                        out_channels=cfg["out_channels"], num_res_blocks=cfg["num_res_blocks"],
-                       attention_resolutions=cfg["attention_resolutions"], dropout=0.0, channel_mult=cfg["channel_mult"],
+                       attention_resolutions=cfg["attention_resolutions"], dropout=cfg.get("dropout", 0.0), channel_mult=cfg["channel_mult"],
                        num_heads=cfg["num_heads"], use_scale_shift_norm=True, use_rpe_net=True)
     assert [k for k, _ in m.named_parameters()] == list(sd.keys())
     m.load_state_dict(sd)

@@ -106,3 +106,23 @@ def test_training_reduces_loss_and_checkpoint_roundtrip(tmp_path):
     model.train()
     b, _ = model(d["x"], x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"], obs_mask=d["obs_mask"], latent_mask=d["latent_mask"])
     assert torch.allclose(a, b.detach(), atol=5e-4), "engine plan must pick up the trained weights"
+
+
+def test_graphed_training_step_with_dropout():
+    """dropout > 0: the micro-step is still captured as a graph and trains with finite losses."""
+    cfg, sd, _ = load_case("micro")
+    model = build_native(dict(cfg, dropout=0.1), sd).train()
+    loop = make_loop(model, lr=1e-4)
+    from improved_diffusion.logger import logger
+    torch.manual_seed(3); np.random.seed(3)
+    losses = []
+    for i in range(6):
+        loop.run_step()
+        loop._flush_loss_log()
+        losses.append(logger.name2val["loss"])
+        logger.dumpkvs()
+        loop.step += 1
+    assert np.isfinite(losses).all(), losses
+    assert loop._graph_state.get("graph") is not None, "the micro-step should be running as a captured graph by now"
+    # the keep masks come from th.rand_like under capture, i.e. torch's graph-safe Philox offsets: the same mechanism
+    # that gives q_sample fresh noise on every replay
