@@ -462,24 +462,6 @@ class HeadFn(th.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- attention
-def _temporal_core_torch(qkv, Rq, Rk, Rv, mask, B, T, P, C, heads):
-    """Differentiable restatement of rpe.py:143-169 on device (used for the core's backward only)."""
-    Fh = C // heads
-    scale = Fh ** -0.5
-    x = qkv.view(B, T, P, 3, heads, Fh).permute(3, 0, 2, 4, 1, 5)   # 3, B, P, H, T, F
-    q, k, v = x[0] * scale, x[1], x[2]
-    logits = q @ k.transpose(-1, -2)
-    logits = logits + th.einsum("bdhtf,btshf->bdhts", q, Rk.view(B, T, T, heads, Fh))
-    logits = logits + th.einsum("bdhtf,btshf->bdhts", k * scale, Rq.view(B, T, T, heads, Fh)).transpose(-1, -2)
-    if mask is not None:
-        m = mask.view(B, T)
-        same = m[:, None, :] * m[:, :, None] + (1 - m[:, None, :]) * (1 - m[:, :, None])
-        logits = logits.masked_fill((same == 0).view(B, 1, 1, T, T), float("-inf"))
-    attn = th.softmax(logits, dim=-1)
-    out = attn @ v + th.einsum("bdhts,btshf->bdhtf", attn, Rv.view(B, T, T, heads, Fh))
-    return out.permute(0, 3, 1, 2, 4).reshape(B * T * P, C)          # rows (b,t,p), channels (h,f)
-
-
 class TemporalAttnFn(th.autograd.Function):
     """x -> GN_t(x) + proj(attn_rpe(qkv(GN_t(x))))   (reference rpe.py:133-174, temporal instance)."""
 
