@@ -171,6 +171,25 @@ class _PackedGrads:
 _packed = _PackedGrads()
 
 
+class _GradMode:
+    """How parameter gradients leave the backward pass.
+
+    inplace=False (default): every Function returns its parameter gradients to autograd, so AccumulateGrad runs and
+    hooks fire - DistributedDataParallel (reference train_util.py:116-125), ``register_hook``, gradient
+    checkpointing wrappers all behave as with ordinary modules.
+    inplace=True (``model.native_grad_accumulation = True``, set by ``TrainLoop``, which owns a flat gradient
+    arena and reduces it itself): the kernels accumulate straight into ``p.grad`` / the packed accumulators and
+    autograd sees no parameter gradients - ~800 small adds and the per-tensor temporaries disappear."""
+    inplace = False
+
+
+_mode = _GradMode()
+
+
+def _leaf(*ps):
+    return _mode.inplace and all(p is None or p.is_leaf for p in ps)
+
+
 def _wgrad_accumulate(w, b, **kw):
     """Weight/bias gradient accumulated by the wgrad kernel without temporaries or AccumulateGrad adds: 1x1 /
     linear weights straight into ``w.grad`` (packed == OIHW), 3x3 weights into their packed accumulator, which
@@ -211,7 +230,7 @@ class ConvFn(th.autograd.Function):
         nat.conv_igemm(src0=x, C0=Cin, N=N, Hs=H, Ws=W, up=int(up), stride=stride, Ho=Ho, Wo=Wo, W=_pack(w), bias=b,
                        Cout=Cout, out=out, ldo=Cout)
         ctx.save_for_backward(x, w)
-        ctx.params = (w, b) if (w.is_leaf and b.is_leaf) else None   # leaf parameters: accumulate in place
+        ctx.params = (w, b) if _leaf(w, b) else None   # in-place mode: accumulate into .grad
         ctx.geom = (N, H, W, stride, up, Ho, Wo)
         return out
 
@@ -259,8 +278,8 @@ class LinearFn(th.autograd.Function):
             kw.update(res=res, ldr=O)
         nat.conv_igemm(**kw)
         ctx.save_for_backward(x, w)
-        ctx.params = (w, b) if (w.is_leaf and b is not None and b.is_leaf) else None
-        ctx.has_res = res is not None
+        ctx.params = (w, b) if (b is not None and _leaf(w, b)) else None
+        ctx.has_res, ctx.has_bias = res is not None, b is not None
         return y
 
     @staticmethod
@@ -280,7 +299,7 @@ class LinearFn(th.autograd.Function):
             dx = _new(M, K, like=x)
             nat.conv_igemm(src0=dy, C0=O, N=M, Hs=1, Ws=1, Ho=1, Wo=1, ksize=1, W=_pack_t(w.view(O, K, 1, 1)), Cout=K,
                            out=dx, ldo=K)
-        return dx, dw, db, (dy if ctx.has_res else None)
+        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None)
 
 
 # ----------------------------------------------------------------------------- GroupNorm helpers
@@ -307,7 +326,8 @@ def _gn_forward(a, b, C0, C1, N, P, gamma, beta, film, T):
     return cA, cB, stats
 
 
-def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, T, want_dx=(True, True), dfilm_out=None):
+def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, T, want_dx=(True, True), dfilm_out=None,
+                 inplace=False):
     """Returns (dx_a, dx_b, dgamma, dbeta, dfilm).  da: [N*P][C] gradient w.r.t. act(GN(x))."""
     C = C0 + C1
     sums = _new(N, C, 2, like=da)
@@ -318,7 +338,7 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
     dxb = _new(N * P, C1, like=da) if C1 else None
     nat.check(L.lfvdm_gn_bwd_apply(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
                                    nat.ptr(sums), act, nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.stream()), "lfvdm_gn_bwd_apply")
-    if gamma.is_leaf and beta.is_leaf:
+    if inplace:
         # parameter gradients accumulated in place by one small kernel (no reductions / AccumulateGrad adds)
         dfilm = None
         if film is not None:       # written into the caller's slot (the embedding network's gradient buffer) if given
@@ -330,7 +350,7 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
                                          dfilm.stride(0) if dfilm is not None else 0, N, C, nat.stream()), "lfvdm_gn_param_grads")
         return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
     s1, s2 = sums[..., 0], sums[..., 1]              # [N][C]: sum dz, sum dz*xhat
-    assert dfilm_out is None, "gradient slots need leaf GroupNorm parameters"
+    assert dfilm_out is None, "gradient slots belong to the in-place mode"
     if film is not None:
         B = N // T
         sc1 = 1.0 + film[:, :C].repeat_interleave(T, dim=0)   # (1 + scale) per (n, c)
@@ -381,6 +401,8 @@ class ResBlockFn(th.autograd.Function):
         nat.conv_igemm(**kw)
         ctx.save_for_backward(a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2, act1, act2, keep)
         ctx.params = (w1, b1, w2, b2, ws, bs)
+        ctx.inplace = _leaf(g1, be1, w1, b1, g2, be2, w2, b2, ws, bs)
+        assert ctx.inplace or dfilm_slot is None
         ctx.dfilm_slot = dfilm_slot
         ctx.geom = (N, H, W, T, C0, C1, Cout)
         return out
@@ -393,9 +415,16 @@ class ResBlockFn(th.autograd.Function):
         dout = dout.contiguous()
         geo = dict(N=N, Hs=H, Ws=W, Ho=H, Wo=W)
         pw1, pb1, pw2, pb2, pws, pbs = ctx.params
-        # conv2: weight grad on the fused operand act(GN2(h1)) (accumulated in place), data grad -> da2
-        _wgrad_accumulate(pw2, pb2, src0=act2, C0=Cout, res=dout, ldr=Cout, **geo)
-        dw2 = db2 = None
+        inplace = ctx.inplace
+
+        def wgrad(pw, pb, **kw):        # -> (dW, db) for autograd, or (None, None) after accumulating in place
+            if inplace:
+                _wgrad_accumulate(pw, pb, **kw)
+                return None, None
+            return _wgrad_into(tuple(pw.shape), a, **kw)
+
+        # conv2: weight grad on the materialised operand act(GN2(h1)), data grad -> da2
+        dw2, db2 = wgrad(pw2, pb2, src0=act2, C0=Cout, res=dout, ldr=Cout, **geo)
         da2 = _new(N * P, Cout, like=a)
         nat.conv_igemm(src0=dout, C0=Cout, W=_pack_t(w2), Cout=Cout, out=da2, ldo=Cout, **geo)
         if keep is not None:
@@ -403,19 +432,19 @@ class ResBlockFn(th.autograd.Function):
         if ctx.dfilm_slot is not None:
             _embed.ensure_backward_queued()
         dh1, _, dg2, dbe2, dfilm = _gn_backward(da2, h1, None, Cout, 0, N, P, cA2, cB2, st2, nat.ACT_SILU, g2, be2, film, T,
-                                                dfilm_out=ctx.dfilm_slot)
+                                                dfilm_out=ctx.dfilm_slot, inplace=inplace)
         # conv1
-        _wgrad_accumulate(pw1, pb1, src0=act1, C0=Cin, res=dh1, ldr=Cout, **geo)
-        dw1 = db1 = None
+        dw1, db1 = wgrad(pw1, pb1, src0=act1, C0=Cin, res=dh1, ldr=Cout, **geo)
         da1 = _new(N * P, Cin, like=a)
         nat.conv_igemm(src0=dh1, C0=Cout, W=_pack_t(w1), Cout=Cin, out=da1, ldo=Cin, **geo)
-        dxa, dxb, dg1, dbe1, _ = _gn_backward(da1, a, b, C0, C1, N, P, cA1, cB1, st1, nat.ACT_SILU, g1, be1, None, T)
+        dxa, dxb, dg1, dbe1, _ = _gn_backward(da1, a, b, C0, C1, N, P, cA1, cB1, st1, nat.ACT_SILU, g1, be1, None, T,
+                                              inplace=inplace)
         # skip path
         dws = dbs = None
         if ws is None:
             dxa = dxa + dout
         else:
-            _wgrad_accumulate(pws, pbs, src0=a, src1=b, C0=C0, C1=C1, ksize=1, res=dout, ldr=Cout, **geo)
+            dws, dbs = wgrad(pws, pbs, src0=a, src1=b, C0=C0, C1=C1, ksize=1, res=dout, ldr=Cout, **geo)
             dsk = _new(N * P, Cin, like=a)
             nat.conv_igemm(src0=dout, C0=Cout, ksize=1, W=_pack_t(ws), Cout=Cin, out=dsk, ldo=Cin, **geo)
             dxa = dxa + dsk[:, :C0]
@@ -436,6 +465,7 @@ class HeadFn(th.autograd.Function):
         nat.conv_igemm(src0=act, C0=C, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=_pack(w), bias=b, Cout=Cout, out=out, ldo=Cout,
                        out_mode=nat.OUT_NCHW)
         ctx.save_for_backward(h, g, be, w, cA, cB, st, act)
+        ctx.inplace = _leaf(g, be)
         ctx.geom = (N, H, W)
         return out
 
@@ -457,7 +487,7 @@ class HeadFn(th.autograd.Function):
         wt[:, :, :Cout] = w.flip(2, 3).reshape(Cout, C, 9).permute(1, 2, 0)
         da = _new(N * P, C, like=h)
         nat.conv_igemm(src0=drows, C0=CP, W=wt, Cout=C, out=da, ldo=C, **geo)
-        dh, _, dg, dbe, _ = _gn_backward(da, h, None, C, 0, N, P, cA, cB, st, nat.ACT_SILU, g, be, None, 1)
+        dh, _, dg, dbe, _ = _gn_backward(da, h, None, C, 0, N, P, cA, cB, st, nat.ACT_SILU, g, be, None, 1, inplace=ctx.inplace)
         return dh, dg, dbe, dw, dbp[:Cout].clone(), None, None, None
 
 
@@ -481,6 +511,7 @@ class TemporalAttnFn(th.autograd.Function):
         ctx.save_for_backward(x, gn_w, wqkv, wproj, Rq, Rk, Rv, mask, xn, qkv, o)
         ctx.params = (wqkv, bqkv, wproj, bproj)
         ctx.gn_b = gn_b
+        ctx.inplace = _leaf(gn_w, gn_b, wqkv, bqkv, wproj, bproj)
         ctx.geom = (B, T, P, heads)
         return y
 
@@ -493,8 +524,15 @@ class TemporalAttnFn(th.autograd.Function):
         dy = dy.contiguous()
         one = dict(N=M, Hs=1, Ws=1, Ho=1, Wo=1)
         pwq, pbq, pwp, pbp = ctx.params
-        _wgrad_accumulate(pwp, pbp, src0=o, C0=C, res=dy, ldr=C, **one)
-        dwp = dbp = dwq = dbq = None
+        inplace = ctx.inplace
+
+        def wgrad(pw, pb, **kw):
+            if inplace:
+                _wgrad_accumulate(pw, pb, **kw)
+                return None, None
+            return _wgrad_into(tuple(pw.shape), x, **kw)
+
+        dwp, dbp = wgrad(pwp, pbp, src0=o, C0=C, res=dy, ldr=C, **one)
         do = _new(M, C, like=x)
         nat.conv_igemm(src0=dy, C0=C, ksize=1, W=_pack_t(wproj.view(C, C, 1, 1)), Cout=C, out=do, ldo=C, **one)
         # attention core backward: HIP kernels (rows -> dq, P, dS; cols -> dk, dv; rpe -> dR_q/k/v over pixels)
@@ -502,13 +540,13 @@ class TemporalAttnFn(th.autograd.Function):
         dRq, dRk, dRv = (_new(B * T * T, C, like=x).view(B, T, T, C) for _ in range(3))
         ws_p, ws_ds = _new(B * P * heads * T, T, like=x), _new(B * P * heads * T, T, like=x)
         nat.attn_temporal_bwd(qkv, do, Rq, Rk, Rv, mask, ws_p, ws_ds, dqkv, dRq, dRk, dRv, B, T, P, C, heads)
-        _wgrad_accumulate(pwq, pbq, src0=xn, C0=C, res=dqkv, ldr=3 * C, **one)
+        dwq, dbq = wgrad(pwq, pbq, src0=xn, C0=C, res=dqkv, ldr=3 * C, **one)
         dxn = _new(M, C, like=x)
         nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
                        ldo=C, **one)
         dx = th.empty_like(x)
         gn_b = ctx.gn_b
-        if gn_w.is_leaf and gn_b.is_leaf:      # accumulate straight into the parameter gradients
+        if inplace:      # accumulate straight into the parameter gradients
             dg, db, tg, tb = None, None, _grad_of(gn_w), _grad_of(gn_b)
         else:
             dg, db = th.zeros(C, device=x.device), th.zeros(C, device=x.device)
@@ -536,6 +574,7 @@ class SpatialAttnFn(th.autograd.Function):
                        ldo=C)
         ctx.save_for_backward(x, gn_w, gn_b, wqkv, wproj, cA, cB, st, qkv, o, lse, xn)
         ctx.params = (wqkv, bqkv, wproj, bproj)
+        ctx.inplace = _leaf(gn_w, gn_b, wqkv, bqkv, wproj, bproj)
         ctx.geom = (N, P, heads)
         return y
 
@@ -548,18 +587,25 @@ class SpatialAttnFn(th.autograd.Function):
         dy = dy.contiguous()
         geo = dict(N=N, Hs=P, Ws=1, Ho=P, Wo=1)
         pwq, pbq, pwp, pbp = ctx.params
-        _wgrad_accumulate(pwp, pbp, src0=o, C0=C, ksize=1, res=dy, ldr=C, **geo)
-        dwp = dbp = dwq = dbq = None
+        inplace = ctx.inplace
+
+        def wgrad(pw, pb, **kw):
+            if inplace:
+                _wgrad_accumulate(pw, pb, **kw)
+                return None, None
+            return _wgrad_into(tuple(pw.shape), x, **kw)
+
+        dwp, dbp = wgrad(pwp, pbp, src0=o, C0=C, ksize=1, res=dy, ldr=C, **geo)
         do = _new(M, C, like=x)
         nat.conv_igemm(src0=dy, C0=C, ksize=1, W=_pack_t(wproj.view(C, C, 1, 1)), Cout=C, out=do, ldo=C, **geo)
         # core backward: flash-style HIP kernels (S, P recomputed from q, k and the saved log-sum-exp)
         dqkv = _new(M, 3 * C, like=x)
         nat.attn_spatial_bwd(qkv, o, do, lse, _new(N * heads, P, like=x), dqkv, N, P, C, heads)
-        _wgrad_accumulate(pwq, pbq, src0=xn, C0=C, ksize=1, res=dqkv, ldr=3 * C, **geo)
+        dwq, dbq = wgrad(pwq, pbq, src0=xn, C0=C, ksize=1, res=dqkv, ldr=3 * C, **geo)
         dxn = _new(M, C, like=x)   # gradient w.r.t. the normalised tensor: qkv path + residual
         nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
                        ldo=C, **geo)
-        dx, _, dg, db, _ = _gn_backward(dxn, x, None, C, 0, N, P, cA, cB, st, nat.ACT_NONE, gn_w, gn_b, None, 1)
+        dx, _, dg, db, _ = _gn_backward(dxn, x, None, C, 0, N, P, cA, cB, st, nat.ACT_NONE, gn_w, gn_b, None, 1, inplace=inplace)
         return dx, dg, db, dwq, dbq, dwp, dbp, None, None, None
 
 
@@ -633,6 +679,8 @@ class _EmbedNet:
 
     def forward(self, m, timesteps, B, dev):
         """-> {module: (output view, gradient slot)} or None if the grouped path does not apply."""
+        if not _mode.inplace:
+            return None                 # gradients must flow through autograd: per-layer path
         st = self.state
         if st is not None:
             ps = st["params"]
@@ -691,6 +739,8 @@ class RpeFrontFn(th.autograd.Function):
                                             nat.ptr(act), B, TT, C, nat.stream()), "lfvdm_rpe_front")
         ctx.save_for_backward(tproj, feats, wd, bd)
         ctx.slot = dtproj_slot
+        ctx.inplace = _leaf(wd, bd)
+        assert ctx.inplace or dtproj_slot is None
         ctx.geom = (B, TT, C)
         return act
 
@@ -698,7 +748,7 @@ class RpeFrontFn(th.autograd.Function):
     def backward(ctx, d_act):
         tproj, feats, wd, bd = ctx.saved_tensors
         B, TT, C = ctx.geom
-        leaf = wd.is_leaf and bd.is_leaf
+        leaf = ctx.inplace
         if ctx.slot is not None:      # accumulate into the embedding network's (zeroed) gradient buffer
             _embed.ensure_backward_queued()
             dtproj = ctx.slot
@@ -735,6 +785,7 @@ class UNetFunction:
         m = engine.model
         if return_attn_weights:
             raise NotImplementedError("attention maps are only produced in no-grad (sampling/logging) mode")
+        _mode.inplace = bool(getattr(m, "native_grad_accumulation", False))
         B, T, Cx, H, W = x.shape
         N = B * T
         ch = m.model_channels

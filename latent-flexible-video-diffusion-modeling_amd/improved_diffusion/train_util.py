@@ -114,6 +114,8 @@ class TrainLoop:
         self.model_params = list(self.model.parameters())
         self.master_params = self.model_params
         self.arena = ParamArena(self.model_params)
+        if hasattr(self.model, "native_grad_accumulation"):
+            self.model.native_grad_accumulation = True      # gradients accumulate in the arena, reduced in optimize_normal
         if hasattr(self.model, "_engine"):
             self.model._engine = None          # parameter storage moved: drop cached device pointers
         dev = self.arena.p.device

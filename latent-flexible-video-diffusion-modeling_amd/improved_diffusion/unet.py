@@ -122,6 +122,10 @@ class UNetVideoModel(nn.Module):
         self.use_rpe_net = use_rpe_net
         self.use_scale_shift_norm = use_scale_shift_norm
         self.dims = dims
+        # False: parameter gradients are returned to autograd (hooks fire; DistributedDataParallel can wrap the model as
+        # in reference train_util.py:116-125).  True (set by TrainLoop, which reduces its own flat gradient arena): the
+        # backward kernels accumulate straight into p.grad (see _backward._GradMode).
+        self.native_grad_accumulation = False
 
         ted = model_channels * 4
         self.time_embed = nn.Sequential(linear(model_channels, ted), SiLU(), linear(ted, ted))
