@@ -1,0 +1,30 @@
+#!/bin/bash
+# Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun; results land in
+# gpurun_out/refresh/ and are copied into profiles/ by hand afterwards):
+#   bash tools/refresh_profiles.sh
+# 1. default bench line (all legs)            -> bench_line.json
+# 2. rocprofv3 kernel stats, sampling bench   -> bench_kernel_stats.csv
+# 3. rocprofv3 kernel stats, training step    -> train_kernel_stats.csv
+# 4. two PMC passes (FETCH_SIZE / WRITE_SIZE) -> pmc_traffic.json + raw counter CSVs
+set -e -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/refresh
+mkdir -p $OUT
+export LFVDM_TUNE_CACHE=$ROOT/profiles/tune_cache_mi355x.json
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 python3 $ROOT/bench.py --pixel-steps 10 --long-video-windows 4 > $OUT/bench_line.json 2> $OUT/bench.err
+echo "bench done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/bp -o bp --output-format csv -- python3 $ROOT/bench.py --steps 300 --warmup 20 --train-steps 0 --no-cpu > $OUT/bp.log 2>&1
+cp $OUT/bp/bp_kernel_stats.csv $OUT/bench_kernel_stats.csv
+echo "bench profile done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/tp -o tp --output-format csv -- python3 $ROOT/tools/train_profile.py 30 > $OUT/tp.log 2>&1
+cp $OUT/tp/tp_kernel_stats.csv $OUT/train_kernel_stats.csv
+echo "train profile done"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/pmc_target.py > $OUT/pmc_fetch.log 2>&1
+echo "pmc fetch done"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/pmc_target.py > $OUT/pmc_write.log 2>&1
+echo "pmc write done"
+python3 $ROOT/tools/pmc_summarize.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json
+rm -rf $OUT/bp/*trace* $OUT/tp/*trace*
+cp $LFVDM_TUNE_CACHE $OUT/tune_cache_mi355x.json
+echo "refresh complete"
