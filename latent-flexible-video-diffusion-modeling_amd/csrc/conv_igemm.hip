@@ -33,10 +33,12 @@ extern "C" int lfvdm_debug_stamps(unsigned long long* host_out) {
 namespace {
 
 // KCH = channels per K chunk (32 or 64; 64 halves the barriers / staging overhead per MFMA)
-template <int WM, int WN, int WK, int NT, int KCH>
+// GL  = 0: operand tiles staged through registers into a padded, double-buffered LDS image;
+//       2/3: tiles written by LDS-DMA (buffer_load ... lds) into GL unpadded, XOR-swizzled stages (see the kernel)
+template <int WM, int WN, int WK, int NT, int KCH, int GL = 0>
 struct Cfg {
     static constexpr int KC = KCH;
-    static constexpr int LDR = KCH + 4;                  // padded LDS row (floats): conflict-free b128 reads
+    static constexpr int LDR = GL ? KCH : KCH + 4;       // LDS row (floats); padded rows: conflict-free b128 reads
     static constexpr int QPR = KCH / 4;                  // float4 per row
     static constexpr int RSH = KCH == 64 ? 4 : 3;        // log2(QPR)
     static constexpr int BM = 32 * WM;
@@ -46,7 +48,8 @@ struct Cfg {
     static constexpr int AE = (BM * QPR) / GT;           // float4 A elements per thread per chunk
     static constexpr int WE = (BN * QPR) / GT;           // float4 W elements per thread per chunk
     static constexpr int STAGE = (BM + BN) * LDR;        // floats per LDS stage
-    static constexpr int GROUP_LDS = 2 * STAGE;          // double buffered
+    static constexpr int NSTAGE = GL ? GL : 2;
+    static constexpr int GROUP_LDS = NSTAGE * STAGE;
     static constexpr size_t LDS_BYTES = (size_t)WK * GROUP_LDS * sizeof(float);
     static_assert((BM * QPR) % GT == 0 && (BN * QPR) % GT == 0, "tile must divide over the group");
 };
@@ -212,10 +215,11 @@ __device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs
     }
 }
 
-template <int WM, int WN, int WK, int NT, int KCH, int PRO, bool SIMPLE>
+template <int WM, int WN, int WK, int NT, int KCH, int PRO, bool SIMPLE, int GL = 0>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfvdm_conv_args p_in, int hyb_nfull, int hyb_kz) {
     const lfvdm_conv_args p = p_in;   // private SSA copy: helpers take it by reference (keeps it out of scratch)
-    using CF = Cfg<WM, WN, WK, NT, KCH>;
+    using CF = Cfg<WM, WN, WK, NT, KCH, GL>;
+    static_assert(GL == 0 || PRO == 0, "LDS-DMA staging carries raw operands only");
     constexpr int BM = CF::BM, BN = CF::BN, KC = CF::KC, LDR = CF::LDR;
     constexpr int RED_LD = BN + 1;
     static_assert(BM * RED_LD <= CF::GROUP_LDS, "reduction tile must fit the group's stages");
@@ -319,6 +323,143 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
+  if constexpr (GL > 0) {
+    // ---- LDS-DMA main loop.  `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 B to ONE contiguous 1 KiB piece
+    // of LDS (wave-uniform base + lane * 16) while every lane supplies its own source offset.  The stage image is
+    // therefore the plain row-major [rows][KC] tile (a piece = 64 / QPR rows), no VGPR staging, no ds_write, no
+    // masking selects: a lane whose tap lies outside the image (or past the last filter / K chunk) passes an offset
+    // beyond the buffer descriptor's num_records and the hardware writes zeros.  Bank conflicts of the b128 fragment
+    // reads are avoided by an XOR swizzle of the 16-byte slot inside a row, applied to the per-lane SOURCE column
+    // and to the read (same involution on both sides, CDNA guide rule 21): slot ^= (row >> 1) & 7 for 128-byte rows,
+    // slot ^= row & 15 for 256-byte rows (distinct slots for the rows of every 16-lane read group).
+    // GL stages: chunk k+GL-1 is in flight while chunk k is multiplied; ONE barrier per chunk; the DMA queue is
+    // drained with counted vmcnt waits (never to zero inside the loop when GL = 3).
+    constexpr int QPR = CF::QPR, RSH = CF::RSH, AE = CF::AE, WE = CF::WE;
+    constexpr unsigned kOOB = 0x40000000u;       // >= num_records of every descriptor (checked by the launcher);
+                                                 // sums of two such terms stay below 2^32 (no wrap back into range)
+    // SIMPLE: one raw source.  Otherwise also the virtual concat (src0 | src1) and the fused 1x1 skip segment
+    // (s2src0 | s2src1 at output resolution, weights W2): one descriptor per tensor, chosen per chunk by scalar selects.
+    const int wld = taps * Cin, w2ld = p.s2C0 + p.s2C1;
+    const unsigned pixA = (unsigned)p.N * p.Hs * p.Ws * 4u;
+    auto desc = [](const float* base, unsigned bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsA0 = desc(p.src0, pixA * p.C0), rsW = desc(p.W, (unsigned)p.Cout * wld * 4u);
+    const __amdgpu_buffer_rsrc_t rsA1 = desc(p.src1, SIMPLE ? 0u : pixA * p.C1);
+    const __amdgpu_buffer_rsrc_t rsS0 = desc(p.s2src0, SIMPLE ? 0u : (unsigned)M * p.s2C0 * 4u);
+    const __amdgpu_buffer_rsrc_t rsS1 = desc(p.s2src1, SIMPLE ? 0u : (unsigned)M * p.s2C1 * 4u);
+    const __amdgpu_buffer_rsrc_t rsW2 = desc(p.W2, SIMPLE ? 0u : (unsigned)p.Cout * w2ld * 4u);
+    // per-lane byte offsets without the chunk's (tap, channel) shift; rows / filters that do not exist start at kOOB
+    constexpr int XE = SIMPLE ? 1 : AE, XW = SIMPLE ? 1 : WE;
+    unsigned aoff[AE], woff[WE], aoff1[XE], soff0[XE], soff1[XE], w2off[XW], amsk[AE];
+#pragma unroll
+    for (int j = 0; j < AE; ++j) {
+        const int e = gt + j * CF::GT, r = e >> RSH, sl = e & (QPR - 1);
+        const unsigned q16 = (unsigned)(sl ^ (KC == 32 ? ((r >> 1) & 7) : (r & 15))) * 16u;
+        aoff[j] = (unsigned)ri[j].pix * p.C0 * 4u + q16;
+        amsk[j] = ri[j].taps | (ri[j].valid ? 0x80000000u : 0u);     // bit 31: the output row exists (skip segment)
+        if constexpr (!SIMPLE) {
+            aoff1[j] = (unsigned)ri[j].pix * p.C1 * 4u + q16;
+            soff0[j] = (unsigned)ri[j].m * p.s2C0 * 4u + q16;
+            soff1[j] = (unsigned)ri[j].m * p.s2C1 * 4u + q16;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WE; ++j) {
+        const int e = gt + j * CF::GT, r = e >> RSH, sl = e & (QPR - 1);
+        const unsigned q16 = (unsigned)(sl ^ (KC == 32 ? ((r >> 1) & 7) : (r & 15))) * 16u;
+        const bool ok = (wmask >> j) & 1u;
+        woff[j] = ok ? (unsigned)wrow[j] * wld * 4u + q16 : kOOB;
+        if constexpr (!SIMPLE) w2off[j] = ok ? (unsigned)wrow[j] * w2ld * 4u + q16 : kOOB;
+    }
+    // fragment read offsets (floats, relative to the stage): A row 32*wm + (lane & 31), W row 32*NT*wn + (lane & 31)
+    // (+ 32 t: same swizzle), logical slot 2g + (lane >> 5)
+    int offA[KC / 8], offW[KC / 8];
+    {
+        const int ra = 32 * wm + (lane & 31), rw = 32 * NT * wn + (lane & 31), h = lane >> 5;
+        const int fa = KC == 32 ? ((ra >> 1) & 7) : (ra & 15), fw = KC == 32 ? ((rw >> 1) & 7) : (rw & 15);
+#pragma unroll
+        for (int g = 0; g < KC / 8; ++g) {
+            offA[g] = ra * KC + (((2 * g + h) ^ fa) << 2);
+            offW[g] = (BM + rw) * KC + (((2 * g + h) ^ fw) << 2);
+        }
+    }
+    const int klast = max(kend - 1, 0);
+    const int k3 = p.ksize == 3 ? 1 : 0;
+    auto issue = [&](int kc_raw, int stage) {       // everything but the per-lane offsets is wave-uniform
+        const bool live = kc_raw < kend;
+        const int kc = min(kc_raw, klast);
+        const bool main_seg = SIMPLE ? true : kc < NK1;
+        const int kk = main_seg ? kc : kc - NK1;
+        const int ci = main_seg ? kk / taps : kk, tap = main_seg ? kk - ci * taps : 0, cc = ci * KC;
+        const int c0 = main_seg ? p.C0 : p.s2C0;
+        const bool second = SIMPLE ? false : cc >= c0;
+        const int cl = second ? cc - c0 : cc;
+        const int Csrc = main_seg ? (second ? p.C1 : p.C0) : (second ? p.s2C1 : p.s2C0);
+        const int t3 = tap / 3, km = main_seg ? k3 : 0;                // branch-free: no tap offset for 1x1 / skip chunks
+        const int dy = (t3 - 1) * km, dx = (tap - t3 * 3 - 1) * km;
+        const int ashift = ((dy * p.Ws + dx) * Csrc + cl) * 4;         // bytes, may be negative
+        const unsigned wshift = live ? (unsigned)(main_seg ? tap * Cin + cc : cc) * 4u : kOOB;
+        const unsigned tapbit = live ? (main_seg ? (1u << tap) : 0x80000000u) : 0u;
+        const __amdgpu_buffer_rsrc_t rsA = main_seg ? (second ? rsA1 : rsA0) : (second ? rsS1 : rsS0);
+        const __amdgpu_buffer_rsrc_t rsB = main_seg ? rsW : rsW2;
+        float* As = gbase + stage * CF::STAGE + wmn * 256;             // this wave's first piece
+        float* Wst = As + BM * KC;
+#pragma unroll
+        for (int j = 0; j < AE; ++j) {
+            unsigned base = aoff[j];
+            if constexpr (!SIMPLE) base = main_seg ? (second ? aoff1[j] : aoff[j]) : (second ? soff1[j] : soff0[j]);
+            const unsigned off = (amsk[j] & tapbit) ? base + (unsigned)ashift : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + j * CF::GT * 4), 16,
+                                                     (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < WE; ++j) {
+            unsigned base = woff[j];
+            if constexpr (!SIMPLE) base = main_seg ? woff[j] : w2off[j];
+            const unsigned off = base + wshift;                        // missing filter row / padding chunk: >= kOOB
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(Wst + j * CF::GT * 4), 16,
+                                                     (int)off, 0, 0, 0);
+        }
+    };
+    const int iters_g = ((NK + KZ - 1) / KZ + WK - 1) / WK;            // chunks of the largest K slice (workgroup-uniform)
+#define LFVDM_GSTEP(S_, IT_)                                                                                    \
+    do {                                                                                                       \
+        /* RAW: this wave's pieces of the chunk have landed (counted vmcnt) before it arrives at the barrier.  \
+           WAR: its fragment reads of the previous chunk have RETURNED (lgkmcnt) before it arrives - the other  \
+           waves restage that buffer right after the barrier, and a zero-filled (out-of-range) piece lands      \
+           within a few cycles */                                                                              \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((GL - 2) * (AE + WE)) : "memory");                  \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        asm volatile("" ::: "memory");                                                                         \
+        issue(kbeg + (IT_) + GL - 1, ((S_) + GL - 1) % GL);                                                    \
+        const float* st_ = gbase + (S_) * CF::STAGE;                                                           \
+        _Pragma("unroll") for (int g = 0; g < KC / 8; ++g) {                                                   \
+            const f32x4 a4 = ld4(st_ + offA[g]);                                                               \
+            f32x4 b4[NT];                                                                                      \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) b4[t] = ld4(st_ + offW[g] + t * 32 * KC);           \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                      \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                 \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[t][e], acc[t], 0, 0, 0);           \
+        }                                                                                                      \
+    } while (0)
+#pragma unroll
+    for (int d = 0; d < GL - 1; ++d) issue(kbeg + d, d);
+    STAMP(1);
+    int it = 0;
+    if constexpr (GL == 2) {
+        for (; it + 2 <= iters_g; it += 2) { LFVDM_GSTEP(0, it); LFVDM_GSTEP(1, it + 1); }
+        if (it < iters_g) { LFVDM_GSTEP(0, it); }
+    } else {
+        for (; it + 3 <= iters_g; it += 3) { LFVDM_GSTEP(0, it); LFVDM_GSTEP(1, it + 1); LFVDM_GSTEP(2, it + 2); }
+        if (it < iters_g) {
+            LFVDM_GSTEP(0, it);
+            if (it + 1 < iters_g) { LFVDM_GSTEP(1, it + 1); }
+        }
+    }
+#undef LFVDM_GSTEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the zero-filled look-ahead pieces must land before the stages are reused
+  } else {
     // Two chunks are kept in flight in registers (R0, R1): the loads of chunk k+2 are issued before the
     // MFMAs of chunk k, so a load has two compute phases (~2 x 1024 MFMA cycles) to come back.
     ChunkRegs<CF::AE, CF::WE> R0, R1;
@@ -384,6 +525,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
 #undef LFVDM_FINISH
 #undef LFVDM_ISSUE
 #undef LFVDM_MFMA
+  }
     STAMP(2);
     __syncthreads();   // all fragment reads done before the stages are reused for the reduction
 
@@ -543,12 +685,13 @@ inline HybridPlan hybrid_plan(long tiles) {
     return h;
 }
 
-template <int WM, int WN, int WK, int NT, int KCH, int PRO, bool SIMPLE>
+template <int WM, int WN, int WK, int NT, int KCH, int PRO, bool SIMPLE, int GL = 0>
 int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
-    using CF = Cfg<WM, WN, WK, NT, KCH>;
+    using CF = Cfg<WM, WN, WK, NT, KCH, GL>;
+    if (CF::LDS_BYTES > 160 * 1024) return LFVDM_E_UNSUPPORTED;
     static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE, GL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::LDS_BYTES) != hipSuccess)
             return LFVDM_E_LAUNCH;
         attr_set = true;
@@ -556,19 +699,45 @@ int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
     const long MT = (M + CF::BM - 1) / CF::BM, NT2 = (a->Cout + CF::BN - 1) / CF::BN;
     if (kz == kHybridKz) {   // tail split (see the kernel): flat grid
         const HybridPlan h = hybrid_plan(MT * NT2);
-        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE>), dim3((unsigned)(h.nfull + h.tail * h.kz)),
+        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE, GL>), dim3((unsigned)(h.nfull + h.tail * h.kz)),
                            dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, (int)h.nfull, h.kz);
         LFVDM_CHECK_LAUNCH();
         return LFVDM_OK;
     }
     const dim3 grid((unsigned)MT, (unsigned)NT2, (unsigned)kz);
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE, GL>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
 
+// LDS bytes of the LDS-DMA variant with `gl` unpadded stages
+constexpr long glds_lds_bytes(int WM, int WN, int WK, int NT, int kch, int gl) {
+    return (long)WK * gl * (32 * WM + 32 * NT * WN) * kch * 4;
+}
+
+// may this launch use the LDS-DMA variant?  Raw operands (no GroupNorm prologue), no upsampling; every tensor it
+// stages must be addressable with 32-bit byte offsets below kOOB (2^30).
+inline bool glds_ok(const lfvdm_conv_args* a) {
+    const long Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1, lim = 1L << 30;
+    const long Cmax = a->C0 > a->C1 ? a->C0 : a->C1, C2max = a->s2C0 > a->s2C1 ? a->s2C0 : a->s2C1;
+    return !a->coefA && a->up == 0 && (long)a->N * a->Hs * a->Ws * Cmax * 4 < lim &&
+           (long)a->N * a->Ho * a->Wo * C2max * 4 < lim && (long)a->Cout * a->ksize * a->ksize * Cin * 4 < lim &&
+           (long)a->Cout * C2 * 4 < lim;
+}
+
 template <int WM, int WN, int WK, int NT, int KCH>
-int launch_kc(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
+int launch_kc(const lfvdm_conv_args* a, hipStream_t s, long M, int kz, int gl) {
+    if (gl && glds_ok(a)) {
+        const bool simple = a->C1 == 0 && a->s2C0 + a->s2C1 == 0;
+        if constexpr (glds_lds_bytes(WM, WN, WK, NT, KCH, 3) <= 160 * 1024) {
+            if (gl == 3) return simple ? launch_pro<WM, WN, WK, NT, KCH, 0, true, 3>(a, s, M, kz)
+                                       : launch_pro<WM, WN, WK, NT, KCH, 0, false, 3>(a, s, M, kz);
+        }
+        if constexpr (glds_lds_bytes(WM, WN, WK, NT, KCH, 2) <= 160 * 1024) {
+            return simple ? launch_pro<WM, WN, WK, NT, KCH, 0, true, 2>(a, s, M, kz)
+                          : launch_pro<WM, WN, WK, NT, KCH, 0, false, 2>(a, s, M, kz);
+        }
+    }
     if (!a->coefA) {
         if (a->up == 0 && a->s2C0 + a->s2C1 == 0) return launch_pro<WM, WN, WK, NT, KCH, 0, true>(a, s, M, kz);
         return launch_pro<WM, WN, WK, NT, KCH, 0, false>(a, s, M, kz);
@@ -578,11 +747,11 @@ int launch_kc(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
 }
 
 template <int WM, int WN, int WK, int NT>
-int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, long M, int kch, int kz) {
+int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, long M, int kch, int kz, int gl) {
     if constexpr (WM * WN >= 4 && NT == 1) {   // 64-channel chunks need a 256-thread k-group (register budget)
-        if (kch == 64) return launch_kc<WM, WN, WK, NT, 64>(a, s, M, kz);
+        if (kch == 64) return launch_kc<WM, WN, WK, NT, 64>(a, s, M, kz, gl);
     }
-    return launch_kc<WM, WN, WK, NT, 32>(a, s, M, kz);
+    return launch_kc<WM, WN, WK, NT, 32>(a, s, M, kz, gl);
 }
 
 // Tile configurations: {WM, WN, WK, NT, waves/SIMD allowed by the VGPR allocation}.
@@ -625,13 +794,22 @@ double model_cycles(const TileCfg& c, int Cout, long M, int NK, int kch, int kz)
 
 // Joint choice of tile configuration and K chunk width (64-channel chunks only when every channel
 // count involved is a multiple of 64 and the k-group has 256 threads).
-struct Pick { int id, kch, NK, kz; };
+struct Pick { int id, kch, NK, kz, gl; };
 
-// tune code (lfvdm_conv_args::tune): 0 = heuristic, else 1 + id + 16*(kch == 64) + 32*log2(kz)
-inline int encode_tune(int id, int kch, int kz) {
+// tune code (lfvdm_conv_args::tune): 0 = heuristic, else 1 + id + 16*(kch == 64) + 32*log2(kz) + 256*g
+// (g = 0 register staging, 1 / 2 = LDS-DMA with 2 / 3 stages)
+inline int encode_tune(int id, int kch, int kz, int gl = 0) {
     int l = 0;
     while ((1 << l) < kz) ++l;
-    return 1 + id + 16 * (kch == 64 ? 1 : 0) + 32 * l;
+    return 1 + id + 16 * (kch == 64 ? 1 : 0) + 32 * l + 256 * (gl ? gl - 1 : 0);
+}
+bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz);
+// is the LDS-DMA variant with `gl` stages legal for (id, kch, kz)?
+bool glds_valid(const lfvdm_conv_args* a, int id, int kch, int kz, int gl) {
+    if (gl != 2 && gl != 3) return false;
+    if (!cfg_valid(a, id, kch, kz) || !glds_ok(a)) return false;
+    const TileCfg c = kCfgs[id];
+    return glds_lds_bytes(c.WM, c.WN, c.WK, c.NT, kch, gl) <= 160 * 1024;
 }
 // is (id, kch, kz) a legal configuration for these arguments?
 bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz) {
@@ -666,14 +844,16 @@ Pick pick_cfg(const lfvdm_conv_args* a, long M) {
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
     if (a->tune > 0) {   // explicit choice (autotuner); fall through to the model if it is not legal here
         const int t = a->tune - 1;
-        const int id = t & 15, kch = (t & 16) ? 64 : 32, kz = 1 << (t >> 5);
-        if (cfg_valid(a, id, kch, kz)) return {id, kch, a->ksize * a->ksize * (Cin / kch) + C2 / kch, kz};
+        const int id = t & 15, kch = (t & 16) ? 64 : 32, kz = 1 << ((t >> 5) & 7), g = (t >> 8) & 3;
+        const int gl = g ? g + 1 : 0;
+        if (gl ? glds_valid(a, id, kch, kz, gl) : cfg_valid(a, id, kch, kz))
+            return {id, kch, a->ksize * a->ksize * (Cin / kch) + C2 / kch, kz, gl};
     }
     const bool can64 = !getenv("LFVDM_CONV_KC32") && Cin % 64 == 0 && a->C0 % 64 == 0 && C2 % 64 == 0 && a->s2C0 % 64 == 0;
     static const int forced = getenv("LFVDM_CONV_CFG") ? atoi(getenv("LFVDM_CONV_CFG")) : -1;  // tuning aid
     static const int forced_kz = getenv("LFVDM_CONV_KZ") ? atoi(getenv("LFVDM_CONV_KZ")) : -1;
     const bool can_split = false;   // the built-in model never splits K over workgroups (see cfg_valid)
-    Pick best = {0, 32, a->ksize * a->ksize * (Cin / 32) + C2 / 32, 1};
+    Pick best = {0, 32, a->ksize * a->ksize * (Cin / 32) + C2 / 32, 1, 0};
     double best_t = 1e30;
     for (int i = 0; i < kNumCfgs; ++i) {
         const TileCfg c = kCfgs[i];
@@ -690,10 +870,13 @@ Pick pick_cfg(const lfvdm_conv_args* a, long M) {
                 if (kz > 1 && (!can_split || NK < 2 * kz * c.WK)) continue;
                 if (forced_kz > 0 && kz != forced_kz && !(kz == 1 && (!can_split || NK < 2 * forced_kz * c.WK))) continue;
                 const double est = model_cycles(c, a->Cout, M, NK, kch, kz);
-                if (est < best_t) { best_t = est; best = {i, kch, NK, kz}; }
+                if (est < best_t) { best_t = est; best = {i, kch, NK, kz, 0}; }
             }
         }
     }
+    // plain convolutions default to the LDS-DMA loop (faster on every measured shape, tools/conv_glds_compare.sh)
+    static const bool no_glds = getenv("LFVDM_CONV_NO_GLDS") != nullptr;
+    if (!no_glds && glds_valid(a, best.id, best.kch, best.kz, 2)) best.gl = 2;
     return best;
 }
 
@@ -723,16 +906,16 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     if (M * (long)(C2 > a->Cout ? C2 : a->Cout) >= (1L << 31) || (long)a->N * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     if ((long)a->Cout * a->ksize * a->ksize * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     const Pick pk = pick_cfg(a, M);
-    const int kch = pk.kch, kz = pk.kz;
+    const int kch = pk.kch, kz = pk.kz, gl = pk.gl;
     switch (pk.id) {
-        case 0: return launch_cfg<2, 2, 1, 1>(a, s, M, kch, kz);
-        case 1: return launch_cfg<2, 2, 1, 2>(a, s, M, kch, kz);
-        case 2: return launch_cfg<1, 2, 2, 1>(a, s, M, kch, kz);
-        case 3: return launch_cfg<1, 2, 4, 1>(a, s, M, kch, kz);
-        case 4: return launch_cfg<1, 1, 8, 1>(a, s, M, kch, kz);
-        case 5: return launch_cfg<2, 2, 2, 1>(a, s, M, kch, kz);
-        case 6: return launch_cfg<1, 1, 4, 1>(a, s, M, kch, kz);
-        case 7: return launch_cfg<2, 2, 2, 2>(a, s, M, kch, kz);
+        case 0: return launch_cfg<2, 2, 1, 1>(a, s, M, kch, kz, gl);
+        case 1: return launch_cfg<2, 2, 1, 2>(a, s, M, kch, kz, gl);
+        case 2: return launch_cfg<1, 2, 2, 1>(a, s, M, kch, kz, gl);
+        case 3: return launch_cfg<1, 2, 4, 1>(a, s, M, kch, kz, gl);
+        case 4: return launch_cfg<1, 1, 8, 1>(a, s, M, kch, kz, gl);
+        case 5: return launch_cfg<2, 2, 2, 1>(a, s, M, kch, kz, gl);
+        case 6: return launch_cfg<1, 1, 4, 1>(a, s, M, kch, kz, gl);
+        case 7: return launch_cfg<2, 2, 2, 2>(a, s, M, kch, kz, gl);
     }
     return LFVDM_E_UNSUPPORTED;
 }
@@ -755,6 +938,12 @@ extern "C" int lfvdm_conv_igemm_candidates(const lfvdm_conv_args* a, int* codes,
         for (int kch = 32; kch <= 64; kch += 32)
             for (int kz = 1; kz <= kHybridKz; kz *= 2)
                 if (cfg_valid(a, id, kch, kz) && n < max_codes) codes[n++] = encode_tune(id, kch, kz);
+    static const bool no_glds = getenv("LFVDM_CONV_NO_GLDS") != nullptr;    // A/B aid
+    for (int gl = 2; gl <= 3 && !no_glds; ++gl)
+        for (int id = 0; id < kNumCfgs; ++id)
+            for (int kch = 32; kch <= 64; kch += 32)
+                for (int kz = 1; kz <= kHybridKz; kz *= 2)
+                    if (glds_valid(a, id, kch, kz, gl) && n < max_codes) codes[n++] = encode_tune(id, kch, kz, gl);
     return n;
 }
 
@@ -770,4 +959,4 @@ extern "C" int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* n
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_abi_version(void) { return 3; }
+extern "C" int lfvdm_abi_version(void) { return 4; }

@@ -240,8 +240,8 @@ def autotune_launch(a, rounds=3, reps=6):
     """Time every legal variant of this implicit-GEMM launch (the launch is idempotent) and return the fastest
     code.  Must not be called while the stream is capturing."""
     L, s = lib(), stream()
-    codes = (C.c_int * 64)()
-    n = L.lfvdm_conv_igemm_candidates(C.byref(a), codes, 64)
+    codes = (C.c_int * 256)()
+    n = L.lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     best, best_t = 0, float("inf")
     for code in [0] + [codes[i] for i in range(n)]:

@@ -415,8 +415,8 @@ def test_conv_splitk_is_exact_and_deterministic(nat):
     keep = dict(src0=cl(x), W=packed(nat, w), bias=b.cuda(), res=res.cuda())   # the struct holds raw pointers
     a = nat.fill_conv_args(C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, Cout=Cout, ldr=Cout, out=out, ldo=Cout, **keep)
     a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
-    codes = (C.c_int * 64)()
-    n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 64)
+    codes = (C.c_int * 256)()
+    n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
     split = [codes[i] for i in range(n) if (codes[i] - 1) >> 5 > 0]
     assert n >= 8 and len(split) >= 3, "split-K candidates expected for a small-M layer"
     for code in [codes[i] for i in range(n)]:
@@ -588,3 +588,76 @@ def test_sampler_tick(nat):
     mt = torch.zeros(3, device="cuda")
     nat.check(nat.lib().lfvdm_sampler_tick(t.data_ptr(), table.data_ptr(), mt.data_ptr(), 3, nat.stream()), "lfvdm_sampler_tick")
     assert t.tolist() == [4, 0, 998] and mt.tolist() == [1.0, 0.0, 249.5]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,k,stride", [(3, 64, 64, 16, 3, 1), (2, 128, 192, 5, 3, 1), (5, 64, 64, 8, 3, 2),
+                                                   (7, 128, 32, 6, 1, 1), (40, 128, 128, 4, 3, 1), (4, 64, 4, 16, 3, 1),
+                                                   (21, 256, 128, 16, 3, 1)])
+def test_conv_every_tune_code(nat, N, Cin, Cout, H, k, stride):
+    """Every legal launch variant - register-staged and LDS-DMA (buffer_load ... lds, 2 and 3 stages), both K-chunk
+    widths, split-K and tail-split - computes the same convolution (odd sizes: ragged last tiles, image borders)."""
+    import ctypes as C
+    pad = 1 if k == 3 else 0
+    x, w, b = rnd("et/x", N, Cin, H, H), rnd("et/w", Cout, Cin, k, k, scale=0.05), rnd("et/b", Cout)
+    ref = F.conv2d(x, w, b, padding=pad, stride=stride)
+    Ho = ref.shape[2]
+    out = torch.empty(N * Ho * Ho, Cout, device="cuda")
+    ws = torch.empty(1 << 22, device="cuda")
+    cnt = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    keep = dict(src0=cl(x), W=packed(nat, w), bias=b.cuda())
+    a = nat.fill_conv_args(C0=Cin, N=N, Hs=H, Ws=H, Ho=Ho, Wo=Ho, Cout=Cout, out=out, ldo=Cout, ksize=k, stride=stride, **keep)
+    a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+    codes = (C.c_int * 256)()
+    n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
+    dma = [codes[i] for i in range(n) if (codes[i] - 1) >> 8]
+    assert n > 0 and dma, "LDS-DMA variants expected for a plain convolution"
+    for code in [0] + [codes[i] for i in range(n)]:
+        a.tune = code
+        out.fill_(float("nan"))
+        nat.conv_igemm_struct(a)
+        got = from_cl(out, N, Ho, Ho, Cout)
+        err = float((got.cpu() - ref).abs().max())
+        assert err < 5e-5, f"tune code {code}: max|d| = {err:.3e}"
+    assert int(cnt.abs().sum()) == 0, "split-K tickets must be left at zero"
+
+
+@pytest.mark.parametrize("N,C0,C1,S0,S1,Cout,H", [(5, 64, 32, 64, 32, 64, 8), (3, 128, 0, 96, 32, 96, 5), (40, 64, 64, 0, 0, 128, 4),
+                                                  (2, 32, 32, 32, 0, 32, 16)])
+def test_conv_concat_and_skip_segment_every_tune_code(nat, N, C0, C1, S0, S1, Cout, H):
+    """Virtual concat (src0 | src1) 3x3 conv + fused 1x1 skip segment on a second raw concat (s2src0 | s2src1) +
+    residual (the second conv of a channel-changing ResBlock, unet.py:173-207): every launch variant, including the
+    general LDS-DMA loop with its per-chunk descriptor selects, gives the same result."""
+    import ctypes as C
+    Cin, C2 = C0 + C1, S0 + S1
+    x, w, b = rnd("cs2/x", N, Cin, H, H), rnd("cs2/w", Cout, Cin, 3, 3, scale=0.05), rnd("cs2/b", Cout)
+    ref = F.conv2d(x, w, b, padding=1)
+    keep = dict(src0=cl(x[:, :C0]), W=packed(nat, w), bias=b.cuda())
+    kw = dict(C0=C0, C1=C1)
+    if C1:
+        keep["src1"] = cl(x[:, C0:])
+    if C2:
+        s, w2, b2 = rnd("cs2/s", N, C2, H, H), rnd("cs2/w2", Cout, C2, scale=0.05), rnd("cs2/b2", Cout)
+        ref = ref + F.conv2d(s, w2.view(Cout, C2, 1, 1), b2)
+        keep.update(s2src0=cl(s[:, :S0]), W2=w2.cuda().contiguous(), bias2=b2.cuda())
+        kw.update(s2C0=S0, s2C1=S1)
+        if S1:
+            keep["s2src1"] = cl(s[:, S0:])
+    else:
+        r = rnd("cs2/r", N * H * H, Cout)
+        ref = ref + r.view(N, H, H, Cout).permute(0, 3, 1, 2)
+        keep["res"] = r.cuda()
+        kw["ldr"] = Cout
+    out = torch.empty(N * H * H, Cout, device="cuda")
+    ws = torch.empty(1 << 22, device="cuda")
+    cnt = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    a = nat.fill_conv_args(N=N, Hs=H, Ws=H, Ho=H, Wo=H, Cout=Cout, out=out, ldo=Cout, **kw, **keep)
+    a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+    codes = (C.c_int * 256)()
+    n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
+    assert n > 0 and any((codes[i] - 1) >> 8 for i in range(n))
+    for code in [0] + [codes[i] for i in range(n)]:
+        a.tune = code
+        out.fill_(float("nan"))
+        nat.conv_igemm_struct(a)
+        err = float((from_cl(out, N, H, H, Cout).cpu() - ref).abs().max())
+        assert err < 5e-5, f"tune code {code}: max|d| = {err:.3e}"
