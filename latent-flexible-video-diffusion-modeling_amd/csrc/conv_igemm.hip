@@ -338,17 +338,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     constexpr unsigned kOOB = 0x40000000u;       // >= num_records of every descriptor (checked by the launcher);
                                                  // sums of two such terms stay below 2^32 (no wrap back into range)
     // SIMPLE: one raw source.  Otherwise also the virtual concat (src0 | src1) and the fused 1x1 skip segment
-    // (s2src0 | s2src1 at output resolution, weights W2): one descriptor per tensor, chosen per chunk by scalar selects.
+    // (s2src0 | s2src1 at output resolution, weights W2); the buffer descriptor of a chunk is built from scalar
+    // selects of base pointer and size (holding six descriptors at once spills SGPRs to scratch).
     const int wld = taps * Cin, w2ld = p.s2C0 + p.s2C1;
     const unsigned pixA = (unsigned)p.N * p.Hs * p.Ws * 4u;
     auto desc = [](const float* base, unsigned bytes) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t rsA0 = desc(p.src0, pixA * p.C0), rsW = desc(p.W, (unsigned)p.Cout * wld * 4u);
-    const __amdgpu_buffer_rsrc_t rsA1 = desc(p.src1, SIMPLE ? 0u : pixA * p.C1);
-    const __amdgpu_buffer_rsrc_t rsS0 = desc(p.s2src0, SIMPLE ? 0u : (unsigned)M * p.s2C0 * 4u);
-    const __amdgpu_buffer_rsrc_t rsS1 = desc(p.s2src1, SIMPLE ? 0u : (unsigned)M * p.s2C1 * 4u);
-    const __amdgpu_buffer_rsrc_t rsW2 = desc(p.W2, SIMPLE ? 0u : (unsigned)p.Cout * w2ld * 4u);
     // per-lane byte offsets without the chunk's (tap, channel) shift; rows / filters that do not exist start at kOOB
     constexpr int XE = SIMPLE ? 1 : AE, XW = SIMPLE ? 1 : WE;
     unsigned aoff[AE], woff[WE], aoff1[XE], soff0[XE], soff1[XE], w2off[XW], amsk[AE];
@@ -386,29 +382,35 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     }
     const int klast = max(kend - 1, 0);
     const int k3 = p.ksize == 3 ? 1 : 0;
+    const int pC0 = p.C0, pC1 = p.C1, pS0 = p.s2C0, pS1 = p.s2C1, pWs = p.Ws;   // by-value copies for the selects below
     auto issue = [&](int kc_raw, int stage) {       // everything but the per-lane offsets is wave-uniform
         const bool live = kc_raw < kend;
         const int kc = min(kc_raw, klast);
         const bool main_seg = SIMPLE ? true : kc < NK1;
         const int kk = main_seg ? kc : kc - NK1;
         const int ci = main_seg ? kk / taps : kk, tap = main_seg ? kk - ci * taps : 0, cc = ci * KC;
-        const int c0 = main_seg ? p.C0 : p.s2C0;
+        const int c0 = sel(main_seg, pC0, pS0);
         const bool second = SIMPLE ? false : cc >= c0;
         const int cl = second ? cc - c0 : cc;
-        const int Csrc = main_seg ? (second ? p.C1 : p.C0) : (second ? p.s2C1 : p.s2C0);
+        const int Csrc = sel(main_seg, sel(second, pC1, pC0), sel(second, pS1, pS0));
         const int t3 = tap / 3, km = main_seg ? k3 : 0;                // branch-free: no tap offset for 1x1 / skip chunks
         const int dy = (t3 - 1) * km, dx = (tap - t3 * 3 - 1) * km;
-        const int ashift = ((dy * p.Ws + dx) * Csrc + cl) * 4;         // bytes, may be negative
+        const int ashift = ((dy * pWs + dx) * Csrc + cl) * 4;          // bytes, may be negative
         const unsigned wshift = live ? (unsigned)(main_seg ? tap * Cin + cc : cc) * 4u : kOOB;
         const unsigned tapbit = live ? (main_seg ? (1u << tap) : 0x80000000u) : 0u;
-        const __amdgpu_buffer_rsrc_t rsA = main_seg ? (second ? rsA1 : rsA0) : (second ? rsS1 : rsS0);
-        const __amdgpu_buffer_rsrc_t rsB = main_seg ? rsW : rsW2;
+        const float* abase = SIMPLE ? p.src0 : sel(main_seg, sel(second, p.src1, p.src0), sel(second, p.s2src1, p.s2src0));
+        const float* bbase = SIMPLE ? p.W : sel(main_seg, p.W, p.W2);
+        const __amdgpu_buffer_rsrc_t rsA = desc(abase, sel(main_seg, pixA, (unsigned)M * 4u) * (unsigned)Csrc);
+        const __amdgpu_buffer_rsrc_t rsB = desc(bbase, (unsigned)p.Cout * (unsigned)sel(main_seg, wld, w2ld) * 4u);
         float* As = gbase + stage * CF::STAGE + wmn * 256;             // this wave's first piece
         float* Wst = As + BM * KC;
 #pragma unroll
         for (int j = 0; j < AE; ++j) {
             unsigned base = aoff[j];
-            if constexpr (!SIMPLE) base = main_seg ? (second ? aoff1[j] : aoff[j]) : (second ? soff1[j] : soff0[j]);
+            if constexpr (!SIMPLE) {   // by-value selects (a ternary on array elements selects an ADDRESS: arrays go to scratch)
+                const unsigned o0 = aoff[j], o1 = aoff1[j], o2 = soff0[j], o3 = soff1[j];
+                base = sel(main_seg, sel(second, o1, o0), sel(second, o3, o2));
+            }
             const unsigned off = (amsk[j] & tapbit) ? base + (unsigned)ashift : kOOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + j * CF::GT * 4), 16,
                                                      (int)off, 0, 0, 0);
@@ -416,7 +418,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
 #pragma unroll
         for (int j = 0; j < WE; ++j) {
             unsigned base = woff[j];
-            if constexpr (!SIMPLE) base = main_seg ? woff[j] : w2off[j];
+            if constexpr (!SIMPLE) {
+                const unsigned o0 = woff[j], o1 = w2off[j];
+                base = sel(main_seg, o0, o1);
+            }
             const unsigned off = base + wshift;                        // missing filter row / padding chunk: >= kOOB
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(Wst + j * CF::GT * 4), 16,
                                                      (int)off, 0, 0, 0);
@@ -432,6 +437,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((GL - 2) * (AE + WE)) : "memory");                  \
         __builtin_amdgcn_s_barrier();                                                                          \
         asm volatile("" ::: "memory");                                                                         \
+        /* look-ahead pieces first (maximum time to land), then per MFMA group: fragment reads + 4*NT MFMAs.    \
+           Measured against hoisting all fragment reads / pinning the order with sched_barriers: this plain     \
+           form, which lets the scheduler slide the wait + barrier of the next step above the last MFMA group, \
+           was the fastest on every shape (tools/ab_libs.sh, tools/ab_shapes.sh) */                            \
         issue(kbeg + (IT_) + GL - 1, ((S_) + GL - 1) % GL);                                                    \
         const float* st_ = gbase + (S_) * CF::STAGE;                                                           \
         _Pragma("unroll") for (int g = 0; g < KC / 8; ++g) {                                                   \

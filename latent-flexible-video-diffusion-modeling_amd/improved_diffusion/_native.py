@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "liblfvdm_hip.so")
+LIB_PATH = os.environ.get("LFVDM_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "liblfvdm_hip.so")   # override: A/B builds
 
 ACT_NONE, ACT_SILU = 0, 1
 OUT_ROWS, OUT_NCHW = 0, 1
