@@ -339,6 +339,206 @@ __global__ __launch_bounds__(256) void conv_wgrad_coop_kernel(const lfvdm_conv_a
     }
 }
 
+// --------------------------------------------------------------------------------------------------------
+// LDS-DMA form of the cooperative kernel for raw operands (no GroupNorm coefficients - the default training
+// plan materialises the activated tensors): the dout tile [32][COT*32] and the operand tile [32][KT*32] of a chunk
+// are written straight into LDS by `buffer_load_dwordx4 ... lds` (64 lanes x 16 B = one contiguous 1 KiB piece per
+// wave instruction; per-lane source offsets; rows past M, filters past Cout and taps outside the image pass an
+// out-of-range offset and arrive as zeros).  The tiles are plain unpadded row-major images: the MFMA operands
+// are COLUMN reads (32 consecutive floats of one row per half wave), conflict-free without padding or swizzle.
+// NS stages, chunk c+NS-1 in flight while chunk c is multiplied, one barrier per chunk: counted vmcnt (this
+// wave's pieces of the chunk have landed) + lgkmcnt(0) (its reads of the buffer that is restaged next have returned).
+template <int COT, int KT, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_args p_in, int msplit) {
+    const lfvdm_conv_args p = p_in;
+    constexpr int DLD = COT * 32, ALD = KT * 32;
+    constexpr int DQ = COT * 8, AQ = KT * 8;          // float4 per tile row
+    constexpr int ND = COT, NA = KT;                  // pieces per thread per chunk
+    constexpr int TC = COT / 2, TK = KT / 2;          // tiles per wave along co / k
+    constexpr int STAGE = 32 * DLD + 32 * ALD;        // floats
+    constexpr unsigned kOOB = 0x40000000u;            // >= num_records of both descriptors (checked by the launcher)
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float* bias_red = wsm + NS * STAGE;               // [8][COT * 32]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave & 1, wk = wave >> 1;
+
+    const int Cin = p.C0 + p.C1;
+    const int taps = p.ksize * p.ksize;
+    const int cpg = Cin / (32 * KT);
+    const int NCG = (p.Cout + 32 * COT - 1) / (32 * COT);
+    const int HoWo = p.Ho * p.Wo;
+    const int M = p.N * HoWo;
+    const int nchunks = (M + 31) / 32;
+
+    const int task = blockIdx.x;                       // (k group, co group, m slice)
+    const int ms = task % msplit;
+    const int cg = (task / msplit) % NCG;
+    const int kg = task / (msplit * NCG);
+    const int tap = kg / cpg;
+    const int cc = (kg - tap * cpg) * 32 * KT;
+    const int dy = p.ksize == 3 ? tap / 3 - 1 : 0;
+    const int dx = p.ksize == 3 ? tap - (tap / 3) * 3 - 1 : 0;
+    const bool second = cc >= p.C0;
+    const float* src = selv(second, p.src1, p.src0);
+    const int Csrc = selv(second, p.C1, p.C0);
+    const int cl = second ? cc - p.C0 : cc;
+    const int Hin = p.up ? 2 * p.Hs : p.Hs, Win = p.up ? 2 * p.Ws : p.Ws;
+    const int c_beg = (int)(((long)nchunks * ms) / msplit), c_end = (int)(((long)nchunks * (ms + 1)) / msplit);
+    const int co0 = cg * 32 * COT;
+    const float rHoWo = 1.0f / (float)HoWo, rWo = 1.0f / (float)p.Wo;
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)((unsigned)M * p.ldr * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)src, 0, (int)((unsigned)p.N * p.Hs * p.Ws * Csrc * 4u), 0x00020000);
+
+    const int dcol = (tid % DQ) * 4, drow0 = tid / DQ;
+    const int acol = (tid % AQ) * 4, arow0 = tid / AQ;
+    constexpr int DRS = 256 / DQ, ARS = 256 / AQ;
+    const unsigned dbase = (co0 + dcol < p.Cout) ? (unsigned)(co0 + dcol) * 4u : kOOB;
+    const unsigned abase = (unsigned)(cl + acol) * 4u;
+    const int upsh = p.up ? 1 : 0;
+
+    f32x16 acc[TC][TK];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bias = kg == 0 && p.bias != nullptr;    // workgroup-uniform
+
+    auto issue = [&](int c, int stage) {
+        const int m0 = c * 32;
+        const bool live = c < c_end;
+        float* Ds = wsm + stage * STAGE + wave * 256;          // this wave's first piece
+        float* As = wsm + stage * STAGE + 32 * DLD + wave * 256;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int m = m0 + drow0 + i * DRS;
+            const unsigned off = (live && m < M) ? dbase + (unsigned)m * p.ldr * 4u : kOOB;   // dbase >= kOOB: filter past Cout
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(Ds + i * 1024), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + arow0 + i * ARS;
+            const bool valid = live && m < M;
+            const int mm = valid ? m : 0;
+            const int n = fdiv(mm, HoWo, rHoWo);
+            const int rem = mm - n * HoWo;
+            const int oy = fdiv(rem, p.Wo, rWo);
+            const int ox = rem - oy * p.Wo;
+            const int iy = oy * p.stride + dy, ix = ox * p.stride + dx;
+            const bool inb = valid && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+            const int sy = iy >> upsh, sx = ix >> upsh;
+            const unsigned off = inb ? abase + (unsigned)((n * p.Hs + sy) * p.Ws + sx) * Csrc * 4u : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + i * 1024), 16, (int)off, 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < NS - 1; ++d) issue(c_beg + d, d);
+    int stage = 0;
+    for (int c = c_beg; c < c_end; ++c) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * (ND + NA)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int nxt = stage + NS - 1;
+        nxt = nxt >= NS ? nxt - NS : nxt;
+        issue(c + NS - 1, nxt);
+        const float* Dst = wsm + stage * STAGE;
+        const float* Ast = Dst + 32 * DLD;
+        if (want_bias) {        // column sums of this slice's dout rows (each thread re-reads the slots of its own pieces)
+#pragma unroll
+            for (int i = 0; i < ND; ++i) bsum += ld4(Dst + (drow0 + i * DRS) * DLD + dcol);
+        }
+        const float* dcolp = Dst + wc * TC * 32 + (lane & 31);
+        const float* acolp = Ast + wk * TK * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mrow = 8 * g + 4 * (lane >> 5) + e;
+                float a[TC], b[TK];
+#pragma unroll
+                for (int x = 0; x < TC; ++x) a[x] = dcolp[mrow * DLD + 32 * x];
+#pragma unroll
+                for (int y = 0; y < TK; ++y) b[y] = acolp[mrow * ALD + 32 * y];
+#pragma unroll
+                for (int x = 0; x < TC; ++x)
+#pragma unroll
+                    for (int y = 0; y < TK; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+            }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // zero-filled look-ahead pieces
+    // ---- accumulate the partial tiles (float atomics; D lane l: column k = l&31, rows (r&3)+8*(r>>2)+4*(l>>5))
+    const int Ktot = taps * Cin;
+    float* dW = p.out;
+    const bool oihw = p.out_mode == 1;
+#pragma unroll
+    for (int x = 0; x < TC; ++x)
+#pragma unroll
+        for (int y = 0; y < TK; ++y) {
+            const int ci = cc + (wk * TK + y) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wc * TC + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < p.Cout) {
+                    float* dst = oihw ? dW + ((size_t)co * Cin + ci) * taps + tap : dW + (size_t)co * Ktot + (size_t)tap * Cin + ci;
+                    atomicAdd(dst, acc[x][y][r]);
+                }
+            }
+        }
+    if (want_bias) {
+        __syncthreads();
+        constexpr int BRL = COT * 32;
+        float* br = bias_red + (tid / DQ % 8) * BRL;
+        if (tid / DQ < 8) { br[dcol + 0] = bsum.x; br[dcol + 1] = bsum.y; br[dcol + 2] = bsum.z; br[dcol + 3] = bsum.w; }
+        __syncthreads();
+        for (int rr = 8; rr < DRS; rr += 8) {
+            if (tid / DQ >= rr && tid / DQ < rr + 8) { br[dcol + 0] += bsum.x; br[dcol + 1] += bsum.y; br[dcol + 2] += bsum.z; br[dcol + 3] += bsum.w; }
+            __syncthreads();
+        }
+        if (tid < COT * 32 && co0 + tid < p.Cout) {
+            float t = 0.f;
+            const int nr = DRS < 8 ? DRS : 8;
+            for (int r = 0; r < nr; ++r) t += bias_red[r * BRL + tid];
+            atomicAdd(const_cast<float*>(p.bias) + co0 + tid, t);
+        }
+    }
+}
+
+// raw operands whose tensors are addressable with 32-bit byte offsets below 2^30: LDS-DMA kernel
+static bool wgrad_dma_ok(const lfvdm_conv_args* a, long M) {
+    const bool off = getenv("LFVDM_WGRAD_NO_DMA") != nullptr;             // A/B aid (read per launch: tests toggle it)
+    const long Cmax = a->C0 > a->C1 ? a->C0 : a->C1, lim = 1L << 30;
+    return !off && !a->coefA && M * a->ldr * 4 < lim && (long)a->N * a->Hs * a->Ws * Cmax * 4 < lim;
+}
+
+template <int COT, int KT, int NS>
+static int launch_wgrad_dma(const lfvdm_conv_args* a, hipStream_t s, int nchunks) {
+    const int Cin = a->C0 + a->C1;
+    const int NKG = a->ksize * a->ksize * (Cin / (32 * KT));
+    const int NCG = (a->Cout + 32 * COT - 1) / (32 * COT);
+    const long tiles = (long)NKG * NCG;
+    static const long target = getenv("LFVDM_WGRAD_WGS") ? atol(getenv("LFVDM_WGRAD_WGS")) : 384;
+    long msplit = (target + tiles - 1) / tiles;
+    if (msplit > nchunks / 2) msplit = nchunks / 2;
+    if (msplit < 1) msplit = 1;
+    constexpr size_t lds = (size_t)(NS * (32 * COT * 32 + 32 * KT * 32) + 8 * COT * 32) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT, KT, NS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return LFVDM_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT, KT, NS>), dim3((unsigned)(tiles * msplit)), dim3(256), lds, s, *a, (int)msplit);
+    return LFVDM_OK;
+}
+
 template <int COT, int KT>
 static void launch_wgrad_coop(const lfvdm_conv_args* a, hipStream_t s, int nchunks) {
     const int Cin = a->C0 + a->C1;
@@ -486,6 +686,15 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
         }
         if (cot && kt && !getenv("LFVDM_WGRAD_WAVE")) {
             hipStream_t s = (hipStream_t)stream;
+            if (wgrad_dma_ok(a, M) && kt == 2) {
+                const int ns = getenv("LFVDM_WGRAD_STAGES") ? atoi(getenv("LFVDM_WGRAD_STAGES")) : 3;
+                int rc;
+                if (cot == 4) rc = ns == 2 ? launch_wgrad_dma<4, 2, 2>(a, s, nchunks) : launch_wgrad_dma<4, 2, 3>(a, s, nchunks);
+                else rc = ns == 2 ? launch_wgrad_dma<2, 2, 2>(a, s, nchunks) : launch_wgrad_dma<2, 2, 3>(a, s, nchunks);
+                if (rc != LFVDM_OK) return rc;
+                LFVDM_CHECK_LAUNCH();
+                return LFVDM_OK;
+            }
             if (cot == 4 && kt == 4) launch_wgrad_coop<4, 4>(a, s, nchunks);
             else if (cot == 4) launch_wgrad_coop<4, 2>(a, s, nchunks);
             else if (kt == 4) launch_wgrad_coop<2, 4>(a, s, nchunks);

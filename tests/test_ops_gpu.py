@@ -661,3 +661,41 @@ def test_conv_concat_and_skip_segment_every_tune_code(nat, N, C0, C1, S0, S1, Co
         nat.conv_igemm_struct(a)
         err = float((from_cl(out, N, H, H, Cout).cpu() - ref).abs().max())
         assert err < 5e-5, f"tune code {code}: max|d| = {err:.3e}"
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,H,k,stride,up", [(10, 128, 0, 128, 16, 3, 1, 0), (5, 64, 0, 96, 5, 3, 1, 0),
+                                                        (6, 64, 64, 160, 8, 1, 1, 0), (4, 64, 0, 64, 8, 3, 2, 0),
+                                                        (3, 128, 0, 128, 4, 3, 1, 1), (40, 256, 0, 128, 2, 3, 1, 0),
+                                                        (2, 32, 0, 32, 6, 3, 1, 0)])
+@pytest.mark.parametrize("variant", ["dma3", "dma2", "regs"])
+def test_conv_wgrad_matches_autograd(nat, monkeypatch, N, C0, C1, Cout, H, k, stride, up, variant):
+    """lfvdm_conv_wgrad (weight + bias gradient of Conv2d / Linear, train_util.py:328 loss.backward()) vs torch
+    autograd: the LDS-DMA kernels (2 / 3 stages) and the register-staged ones, concat sources, stride 2, nearest
+    upsampling, ragged M, filter counts that do not fill the last tile."""
+    import os
+    for key in ("LFVDM_WGRAD_NO_DMA", "LFVDM_WGRAD_STAGES"):
+        monkeypatch.delenv(key, raising=False)
+    if variant == "regs":
+        monkeypatch.setenv("LFVDM_WGRAD_NO_DMA", "1")
+    else:
+        monkeypatch.setenv("LFVDM_WGRAD_STAGES", variant[-1])
+    Cin = C0 + C1
+    x = rnd("wg/x", N, Cin, H, H)
+    w = (rnd("wg/w", Cout, Cin, k, k, scale=0.05)).requires_grad_(True)
+    b = rnd("wg/b", Cout).requires_grad_(True)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    y = F.conv2d(xin, w, b, padding=1 if k == 3 else 0, stride=stride)
+    Ho = y.shape[2]
+    dout = rnd("wg/d", N, Cout, Ho, Ho)
+    y.backward(dout)
+    gp = torch.zeros(Cout, k * k, Cin, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    kw = dict(src0=cl(x[:, :C0]), C0=C0, C1=C1, N=N, Hs=H, Ws=H, Ho=Ho, Wo=Ho, ksize=k, stride=stride, up=up,
+              res=cl(dout), ldr=Cout, out=gp, bias=db, Cout=Cout)
+    if C1:
+        kw["src1"] = cl(x[:, C0:])
+    nat.conv_wgrad(**kw)
+    got_w = gp.view(Cout, k, k, Cin).permute(0, 3, 1, 2).cpu()
+    scale = float(w.grad.abs().max())
+    assert float((got_w - w.grad).abs().max()) < 2e-5 * max(1.0, scale), float((got_w - w.grad).abs().max())
+    assert float((db.cpu() - b.grad).abs().max()) < 2e-5 * max(1.0, float(b.grad.abs().max()))

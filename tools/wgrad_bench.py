@@ -23,6 +23,7 @@ shapes = [(40, 16, 128, 0, 128, 3, 1), (40, 16, 128, 128, 128, 3, 1), (40, 8, 25
           (40, 4, 256, 0, 256, 3, 1), (40, 2, 256, 0, 256, 3, 1), (40, 16, 128, 0, 384, 1, 0), (40, 16, 128, 0, 128, 1, 0),
           (40, 8, 256, 0, 768, 1, 0), (1, 800, 256, 0, 256, 1, 0)]
 for (N, H, C0, C1, Cout, k, coef) in shapes:
+    coef = coef if os.environ.get("WG_COEF") else 0      # the training plan feeds materialised (raw) operands
     Cin = C0 + C1
     M = N * H * H if k == 3 else N * H * (H if N > 1 else 1)
     Hs, Ws = (H, H) if k == 3 else ((H * H, 1) if N > 1 else (H, 1))
