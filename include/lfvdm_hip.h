@@ -86,8 +86,11 @@ typedef struct lfvdm_conv_args {
     float* out;
     int32_t ldo;      /* row stride for LFVDM_OUT_ROWS */
     int32_t out_mode; /* LFVDM_OUT_* */
-    int32_t tune;     /* 0: built-in makespan model picks tile shape / K-chunk (never split-K); otherwise a
-                       * code returned by lfvdm_conv_igemm_candidates (set by an autotuner for a fixed shape) */
+    int32_t tune;     /* 0: built-in makespan model picks tile shape / K-chunk (never split-K; LDS-DMA staging
+                       * whenever the operands are raw); otherwise a code returned by lfvdm_conv_igemm_candidates
+                       * (set by an autotuner for a fixed shape).  Codes are opaque to callers and tied to
+                       * lfvdm_abi_version(): 1 + tile id + 16*(64-channel chunks) + 32*log2(split-K) +
+                       * 256*(0 register staging | 1 LDS-DMA 2 stages | 2 LDS-DMA 3 stages) */
     /* optional workspace enabling deterministic split-K over workgroups for small-M layers: slabs of partial
      * tiles + one arrival ticket per output tile.  The tickets must be ZERO before the first launch; every
      * launch leaves them zero again (the last slice to arrive resets its tile's ticket) */
@@ -101,7 +104,8 @@ int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream);
 /* template instance (NT = 32-column tiles per wave, nwaves = K-split waves per workgroup) that
  * lfvdm_conv_igemm picks for these arguments; profiling aid, launches nothing. */
 int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* nwaves);
-/* legal `tune` codes for these arguments (tile configuration x K-chunk width x split-K factor) */
+/* legal `tune` codes for these arguments (tile configuration x K-chunk width x split-K factor x operand staging);
+ * up to ~100 codes: pass max_codes >= 256 */
 int lfvdm_conv_igemm_candidates(const lfvdm_conv_args* a, int* codes, int max_codes);
 
 /* OIHW [Cout][Cin][k][k] -> [Cout][k*k][Cin] (k in {1,3}); state-dict layout stays OIHW. */
