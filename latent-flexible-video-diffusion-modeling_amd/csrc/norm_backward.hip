@@ -76,10 +76,17 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_stats_kernel(
 }
 
 // pass 2: dx (split over the two concat destinations, overwrite or accumulate)
+struct GnParamGradArgs {
+    const float *gamma, *beta, *film;
+    float *dgamma, *dbeta, *dfilm;
+    int film_ld, dfilm_ld, T;
+};
+
 __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
     const float* __restrict__ da, const float* __restrict__ s0, const float* __restrict__ s1p, int C0, int C1, int P,
     const float* __restrict__ coefA, const float* __restrict__ coefB, const float* __restrict__ stats,
-    const float* __restrict__ sums, int act, float* __restrict__ out0, float* __restrict__ out1, int acc0, int acc1) {
+    const float* __restrict__ sums, int act, float* __restrict__ out0, float* __restrict__ out1, int acc0, int acc1,
+    GnParamGradArgs pg) {
     const int C = C0 + C1;
     const int cg = C / 32;
     const int CW = GB_GPW * cg;
@@ -89,6 +96,24 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
     const int PL = GB_THREADS / Q;
     const int tid = threadIdx.x;
     __shared__ float gS1[GB_GPW], gS2[GB_GPW];
+    if (pg.dgamma != nullptr) {
+        // parameter gradients of this (sample, channel slice), folded in with float atomics (same sums as
+        // gn_param_grads_kernel, one launch less per GroupNorm):
+        //   dgamma[c] += s2 * (1 + scale);  dbeta[c] += s1 * (1 + scale);  dfilm[b][c] += s2*gamma + s1*beta;  dfilm[b][C+c] += s1
+        for (int cc = tid; cc < CW; cc += GB_THREADS) {
+            const int ch = cbase + cc;
+            const float s1 = sums[((size_t)n * C + ch) * 2 + 0], s2 = sums[((size_t)n * C + ch) * 2 + 1];
+            float sc1 = 1.0f;
+            if (pg.film != nullptr) {
+                const int b = n / pg.T;
+                sc1 += pg.film[(size_t)b * pg.film_ld + ch];
+                atomicAdd(pg.dfilm + (size_t)b * pg.dfilm_ld + ch, s2 * pg.gamma[ch] + s1 * pg.beta[ch]);
+                atomicAdd(pg.dfilm + (size_t)b * pg.dfilm_ld + C + ch, s1);
+            }
+            atomicAdd(pg.dgamma + ch, s2 * sc1);
+            atomicAdd(pg.dbeta + ch, s1 * sc1);
+        }
+    }
     if (tid < GB_GPW) {
         const int g = blockIdx.y * GB_GPW + tid;
         const float rstd = stats[((size_t)n * 32 + g) * 2 + 1];
@@ -330,8 +355,26 @@ extern "C" int lfvdm_gn_bwd_apply(const float* da, const float* src0, const floa
     const int C = C0 + C1;
     if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
     if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
+    const GnParamGradArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1};
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
-                       C0, C1, P, coefA, coefB, stats, sums, act, out0, out1, acc0, acc1);
+                       C0, C1, P, coefA, coefB, stats, sums, act, out0, out1, acc0, acc1, none);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_bwd_apply_params(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                                         const float* coefA, const float* coefB, const float* stats, const float* sums,
+                                         int act, float* out0, float* out1, int acc0, int acc1, const float* gamma,
+                                         const float* beta, const float* film, int film_ld, int T, float* dgamma,
+                                         float* dbeta, float* dfilm, int dfilm_ld, void* stream) {
+    const int C = C0 + C1;
+    if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
+    if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
+    if (!dgamma || !dbeta) return LFVDM_E_SHAPE;
+    if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T || film_ld < 2 * C || dfilm_ld < 2 * C)) return LFVDM_E_SHAPE;
+    const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1};
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
+                       C0, C1, P, coefA, coefB, stats, sums, act, out0, out1, acc0, acc1, pg);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

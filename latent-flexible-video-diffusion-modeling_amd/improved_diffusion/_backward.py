@@ -336,19 +336,20 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
                                    act, nat.ptr(sums), nat.stream()), "lfvdm_gn_bwd_stats")
     dxa = _new(N * P, C0, like=da)
     dxb = _new(N * P, C1, like=da) if C1 else None
+    if inplace:
+        # dx and the parameter gradients in ONE launch (float atomics into .grad / the FiLM gradient slot)
+        dfilm = None
+        if film is not None:       # accumulated into the caller's (zeroed) slot of the embedding network's gradient buffer
+            dfilm = dfilm_out if dfilm_out is not None else th.zeros(N // T, 2 * C, device=da.device, dtype=th.float32)
+        nat.check(L.lfvdm_gn_bwd_apply_params(
+            nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats), nat.ptr(sums), act,
+            nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.ptr(gamma), nat.ptr(beta),
+            film.data_ptr() if film is not None else None, film.stride(0) if film is not None else 0, T,
+            nat.ptr(_grad_of(gamma)), nat.ptr(_grad_of(beta)), dfilm.data_ptr() if dfilm is not None else None,
+            dfilm.stride(0) if dfilm is not None else 0, nat.stream()), "lfvdm_gn_bwd_apply_params")
+        return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
     nat.check(L.lfvdm_gn_bwd_apply(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
                                    nat.ptr(sums), act, nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.stream()), "lfvdm_gn_bwd_apply")
-    if inplace:
-        # parameter gradients accumulated in place by one small kernel (no reductions / AccumulateGrad adds)
-        dfilm = None
-        if film is not None:       # written into the caller's slot (the embedding network's gradient buffer) if given
-            dfilm = dfilm_out if dfilm_out is not None else _new(N // T, 2 * C, like=da)
-        nat.check(L.lfvdm_gn_param_grads(nat.ptr(sums), nat.ptr(gamma), nat.ptr(beta),
-                                         film.data_ptr() if film is not None else None, film.stride(0) if film is not None else 0,
-                                         T, nat.ptr(_grad_of(gamma)), nat.ptr(_grad_of(beta)),
-                                         dfilm.data_ptr() if dfilm is not None else None,
-                                         dfilm.stride(0) if dfilm is not None else 0, N, C, nat.stream()), "lfvdm_gn_param_grads")
-        return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
     s1, s2 = sums[..., 0], sums[..., 1]              # [N][C]: sum dz, sum dz*xhat
     assert dfilm_out is None, "gradient slots belong to the in-place mode"
     if film is not None:
