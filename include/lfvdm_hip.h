@@ -192,12 +192,13 @@ int lfvdm_gn_bwd_apply(const float* da, const float* src0, const float* src1, in
                        float* out0, float* out1, int acc0, int acc1, void* stream);
 /* lfvdm_gn_bwd_apply + the GroupNorm(+FiLM) parameter gradients in the same launch: dgamma / dbeta [C] and dfilm
  * [N/T][2C] (when film != NULL; zero it first) are ACCUMULATED with float atomics (same sums as lfvdm_gn_param_grads,
- * summation order not fixed). */
+ * summation order not fixed).  add (optional, rows [N*P][add_ld], add_ld >= C0+C1): a second gradient of the same
+ * input - e.g. the skip path of a ResBlock - added to dx on the way out. */
 int lfvdm_gn_bwd_apply_params(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
                               const float* coefA, const float* coefB, const float* stats, const float* sums, int act,
                               float* out0, float* out1, int acc0, int acc1, const float* gamma, const float* beta,
                               const float* film, int film_ld, int T, float* dgamma, float* dbeta, float* dfilm,
-                              int dfilm_ld, void* stream);
+                              int dfilm_ld, const float* add, int add_ld, void* stream);
 /* GroupNorm(+FiLM) parameter gradients from the sums of lfvdm_gn_bwd_stats: dgamma / dbeta [C] are ACCUMULATED
  * (+=, fixed order), dfilm [N/T][2C] (d scale | d shift of unet.py:199-203; row strides film_ld / dfilm_ld) is
  * written when film != NULL. */

@@ -80,6 +80,8 @@ struct GnParamGradArgs {
     const float *gamma, *beta, *film;
     float *dgamma, *dbeta, *dfilm;
     int film_ld, dfilm_ld, T;
+    const float* add;     // optional [N*P][add_ld] rows added to dx (the skip path's gradient of a ResBlock input)
+    int add_ld;
 };
 
 __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
         f32x4 dx = A * dz - rs * (S1 + xh * S2);     // rstd*g'*dz == A*dz
         float* o = out + (pos0 + p) * Cd + cd;
         if (acc) dx += ld4(o);
+        if (pg.add != nullptr) dx += ld4(pg.add + (pos0 + p) * pg.add_ld + c);
         st4(o, dx);
     }
 }
@@ -355,7 +358,7 @@ extern "C" int lfvdm_gn_bwd_apply(const float* da, const float* src0, const floa
     const int C = C0 + C1;
     if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
     if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
-    const GnParamGradArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1};
+    const GnParamGradArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, nullptr, 0};
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
                        C0, C1, P, coefA, coefB, stats, sums, act, out0, out1, acc0, acc1, none);
     LFVDM_CHECK_LAUNCH();
@@ -366,13 +369,15 @@ extern "C" int lfvdm_gn_bwd_apply_params(const float* da, const float* src0, con
                                          const float* coefA, const float* coefB, const float* stats, const float* sums,
                                          int act, float* out0, float* out1, int acc0, int acc1, const float* gamma,
                                          const float* beta, const float* film, int film_ld, int T, float* dgamma,
-                                         float* dbeta, float* dfilm, int dfilm_ld, void* stream) {
+                                         float* dbeta, float* dfilm, int dfilm_ld, const float* add, int add_ld,
+                                         void* stream) {
     const int C = C0 + C1;
     if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
     if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
     if (!dgamma || !dbeta) return LFVDM_E_SHAPE;
+    if (add && (add_ld < C || add_ld % 4)) return LFVDM_E_SHAPE;
     if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T || film_ld < 2 * C || dfilm_ld < 2 * C)) return LFVDM_E_SHAPE;
-    const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1};
+    const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1, add, add_ld};
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
                        C0, C1, P, coefA, coefB, stats, sums, act, out0, out1, acc0, acc1, pg);
     LFVDM_CHECK_LAUNCH();

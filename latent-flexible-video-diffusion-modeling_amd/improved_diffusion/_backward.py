@@ -327,8 +327,9 @@ def _gn_forward(a, b, C0, C1, N, P, gamma, beta, film, T):
 
 
 def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, T, want_dx=(True, True), dfilm_out=None,
-                 inplace=False):
-    """Returns (dx_a, dx_b, dgamma, dbeta, dfilm).  da: [N*P][C] gradient w.r.t. act(GN(x))."""
+                 inplace=False, add=None):
+    """Returns (dx_a, dx_b, dgamma, dbeta, dfilm).  da: [N*P][C] gradient w.r.t. act(GN(x)).  add: optional
+    [N*P][C] rows (a second gradient of the same input) folded into dx by the in-place kernel."""
     C = C0 + C1
     sums = _new(N, C, 2, like=da)
     L = nat.lib()
@@ -346,10 +347,15 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
             nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.ptr(gamma), nat.ptr(beta),
             film.data_ptr() if film is not None else None, film.stride(0) if film is not None else 0, T,
             nat.ptr(_grad_of(gamma)), nat.ptr(_grad_of(beta)), dfilm.data_ptr() if dfilm is not None else None,
-            dfilm.stride(0) if dfilm is not None else 0, nat.stream()), "lfvdm_gn_bwd_apply_params")
+            dfilm.stride(0) if dfilm is not None else 0, nat.ptr(add), add.stride(0) if add is not None else 0,
+            nat.stream()), "lfvdm_gn_bwd_apply_params")
         return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
     nat.check(L.lfvdm_gn_bwd_apply(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
                                    nat.ptr(sums), act, nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.stream()), "lfvdm_gn_bwd_apply")
+    if add is not None:
+        dxa = dxa + add[:, :C0]
+        if dxb is not None:
+            dxb = dxb + add[:, C0:]
     s1, s2 = sums[..., 0], sums[..., 1]              # [N][C]: sum dz, sum dz*xhat
     assert dfilm_out is None, "gradient slots belong to the in-place mode"
     if film is not None:
@@ -438,19 +444,16 @@ class ResBlockFn(th.autograd.Function):
         dw1, db1 = wgrad(pw1, pb1, src0=act1, C0=Cin, res=dh1, ldr=Cout, **geo)
         da1 = _new(N * P, Cin, like=a)
         nat.conv_igemm(src0=dh1, C0=Cout, W=_pack_t(w1), Cout=Cin, out=da1, ldo=Cin, **geo)
-        dxa, dxb, dg1, dbe1, _ = _gn_backward(da1, a, b, C0, C1, N, P, cA1, cB1, st1, nat.ACT_SILU, g1, be1, None, T,
-                                              inplace=inplace)
-        # skip path
+        # skip path first: its gradient w.r.t. the block input is folded into the GroupNorm-1 backward launch
         dws = dbs = None
         if ws is None:
-            dxa = dxa + dout
+            skip_grad = dout                       # identity skip (C1 == 0, Cin == Cout)
         else:
             dws, dbs = wgrad(pws, pbs, src0=a, src1=b, C0=C0, C1=C1, ksize=1, res=dout, ldr=Cout, **geo)
-            dsk = _new(N * P, Cin, like=a)
-            nat.conv_igemm(src0=dout, C0=Cout, ksize=1, W=_pack_t(ws), Cout=Cin, out=dsk, ldo=Cin, **geo)
-            dxa = dxa + dsk[:, :C0]
-            if dxb is not None:
-                dxb = dxb + dsk[:, C0:]
+            skip_grad = _new(N * P, Cin, like=a)
+            nat.conv_igemm(src0=dout, C0=Cout, ksize=1, W=_pack_t(ws), Cout=Cin, out=skip_grad, ldo=Cin, **geo)
+        dxa, dxb, dg1, dbe1, _ = _gn_backward(da1, a, b, C0, C1, N, P, cA1, cB1, st1, nat.ACT_SILU, g1, be1, None, T,
+                                              inplace=inplace, add=skip_grad)
         return (dxa, dxb, dfilm, dg1, dbe1, dw1, db1, dg2, dbe2, dw2, db2, dws, dbs, None, None, None, None, None, None)
 
 
