@@ -69,6 +69,14 @@ def conv_flops(a):
     return 2.0 * M * a.Cout * K
 
 
+def conv_bytes(a):
+    """Compulsory bytes of one implicit-GEMM launch: every operand once (sources, packed weights, residual) + the output."""
+    M = a.N * a.Ho * a.Wo
+    src = a.N * a.Hs * a.Ws * (a.C0 + a.C1) + M * (a.s2C0 + a.s2C1)
+    w = a.Cout * (a.ksize * a.ksize * (a.C0 + a.C1) + a.s2C0 + a.s2C1)
+    return 4.0 * (src + w + M * a.Cout * (2 if a.res else 1))
+
+
 def kernel_breakdown(plan, reps=10, inner=4):
     """Per-launch HIP-event timing of every step of the forward plan (eager, on the stream the kernels are launched
     on).  Each step is launched `inner` times back to back between one event pair, which amortises the ~5 us that
@@ -93,7 +101,7 @@ def kernel_breakdown(plan, reps=10, inner=4):
     groups = {}
     for i, (fn, args) in enumerate(plan.steps):
         name = fn.__name__
-        flops = 0.0
+        flops = nbytes = 0.0
         if name == "lfvdm_conv_igemm":
             a = args[0]._obj
             nt, nw = C.c_int(), C.c_int()
@@ -101,10 +109,12 @@ def kernel_breakdown(plan, reps=10, inner=4):
             v = nt.value
             name = f"conv_igemm_kernel<{v // 1000},{v // 100 % 10},{v // 10 % 10},{v % 10}>"
             flops = conv_flops(a)
-        gsum = groups.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+            nbytes = conv_bytes(a)
+        gsum = groups.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
         gsum["launches"] += 1
         gsum["ms"] += tot[i] / reps
         gsum["flops"] += flops
+        gsum["bytes"] += nbytes
     return groups
 
 
@@ -380,7 +390,7 @@ def main():
             # dominant kernel = the implicit-GEMM template (conv_igemm_kernel): its tile-shape instances together are
             # ~60 % of the step; which instance leads depends on the tuner's picks, so the family is reported as one
             dom = {"flops": sum(g["flops"] for g in convs.values()), "ms": sum(g["ms"] for g in convs.values()),
-                   "launches": sum(g["launches"] for g in convs.values())}
+                   "launches": sum(g["launches"] for g in convs.values()), "bytes": sum(g["bytes"] for g in convs.values())}
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             tr = [(pmc_traffic(k), g["launches"]) for k, g in convs.items()]
             traffic = (round(sum(t * n for t, n in tr if t is not None) / max(1, sum(n for t, n in tr if t is not None)))
@@ -388,6 +398,7 @@ def main():
             lead_name, lead = max(convs.items(), key=lambda kv: kv[1]["ms"])
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "algorithmic_bytes": round(dom["bytes"] / dom["launches"]),
                                "kernel": "conv_igemm_kernel (all tile-shape instances of the implicit GEMM)",
                                "launches_per_step": dom["launches"],
                                "avg_launch_us": round(1000.0 * dom["ms"] / dom["launches"], 2),
@@ -395,7 +406,8 @@ def main():
                                                     "tflops": round(lead["flops"] / (lead["ms"] * 1e-3) / 1e12, 2)},
                                "note": "fp32 MFMA (shares the vector ALUs with VALU on gfx950: 157.3 TFLOP/s is the peak of both together); "
                                        "achieved = algorithmic conv/GEMM FLOPs of these launches / their HIP-event time; "
-                                       "traffic = launch-weighted mean of the PMC bytes per launch"}
+                                       "traffic = launch-weighted mean of the PMC bytes per launch (L2 fills + write-backs; every XCD "
+                                       "that runs a filter tile fetches its weights); algorithmic_bytes = operands + output once"}
             all_conv_flops = sum(g["flops"] for g in convs.values())
             all_conv_ms = sum(g["ms"] for g in convs.values())
             out["breakdown"] = {"eager_sum_ms": round(tot_ms, 4), "launches": len(sampler.plan.steps),
