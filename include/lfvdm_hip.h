@@ -108,6 +108,16 @@ int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* nwaves);
  * up to ~100 codes: pass max_codes >= 256 */
 int lfvdm_conv_igemm_candidates(const lfvdm_conv_args* a, int* codes, int max_codes);
 
+/* Several small weight-gradient launches as ONE (the wave-private kernel: a wave owns a 32 x 32 tile of dW for a
+ * slice of M): job i covers wave tasks [task0, task0 + ntasks), ntasks = taps * (Cin/32) * ceil(Cout/32) * msplit;
+ * jobs sorted by task0.  Same argument meaning as lfvdm_conv_wgrad. */
+typedef struct lfvdm_wgrad_job {
+    lfvdm_conv_args a;
+    int32_t msplit;
+    int32_t task0;
+} lfvdm_wgrad_job;
+int lfvdm_conv_wgrad_grouped(const lfvdm_wgrad_job* jobs_dev, int njobs, int total_tasks, void* stream);
+
 /* OIHW [Cout][Cin][k][k] -> [Cout][k*k][Cin] (k in {1,3}); state-dict layout stays OIHW. */
 int lfvdm_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int ksize, void* stream);
 
@@ -263,10 +273,39 @@ typedef struct lfvdm_rpe_job {
     float* R;           /* [B][T][T][C] */
     int32_t C;
     int32_t tile0;      /* first workgroup index of this job */
+    int32_t tproj_ld;   /* row stride of tproj (>= C) */
+    int32_t pad_;
+    float* act;         /* optional [B*T*T][C]: the hidden activations SiLU(...) (operand of the output layer's weight
+                         * gradient in training); NULL = not stored */
 } lfvdm_rpe_job;
 
 int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, const int64_t* frame_indices_i64,
                    int B, int T, void* stream);
+
+/* Backward of the RPE networks of a training step in ONE launch (autograd of rpe.py:20-31 through the output layer's
+ * input and the hidden layer): per job, from dR [B*T*T][C],
+ *   d_act = dR * Wout  (Wout_t = Wout transposed, [C in][C out] as packed by lfvdm_pack_conv_weight_t),
+ *   dhid = d_act * silu'(hid)  (hid recomputed from tproj, Wd, bd and the frame indices),
+ *   dtproj[b][c] += sum_{t,s} dhid,  dWd[c][j] += sum dhid * feats[j],  dbd[c] += sum dhid      (float atomics).
+ * The output layer's own weight / bias gradient is a lfvdm_conv_wgrad_grouped job on the stored activations.
+ * Needs T*T >= 32 (a 32-row tile then spans at most two batch elements) and C % 32 == 0. */
+typedef struct lfvdm_rpe_bwd_job {
+    const float* tproj; /* [B][C], row stride tproj_ld */
+    const float* Wd;    /* [C][3] */
+    const float* bd;    /* [C] */
+    const float* Wout_t;/* [C][C]: Wout_t[c][o] = Wout[o][c] */
+    const float* dR;    /* [B*T*T][C] */
+    float* dtproj;      /* [B][C], row stride dtproj_ld, accumulated */
+    float* dWd;         /* [C][3], accumulated */
+    float* dbd;         /* [C], accumulated */
+    int32_t C;
+    int32_t tile0;
+    int32_t tproj_ld;
+    int32_t dtproj_ld;
+} lfvdm_rpe_bwd_job;
+
+int lfvdm_rpe_nets_bwd(const lfvdm_rpe_bwd_job* jobs_dev, int njobs, int total_tiles, const int64_t* frame_indices_i64,
+                       int B, int T, void* stream);
 
 /* Hidden layer of one RPENet for the training path (rpe.py:20-31 before the output layer) and its backward:
  *   act[r][c] = silu(tproj[b][c] + Wd[c][0..2] . feats[r][0..2] + bd[c]),  rows r = (b, t, s), rows_per_b = T*T,

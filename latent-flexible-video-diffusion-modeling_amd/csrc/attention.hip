@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void rpe_nets_kernel(const lfvdm_rpe_job* __re
         if (rowf[r][3] >= 0.f) {
             const int b = (int)rowf[r][3];
             const float hd = (rowf[r][0] * J.Wd[k * 3 + 0] + rowf[r][1] * J.Wd[k * 3 + 1] + rowf[r][2] * J.Wd[k * 3 + 2]) + J.bd[k];
-            v = silu_f(J.tproj[b * C + k] + hd);
+            v = silu_f(J.tproj[b * J.tproj_ld + k] + hd);
+            if (J.act != nullptr) J.act[(size_t)(m0 + r) * C + k] = v;
         }
         As[r * ALD + k] = v;
     }

@@ -508,6 +508,110 @@ __global__ __launch_bounds__(256) void rpe_front_bwd_kernel(const float* __restr
     }
 }
 
+// ======================================================================================
+// Backward of all RPE networks of a training step in one launch (see lfvdm_rpe_bwd_job).  Same decomposition as the
+// forward lfvdm_rpe_nets: workgroup = (network, 32 rows (b, t, s)); the dR tile [32][C] sits in LDS, every wave walks
+// n tiles of 32 hidden channels: d_act = dR * Wout on fp32 MFMA (Wout_t chunks staged wave-privately), then the
+// hidden layer's backward on the accumulator registers - lane l holds channel c = 32 nt + (l & 31) of 16 rows,
+// the two half waves (l, l + 32) are folded with one shuffle and lanes 0..31 issue the float atomics.
+// ======================================================================================
+constexpr int RPB_LDR = 36;
+
+__global__ __launch_bounds__(256) void rpe_nets_bwd_kernel(const lfvdm_rpe_bwd_job* __restrict__ jobs, int njobs,
+                                                           const int64_t* __restrict__ fi, int B, int T) {
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].tile0 <= (int)blockIdx.x) ++j;
+    const lfvdm_rpe_bwd_job J = jobs[j];
+    const int C = J.C;
+    const int TT = T * T;
+    const int M = B * TT;
+    const int m0 = ((int)blockIdx.x - J.tile0) * 32;
+    const int ALD = C + 4;
+    float* As = rsm;                                        // [32][ALD] dR rows
+    float* Wst = rsm + 32 * ALD + wave * 32 * RPB_LDR;      // wave-private Wout_t chunk [32][36]
+    __shared__ float rowf[32][4];                           // f0, f1, f2, batch index (or -1 past the end)
+    if (threadIdx.x < 32) {
+        const int m = m0 + threadIdx.x;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, fb = -1.f;
+        if (m < M) {
+            const int b = m / TT;
+            const int rem = m - b * TT;
+            const int t = rem / T, s = rem - t * T;
+            const float d = (float)(fi[b * T + t] - fi[b * T + s]);
+            f0 = log1pf(fmaxf(d, 0.f));
+            f1 = log1pf(fmaxf(-d, 0.f));
+            f2 = d == 0.f ? 1.f : 0.f;
+            fb = (float)b;
+        }
+        rowf[threadIdx.x][0] = f0; rowf[threadIdx.x][1] = f1; rowf[threadIdx.x][2] = f2; rowf[threadIdx.x][3] = fb;
+    }
+    for (int e = threadIdx.x; e < 32 * (C / 4); e += 256) {
+        const int r = e / (C / 4), k = (e - r * (C / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + r < M) v = ld4(J.dR + (size_t)(m0 + r) * C + k);
+        st4(As + r * ALD + k, v);
+    }
+    __syncthreads();
+    const int b_lo = m0 / TT;                               // T*T >= 32: the tile spans batch elements b_lo, b_lo + 1
+    const int st_off = (lane >> 3) * RPB_LDR + (lane & 7) * 4;
+    const int frw = (lane & 31) * RPB_LDR + (lane >> 5) * 4;
+    const int fra = (lane & 31) * ALD + (lane >> 5) * 4;
+    for (int nt = wave; nt * 32 < C; nt += 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int kc = 0; kc < C; kc += 32) {                // d_act[r][c] = sum_o dR[r][o] * Wout_t[c][o]
+            f32x4 w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = ld4(J.Wout_t + (size_t)(nt * 32 + r * 8 + (lane >> 3)) * C + kc + (lane & 7) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st4(Wst + r * 8 * RPB_LDR + st_off, w[r]);
+            wave_lds_fence();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a4 = ld4(As + fra + kc + g * 8);
+                const f32x4 b4 = ld4(Wst + frw + g * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
+            }
+            wave_lds_fence();
+        }
+        const int c = nt * 32 + (lane & 31);
+        const float w0 = J.Wd[(size_t)c * 3], w1 = J.Wd[(size_t)c * 3 + 1], w2 = J.Wd[(size_t)c * 3 + 2], bdc = J.bd[c];
+        const float tp_lo = J.tproj[(size_t)min(b_lo, B - 1) * J.tproj_ld + c] + bdc;
+        const float tp_hi = J.tproj[(size_t)min(b_lo + 1, B - 1) * J.tproj_ld + c] + bdc;
+        float s_lo = 0.f, s_hi = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            const float fb = rowf[r][3];
+            if (fb >= 0.f) {
+                const bool hi = (int)fb != b_lo;
+                const float f0 = rowf[r][0], f1 = rowf[r][1], f2 = rowf[r][2];
+                const float h = (hi ? tp_hi : tp_lo) + w0 * f0 + w1 * f1 + w2 * f2;
+                const float sg = 1.0f / (1.0f + __expf(-h));
+                const float d = acc[i] * sg * (1.0f + h * (1.0f - sg));
+                s_lo += hi ? 0.f : d;
+                s_hi += hi ? d : 0.f;
+                s0 += d * f0; s1 += d * f1; s2 += d * f2;
+            }
+        }
+        s_lo += __shfl_xor(s_lo, 32, 64); s_hi += __shfl_xor(s_hi, 32, 64);
+        s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (lane < 32) {
+            atomicAdd(J.dtproj + (size_t)b_lo * J.dtproj_ld + c, s_lo);
+            if (b_lo + 1 < B && (m0 + 31) / TT != b_lo) atomicAdd(J.dtproj + (size_t)(b_lo + 1) * J.dtproj_ld + c, s_hi);
+            atomicAdd(J.dbd + c, s_lo + s_hi);
+            atomicAdd(J.dWd + (size_t)c * 3 + 0, s0);
+            atomicAdd(J.dWd + (size_t)c * 3 + 1, s1);
+            atomicAdd(J.dWd + (size_t)c * 3 + 2, s2);
+        }
+    }
+}
+
 template <int TMAX, int FC>
 int launch_tb(const float* qkv, const float* d_o, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* Pg,
               float* dSg, float* dqkv, int B, int T, int P, int C, int heads, hipStream_t s) {
@@ -590,6 +694,23 @@ extern "C" int lfvdm_rpe_front_bwd(const float* tproj, int tproj_ld, const float
     hipLaunchKernelGGL(rpe_front_bwd_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B, (unsigned)((rows_per_b + chunk - 1) / chunk)),
                        dim3(256), 0, (hipStream_t)stream, tproj, tproj_ld, feats, Wd, bd, d_act, dtproj, dtproj_ld, dWd, dbd, rows_per_b, C,
                        chunk);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_rpe_nets_bwd(const lfvdm_rpe_bwd_job* jobs_dev, int njobs, int total_tiles, const int64_t* fi, int B,
+                                  int T, void* stream) {
+    if (!jobs_dev || !fi || njobs <= 0 || total_tiles <= 0 || B <= 0 || T <= 0 || T * T < 32) return LFVDM_E_SHAPE;
+    const int maxC = 512;    // LDS sized for the largest supported C: dR tile 32*(C+4) + 4 wave-private W chunks
+    const size_t lds = (size_t)(32 * (maxC + 4) + 4 * 32 * RPB_LDR) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rpe_nets_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return LFVDM_E_LAUNCH;
+        attr = true;
+    }
+    hipLaunchKernelGGL(rpe_nets_bwd_kernel, dim3(total_tiles), dim3(256), lds, (hipStream_t)stream, jobs_dev, njobs, fi, B, T);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

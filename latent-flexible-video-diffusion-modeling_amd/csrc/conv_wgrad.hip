@@ -41,13 +41,9 @@ __device__ __forceinline__ T selv(bool c, T a, T b) {
 // args reuse lfvdm_conv_args: src*/C*/N/Hs/Ws/up/stride/ksize/Ho/Wo/coefA/coefB/act describe the forward
 // operand; `res` = dout rows [M][ldr] (ldr >= Cout); `out` = packed dW [Cout][taps*Cin] (accumulated);
 // `bias` (non-const use) = db [Cout] or NULL.
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const lfvdm_conv_args p_in, int msplit) {
-    const lfvdm_conv_args p = p_in;
-    __shared__ __attribute__((aligned(16))) float smem[4][2 * 32 * WLD];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* Ds = smem[wave];            // dout tile [32 m][32 co]
-    float* As = Ds + 32 * WLD;         // a tile    [32 m][32 k]
+// one wave task (k tile, co tile, m slice) of a weight-gradient launch; Ds = this wave's private LDS (2 * 32 * WLD floats)
+__device__ __forceinline__ void wgrad_wave_task(const lfvdm_conv_args& p, int msplit, long task, float* Ds, int lane) {
+    float* As = Ds + 32 * WLD;         // a tile [32 m][32 k]; Ds: dout tile [32 m][32 co]
 
     const int Cin = p.C0 + p.C1;
     const int taps = p.ksize * p.ksize;
@@ -59,7 +55,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const lfvdm_conv_args p
     const int nchunks = (M + 31) / 32;
 
     // wave task = (k tile, co tile, m slice)
-    const long task = (long)blockIdx.x * 4 + wave;
     const long ntasks = (long)NKT * NCT * msplit;
     if (task >= ntasks) return;
     const int ms = (int)(task % msplit);
@@ -161,6 +156,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const lfvdm_conv_args p
             atomicAdd(db + co0 + col + 2, bsum.z); atomicAdd(db + co0 + col + 3, bsum.w);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const lfvdm_conv_args p_in, int msplit) {
+    const lfvdm_conv_args p = p_in;
+    __shared__ __attribute__((aligned(16))) float smem[4][2 * 32 * WLD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    wgrad_wave_task(p, msplit, (long)blockIdx.x * 4 + wave, smem[wave], lane);
+}
+
+// Grouped form: the waves of a workgroup may belong to different jobs (wave-private LDS, no workgroup barrier);
+// the job's arguments are read from the device table with scalar loads.
+__global__ __launch_bounds__(256) void conv_wgrad_grouped_kernel(const lfvdm_wgrad_job* __restrict__ jobs, int njobs,
+                                                                 int total_tasks) {
+    __shared__ __attribute__((aligned(16))) float smem[4][2 * 32 * WLD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = (int)blockIdx.x * 4 + wave;
+    if (task >= total_tasks) return;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                       // last job with task0 <= task
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].task0 <= task) lo = mid; else hi = mid - 1;
+    }
+    const lfvdm_conv_args p = jobs[lo].a;
+    wgrad_wave_task(p, jobs[lo].msplit, (long)(task - jobs[lo].task0), smem[wave], lane);
 }
 
 // --------------------------------------------------------------------------------------------------------
@@ -710,6 +731,14 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
     const long ntasks = tiles * msplit;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a,
                        (int)msplit);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_conv_wgrad_grouped(const lfvdm_wgrad_job* jobs_dev, int njobs, int total_tasks, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_tasks <= 0) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(conv_wgrad_grouped_kernel, dim3((unsigned)((total_tasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       jobs_dev, njobs, total_tasks);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -186,7 +186,7 @@ class Plan:
                     Rb = self.buf(B, T, T, Cc)
                     self.R[r] = Rb
                     rjobs.append(nat.RpeJob(_p(self.tproj[r]), _p(net.embed_distances.weight), _p(net.embed_distances.bias),
-                                            _p(net.out.weight), _p(net.out.bias), _p(Rb), Cc, tile0))
+                                            _p(net.out.weight), _p(net.out.bias), _p(Rb), Cc, tile0, Cc, 0, None))
                     tile0 += tiles_per
         if rjobs:
             jr = nat.jobs_to_device(rjobs, self.dev)

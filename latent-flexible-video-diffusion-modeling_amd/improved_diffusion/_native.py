@@ -71,7 +71,17 @@ class UnpackJob(C.Structure):
 
 class RpeJob(C.Structure):
     _fields_ = [("tproj", c_fp), ("Wd", c_fp), ("bd", c_fp), ("Wout", c_fp), ("bout", c_fp), ("R", c_fp),
-                ("C", C.c_int32), ("tile0", C.c_int32)]
+                ("C", C.c_int32), ("tile0", C.c_int32), ("tproj_ld", C.c_int32), ("pad_", C.c_int32), ("act", c_fp)]
+
+
+class RpeBwdJob(C.Structure):
+    _fields_ = [("tproj", c_fp), ("Wd", c_fp), ("bd", c_fp), ("Wout_t", c_fp), ("dR", c_fp), ("dtproj", c_fp),
+                ("dWd", c_fp), ("dbd", c_fp), ("C", C.c_int32), ("tile0", C.c_int32), ("tproj_ld", C.c_int32),
+                ("dtproj_ld", C.c_int32)]
+
+
+class WgradJob(C.Structure):
+    _fields_ = [("a", ConvArgs), ("msplit", C.c_int32), ("task0", C.c_int32)]
 
 
 _SIGS = {
@@ -99,6 +109,8 @@ _SIGS = {
     "lfvdm_gn_temporal": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rowdot": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_nets": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
+    "lfvdm_rpe_nets_bwd": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
+    "lfvdm_conv_wgrad_grouped": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_attn_spatial": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_front": ([c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_front_bwd": ([c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),

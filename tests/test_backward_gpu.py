@@ -138,3 +138,43 @@ def test_distributed_data_parallel_wrap_fires_hooks_and_matches_plain_gradients(
         # wgrad partial tiles are added with float atomics: run-to-run differences of a few ulp of the largest terms
         # (biases in front of a GroupNorm have gradients that cancel to ~0: floor by the global gradient scale)
         assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-4 * float(q.grad.abs().max()) + 1e-4 * gmax), k
+
+
+def test_grouped_rpe_training_path_matches_per_network_path(monkeypatch):
+    """T*T >= 32: the RPE networks of a training step run as grouped launches (lfvdm_rpe_nets with stored activations,
+    lfvdm_rpe_nets_bwd, lfvdm_conv_wgrad_grouped).  Every parameter gradient must agree with the per-network path
+    (itself pinned to the oracle above), and with the oracle's gradients for the RPE parameters."""
+    cfg, sd, _ = load_case("micro")
+    B, T, C, H = 2, 8, cfg["in_channels"], 16
+    g = torch.Generator().manual_seed(11)
+    x, x0 = torch.randn(B, T, C, H, H, generator=g), torch.randn(B, T, C, H, H, generator=g)
+    t = torch.tensor([37.0, 512.0])
+    fi = torch.stack([torch.sort(torch.randperm(60, generator=g)[:T]).values for _ in range(B)])
+    obs = torch.zeros(B, T, 1, 1, 1); obs[:, :3] = 1
+    lat = 1 - obs; lat[:, -1] = 0
+    probe = torch.randn(B, T, cfg["out_channels"], H, H, generator=g)
+    d = dict(x=x.cuda(), x0=x0.cuda(), t=t.cuda(), fi=fi.cuda(), obs=obs.cuda(), lat=lat.cuda())
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LFVDM_RPE_GROUPED", mode)
+        model = build_native(cfg, sd).train()
+        model.native_grad_accumulation = True
+        out, _ = model(d["x"], x0=d["x0"], timesteps=d["t"], frame_indices=d["fi"], obs_mask=d["obs"], latent_mask=d["lat"])
+        (out * probe.cuda()).sum().backward()
+        grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
+        if mode == "1":
+            from improved_diffusion import _backward as bw
+            assert bw._rpe_group.state is not None, "the grouped path should have been taken"
+    gmax = max(float(v.abs().max()) for v in grads["0"].values())
+    for k in grads["0"]:
+        a, b = grads["1"][k], grads["0"][k]
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()) + 1e-4 * gmax), (k, float((a - b).abs().max()))
+    # RPE parameters against the oracle's autograd as well
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o, _ = uo.unet_forward(sdo, cfg, x, x0, t, fi, obs, lat)
+    (o * probe).sum().backward()
+    for k in grads["1"]:
+        if ".rpe_" in k:
+            ref = sdo[k].grad
+            err = float((grads["1"][k].cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-3 * gmax)
+            assert err < 2e-3, (k, err)

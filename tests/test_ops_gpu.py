@@ -213,7 +213,7 @@ def test_rpe_nets(nat, Cc, heads):
         R = torch.empty(B, T, T, Cc, device="cuda")
         keep.append((d, tproj, R))
         jobs.append(nat.RpeJob(tproj.data_ptr(), d["p.embed_distances.weight"].data_ptr(), d["p.embed_distances.bias"].data_ptr(),
-                               d["p.out.weight"].data_ptr(), d["p.out.bias"].data_ptr(), R.data_ptr(), Cc, tile0))
+                               d["p.out.weight"].data_ptr(), d["p.out.bias"].data_ptr(), R.data_ptr(), Cc, tile0, Cc, 0, None))
         tile0 += (B * T * T + 31) // 32
     jd = nat.jobs_to_device(jobs, "cuda")
     nat.rpe_nets(jd, 3, tile0, fi.cuda(), B, T)
@@ -295,7 +295,7 @@ def test_temporal_attention_block(nat, B, T, P, Cc, heads):
         Rs[r] = torch.empty(B, T, T, Cc, device="cuda")
         keep.append(tproj)
         jobs.append(nat.RpeJob(tproj.data_ptr(), d[pre + "embed_distances.weight"].data_ptr(), d[pre + "embed_distances.bias"].data_ptr(),
-                               d[pre + "out.weight"].data_ptr(), d[pre + "out.bias"].data_ptr(), Rs[r].data_ptr(), Cc, tile0))
+                               d[pre + "out.weight"].data_ptr(), d[pre + "out.bias"].data_ptr(), Rs[r].data_ptr(), Cc, tile0, Cc, 0, None))
         tile0 += (B * T * T + 31) // 32
     nat.rpe_nets(nat.jobs_to_device(jobs, "cuda"), 3, tile0, fi.cuda(), B, T)
     o = torch.empty(M, Cc, device="cuda")
