@@ -799,6 +799,8 @@ class _RpeGroup:
 
     @staticmethod
     def _key(m, views, flat, params, B, T, dev):
+        if any(n not in views for n in flat):      # tables of another model
+            return None
         return (id(m), B, T, str(dev), tuple(p.data_ptr() for p in params),
                 tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in params),
                 tuple(views[n][0].data_ptr() for n in flat))
