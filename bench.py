@@ -306,7 +306,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=10, help="timed optimizer steps of the training leg (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=30, help="timed optimizer steps of the training leg (0 = skip)")
     ap.add_argument("--pixel-steps", type=int, default=0, help="also time this many steps of the pixel-space stress config (0 = skip)")
     ap.add_argument("--long-video-windows", type=int, default=0,
                     help="also run the hierarchy-2 long-video leg with at most this many windows (97 = full; 0 = skip)")

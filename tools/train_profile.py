@@ -54,3 +54,10 @@ if g is not None:
     for _ in range(40):
         th.cuda.synchronize(); t = time.perf_counter(); _replay(g); th.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
     print("bare replays (same inputs):", " ".join(f"{t:.1f}" for t in ts), flush=True)
+if g is not None:      # does a replay block the host while the previous replay of the same graph is still running?
+    th.cuda.synchronize()
+    ts = []
+    for _ in range(6):
+        t = time.perf_counter(); _replay(g); ts.append((time.perf_counter() - t) * 1e3)
+    th.cuda.synchronize()
+    print("host time of back-to-back replay calls (no sync):", " ".join(f"{t:.2f}" for t in ts), flush=True)
