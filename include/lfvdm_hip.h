@@ -98,6 +98,23 @@ typedef struct lfvdm_conv_args {
     int32_t* splitk_cnt;
     int64_t splitk_ws_floats;
     int64_t splitk_cnt_ints;
+    /* optional fused GroupNorm(32 groups, nn.py:17-19) + FiLM (unet.py:199-203) + activation of the OUTPUT - the
+     * normalisation that sits in front of the NEXT layer - evaluated in this launch's epilogue (LFVDM_OUT_ROWS only):
+     *   gn_out[m][co] = act((out - mean) * rstd * gamma[co] + beta[co]) * (1 + film[n / gn_film_div][co]) + film[..][Cout + co])
+     * with mean / rstd over the Ho*Wo rows x Cout/32 channels of (sample n, group).  Needs Cout % 32 == 0 and a tile
+     * that holds whole samples and whole groups (Ho*Wo divides the tile's rows; lfvdm_conv_igemm_candidates only
+     * offers such tiles, and the launch returns LFVDM_E_UNSUPPORTED if none exists).  gn_skip_raw != 0: `out`
+     * itself is not written (nobody else reads the raw tensor). */
+    const float* gn_gamma;
+    const float* gn_beta;
+    const float* gn_film;   /* [N / gn_film_div][gn_film_ld] (scale | shift) or NULL */
+    float* gn_out;          /* [M][Cout]; NULL = no fused normalisation */
+    int32_t gn_film_ld;
+    int32_t gn_film_div;
+    int32_t gn_act;         /* LFVDM_ACT_* */
+    int32_t gn_skip_raw;
+    float gn_eps;
+    int32_t gn_pad_;
 } lfvdm_conv_args;
 
 int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream);

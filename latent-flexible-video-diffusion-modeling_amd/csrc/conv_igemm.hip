@@ -634,6 +634,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                 rb[i] = ld4(p.resB + (unsigned)(n * p.Cout + cc));
             }
         }
+        const bool gn = p.gn_out != nullptr;
+        const bool store_raw = !gn || p.gn_skip_raw == 0;
+        f32x4 tv[EPV];
 #pragma unroll
         for (int i = 0; i < EPV; ++i) {
             const int row = min(row0 + i * RSTEP, BM - 1);
@@ -643,10 +646,95 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                 t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
             }
             if (p.res) t += rv[i] * ra[i] + rb[i];
+            tv[i] = t;
             const int m = m0 + row;
-            if (m < M && cok && row0 + i * RSTEP < BM) st4(p.out + ((size_t)m * p.ldo + co), t);
+            if (store_raw && m < M && cok && row0 + i * RSTEP < BM) st4(p.out + ((size_t)m * p.ldo + co), t);
         }
         STAMP(3);
+        if (gn) {
+            // ---- fused GroupNorm(+FiLM)(+activation) of the output tile.  The launcher guarantees whole samples
+            // (P = Ho*Wo divides BM) and whole groups (gw = Cout/32 divides BN) per tile.  The finished values go
+            // back into group 0's LDS tile (each element is read and rewritten by its one owner thread), then one
+            // exact two-pass mean / variance per (sample, group) unit, then the affine on the registers.
+            // the per-channel / per-sample coefficients are fetched first: their latency hides behind the statistics
+            const int P = HoWo, gw = p.Cout >> 5;
+            f32x4 gam = {0.f, 0.f, 0.f, 0.f}, bet = gam, fsc[EPV], fsh[EPV];
+            if (cok) {
+                gam = ld4(p.gn_gamma + cc);
+                bet = ld4(p.gn_beta + cc);
+            }
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) {
+                fsc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                fsh[i] = fsc[i];
+                const int m = min(m0 + min(row0 + i * RSTEP, BM - 1), M - 1);
+                if (p.gn_film && cok) {
+                    const float* fl = p.gn_film + (size_t)((m / P) / p.gn_film_div) * p.gn_film_ld + cc;
+                    fsc[i] = ld4(fl);
+                    fsh[i] = ld4(fl + p.Cout);
+                }
+            }
+            __syncthreads();                 // every partial-tile read above is done before group 0's tile is rewritten
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) {
+                if (row0 + i * RSTEP < BM) {
+                    float* r = smem + (row0 + i * RSTEP) * RED_LD + c4;
+                    r[0] = tv[i].x; r[1] = tv[i].y; r[2] = tv[i].z; r[3] = tv[i].w;
+                }
+            }
+            const int SPT = BM / P, GPT = BN / gw, U = SPT * GPT;          // samples / groups / units per tile
+            float* ustat = smem + BM * RED_LD;                               // [U][2] (mean, rstd)
+            __syncthreads();
+            int tpu = CF::NTHREADS / U;                                      // threads per unit: power of two in [1, 64]
+            tpu = tpu < 1 ? 1 : tpu > 64 ? 64 : tpu;
+            tpu = 1 << (31 - __builtin_clz(tpu));
+            const int li = tid & (tpu - 1);
+            const int ne = P * gw;
+            const float inv = 1.0f / (float)ne;
+            for (int u = tid / tpu; u < U; u += CF::NTHREADS / tpu) {        // uniform trip count within a unit's lanes
+                const int sI = u / GPT, g = u - sI * GPT;
+                const float* base = smem + sI * P * RED_LD + g * gw;
+                float s1 = 0.f;
+                for (int e = li; e < ne; e += tpu) s1 += base[(e / gw) * RED_LD + (e % gw)];
+                for (int o = tpu >> 1; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+                const float mean = s1 * inv;
+                float s2 = 0.f;
+                for (int e = li; e < ne; e += tpu) {
+                    const float d = base[(e / gw) * RED_LD + (e % gw)] - mean;
+                    s2 += d * d;
+                }
+                for (int o = tpu >> 1; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+                if (li == 0) {
+                    ustat[2 * u] = mean;
+                    ustat[2 * u + 1] = 1.0f / sqrtf(s2 * inv + p.gn_eps);
+                }
+            }
+            __syncthreads();
+            if (cok) {
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) {
+                    const int row = row0 + i * RSTEP;
+                    const int m = m0 + row;
+                    if (row < BM && m < M) {
+                        const int sI = row / P;
+                        const float* us = ustat + 2 * (sI * GPT);
+                        f32x4 A, B;
+#define LFVDM_GNC(k, f)                                                                        \
+                        { const float* q = us + 2 * ((c4 + k) / gw); A.f = q[1] * gam.f; B.f = bet.f - q[0] * A.f; }
+                        LFVDM_GNC(0, x) LFVDM_GNC(1, y) LFVDM_GNC(2, z) LFVDM_GNC(3, w)
+#undef LFVDM_GNC
+                        if (p.gn_film) {
+                            const f32x4 sc = fsc[i] + (f32x4){1.f, 1.f, 1.f, 1.f};
+                            A = A * sc;
+                            B = B * sc + fsh[i];
+                        }
+                        f32x4 y = tv[i] * A + B;
+                        if (p.gn_act == LFVDM_ACT_SILU) { y.x = silu_f(y.x); y.y = silu_f(y.y); y.z = silu_f(y.z); y.w = silu_f(y.w); }
+                        st4(p.gn_out + ((size_t)m * p.Cout + co), y);
+                    }
+                }
+            }
+        }
     } else {
         // frame layout out[(n*Cout + co)*HoWo + pix]: consecutive threads take consecutive pixels
         for (int e = tid; e < BM * BN; e += CF::NTHREADS) {
@@ -820,6 +908,14 @@ bool glds_valid(const lfvdm_conv_args* a, int id, int kch, int kz, int gl) {
     const TileCfg c = kCfgs[id];
     return glds_lds_bytes(c.WM, c.WN, c.WK, c.NT, kch, gl) <= 160 * 1024;
 }
+// fused output GroupNorm: the tile must hold whole samples and whole groups, and the unit statistics must fit
+// behind the reduction tile in the first k-group's LDS (checked against the smallest stage layout: 2 unpadded stages)
+inline bool gn_tile_ok(const lfvdm_conv_args* a, int BM, int BN) {
+    const int P = a->Ho * a->Wo, gw = a->Cout / 32;
+    if (a->Cout % 32 || a->out_mode != LFVDM_OUT_ROWS || P <= 0 || BM % P || gw <= 0 || BN % gw || a->Cout % 4) return false;
+    const int U = (BM / P) * (BN / gw);
+    return BM * (BN + 1) + 2 * U <= 2 * (BM + BN) * 32;
+}
 // is (id, kch, kz) a legal configuration for these arguments?
 bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz) {
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
@@ -827,6 +923,7 @@ bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz) {
     const TileCfg c = kCfgs[id];
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
     if (a->Cout <= 32 && BN > 32) return false;
+    if (a->gn_out && !gn_tile_ok(a, BM, BN)) return false;
     const bool can64 = Cin % 64 == 0 && a->C0 % 64 == 0 && C2 % 64 == 0 && a->s2C0 % 64 == 0;
     if (kch == 64 && (!can64 || c.WM * c.WN < 4 || c.NT > 1)) return false;
     const int NK = a->ksize * a->ksize * (Cin / kch) + C2 / kch;
@@ -862,7 +959,7 @@ Pick pick_cfg(const lfvdm_conv_args* a, long M) {
     static const int forced = getenv("LFVDM_CONV_CFG") ? atoi(getenv("LFVDM_CONV_CFG")) : -1;  // tuning aid
     static const int forced_kz = getenv("LFVDM_CONV_KZ") ? atoi(getenv("LFVDM_CONV_KZ")) : -1;
     const bool can_split = false;   // the built-in model never splits K over workgroups (see cfg_valid)
-    Pick best = {0, 32, a->ksize * a->ksize * (Cin / 32) + C2 / 32, 1, 0};
+    Pick best = {-1, 32, a->ksize * a->ksize * (Cin / 32) + C2 / 32, 1, 0};
     double best_t = 1e30;
     for (int i = 0; i < kNumCfgs; ++i) {
         const TileCfg c = kCfgs[i];
@@ -870,6 +967,7 @@ Pick pick_cfg(const lfvdm_conv_args* a, long M) {
         if (i == 7) continue;   // 64x128 with two k-groups exceeds the register budget (spills): not offered
         const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
         if (a->Cout <= 32 && BN > 32) continue;
+        if (a->gn_out && !gn_tile_ok(a, BM, BN)) continue;
         for (int kch = 32; kch <= 64; kch += 32) {
             if (kch == 64 && (!can64 || c.WM * c.WN < 4 || c.NT > 1)) continue;
             const int NK = a->ksize * a->ksize * (Cin / kch) + C2 / kch;
@@ -882,6 +980,10 @@ Pick pick_cfg(const lfvdm_conv_args* a, long M) {
                 if (est < best_t) { best_t = est; best = {i, kch, NK, kz, 0}; }
             }
         }
+    }
+    if (best.id < 0) {
+        if (a->gn_out) return best;     // no tile holds whole samples and groups: the launch is refused
+        best.id = 0;                    // nothing passed the filters (tiny K with a narrow output): the 64x64 tile always works
     }
     // plain convolutions default to the LDS-DMA loop (faster on every measured shape, tools/conv_glds_compare.sh)
     static const bool no_glds = getenv("LFVDM_CONV_NO_GLDS") != nullptr;
@@ -914,6 +1016,8 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     if ((long)a->N * a->Hs * a->Ws * (a->C0 > a->C1 ? a->C0 : a->C1) >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     if (M * (long)(C2 > a->Cout ? C2 : a->Cout) >= (1L << 31) || (long)a->N * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     if ((long)a->Cout * a->ksize * a->ksize * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
+    if (a->gn_out && (!a->gn_gamma || !a->gn_beta || a->gn_film_div <= 0 || (a->gn_film && a->gn_film_ld < 2 * a->Cout)))
+        return LFVDM_E_SHAPE;
     const Pick pk = pick_cfg(a, M);
     const int kch = pk.kch, kz = pk.kz, gl = pk.gl;
     switch (pk.id) {
@@ -962,10 +1066,11 @@ extern "C" int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* n
     const long M = (long)a->N * a->Ho * a->Wo;
     const Pick pk = pick_cfg(a, M);
     const int id = pk.id, kch = pk.kch;
+    if (id < 0) return LFVDM_E_UNSUPPORTED;
     // encoded as (WM*1000 + WN*100 + WK*10 + NT, waves) so that callers can print the template instance
     *nt = kCfgs[id].WM * 1000 + kCfgs[id].WN * 100 + kCfgs[id].WK * 10 + kCfgs[id].NT;
     *nwaves = kCfgs[id].WM * kCfgs[id].WN * kCfgs[id].WK + 1000 * kch;
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_abi_version(void) { return 5; }
+extern "C" int lfvdm_abi_version(void) { return 6; }

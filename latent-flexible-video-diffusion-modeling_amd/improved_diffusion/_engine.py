@@ -30,6 +30,8 @@ def _p(t):
 
 # LFVDM_FUSED_GN=1 restores the older plan that folds GroupNorm/FiLM/SiLU into the operand load of the consuming GEMM
 FUSED_GN = os.environ.get("LFVDM_FUSED_GN", "0") == "1"
+# LFVDM_GN_EPILOGUE=0: never evaluate a GroupNorm in the epilogue of the GEMM that produces its input (A/B aid)
+GN_EPILOGUE = os.environ.get("LFVDM_GN_EPILOGUE", "1") != "0"
 
 
 class Plan:
@@ -79,6 +81,25 @@ class Plan:
         self.steps.append((fn, args))
 
     def add_conv(self, **kw):
+        self.add_conv_args(self.conv_args(**kw))
+
+    def add_conv_args(self, a):
+        self.keep.append(a)
+        self.add(nat.lib().lfvdm_conv_igemm, C.byref(a))
+
+    def conv_fused_gn(self, **kw):
+        """Add a conv whose epilogue also evaluates the NEXT GroupNorm(+FiLM)+activation into kw['gn_out'] - if a tile
+        exists that holds whole samples and groups (low-resolution levels); returns False (nothing added) otherwise."""
+        if not GN_EPILOGUE:
+            return False
+        a = self.conv_args(**kw)
+        nt, nw = C.c_int(), C.c_int()
+        if nat.lib().lfvdm_conv_igemm_config(C.byref(a), C.byref(nt), C.byref(nw)) != 0:
+            return False
+        self.add_conv_args(a)
+        return True
+
+    def conv_args(self, **kw):
         a = nat.ConvArgs()
         g = kw.get
         a.src0 = _p(kw["src0"]); a.src1 = _p(g("src1")) if g("src1") is not None else None
@@ -98,14 +119,20 @@ class Plan:
         a.resA = _p(g("resA")) if g("resA") is not None else None
         a.resB = _p(g("resB")) if g("resB") is not None else None
         a.out = _p(kw["out"]); a.ldo = kw["ldo"]; a.out_mode = g("out_mode", nat.OUT_ROWS)
+        if g("gn_out") is not None:     # fused GroupNorm(+FiLM)(+activation) of the output (lfvdm_conv_args)
+            gn, film = kw["gn"], g("gn_film")
+            a.gn_gamma, a.gn_beta, a.gn_out = _p(gn.weight), _p(gn.bias), _p(kw["gn_out"])
+            a.gn_film = _p(film) if film is not None else None
+            a.gn_film_ld = 2 * kw["Cout"] if film is not None else 0
+            a.gn_film_div = self.T if film is not None else 1
+            a.gn_act, a.gn_skip_raw, a.gn_eps = g("gn_act", nat.ACT_NONE), int(g("gn_skip_raw", 0)), gn.eps
         # shared split-K workspace (launches are stream-ordered, so one buffer serves every conv of the plan)
         if getattr(self, "splitk_ws", None) is None:
             self.splitk_ws = self.buf(2 * 1024 * 1024)                      # 8 MiB of slabs
             self.splitk_cnt = self.buf(4096, dtype=th.int32).zero_()          # tickets: zero once, self-cleaning
         a.splitk_ws, a.splitk_cnt = _p(self.splitk_ws), _p(self.splitk_cnt)
         a.splitk_ws_floats, a.splitk_cnt_ints = self.splitk_ws.numel(), self.splitk_cnt.numel()
-        self.keep.append(a)
-        self.add(nat.lib().lfvdm_conv_igemm, C.byref(a))
+        return a
 
     # ------------------------------------------------------------------ build
     def _build(self):
@@ -278,9 +305,14 @@ class Plan:
             # GroupNorm(+FiLM)+SiLU evaluated ONCE into a scratch tensor (the concat of the two sources becomes
             # real); the implicit GEMMs then stage raw operands (see lfvdm_gn_apply for why this wins on gfx950)
             act1 = self.gn_apply(a, b, C0, C1, N, P, gn1, None, nat.ACT_SILU, "act1")
-            self.add_conv(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight), bias=conv1.bias,
-                          Cout=Cout, out=h1, ldo=Cout)
-            act2 = self.gn_apply(h1, None, Cout, 0, N, P, gn2, film, nat.ACT_SILU, "act2")
+            c1 = dict(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight), bias=conv1.bias,
+                      Cout=Cout, out=h1, ldo=Cout)
+            # low-resolution levels: GroupNorm-2 + FiLM + SiLU in the epilogue of conv1 (whole samples per tile);
+            # the raw h1 is not needed by anything else and is not written
+            act2 = self.scratch("act2", N * P, Cout)
+            if not self.conv_fused_gn(gn=gn2, gn_film=film, gn_out=act2, gn_act=nat.ACT_SILU, gn_skip_raw=1, **c1):
+                self.add_conv(**c1)
+                act2 = self.gn_apply(h1, None, Cout, 0, N, P, gn2, film, nat.ACT_SILU, "act2")
             kw = dict(src0=act2, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv2.weight), bias=conv2.bias,
                       Cout=Cout, out=out, ldo=Cout)
         if isinstance(rb.skip_connection, nn.Identity):

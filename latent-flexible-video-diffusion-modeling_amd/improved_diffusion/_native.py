@@ -34,6 +34,9 @@ class ConvArgs(C.Structure):
         ("res", c_fp), ("ldr", C.c_int32), ("resA", c_fp), ("resB", c_fp),
         ("out", c_fp), ("ldo", C.c_int32), ("out_mode", C.c_int32), ("tune", C.c_int32),
         ("splitk_ws", c_fp), ("splitk_cnt", c_fp), ("splitk_ws_floats", C.c_int64), ("splitk_cnt_ints", C.c_int64),
+        ("gn_gamma", c_fp), ("gn_beta", c_fp), ("gn_film", c_fp), ("gn_out", c_fp), ("gn_film_ld", C.c_int32),
+        ("gn_film_div", C.c_int32), ("gn_act", C.c_int32), ("gn_skip_raw", C.c_int32), ("gn_eps", C.c_float),
+        ("gn_pad_", C.c_int32),
     ]
 
 
@@ -171,18 +174,9 @@ def ptr(t, dtype=torch.float32):
 
 # ------------------------------------------------------------------------------ thin wrappers
 def conv_igemm(**kw):
-    """Fill an lfvdm_conv_args from keyword tensors/ints and launch.  Required: src0, C0, N, Hs, Ws,
-    Ho, Wo, W, Cout, out, ldo.  Everything else defaults to 'absent'."""
-    a = ConvArgs()
-    a.src0 = ptr(kw["src0"]); a.src1 = ptr(kw.get("src1")); a.C0 = kw["C0"]; a.C1 = kw.get("C1", 0)
-    a.N = kw["N"]; a.Hs = kw["Hs"]; a.Ws = kw["Ws"]; a.up = kw.get("up", 0); a.stride = kw.get("stride", 1)
-    a.ksize = kw.get("ksize", 3); a.Ho = kw["Ho"]; a.Wo = kw["Wo"]
-    a.coefA = ptr(kw.get("coefA")); a.coefB = ptr(kw.get("coefB")); a.act = kw.get("act", ACT_NONE)
-    a.W = ptr(kw["W"]); a.bias = ptr(kw.get("bias")); a.Cout = kw["Cout"]
-    a.s2src0 = ptr(kw.get("s2src0")); a.s2src1 = ptr(kw.get("s2src1")); a.s2C0 = kw.get("s2C0", 0); a.s2C1 = kw.get("s2C1", 0)
-    a.W2 = ptr(kw.get("W2")); a.bias2 = ptr(kw.get("bias2"))
-    a.res = ptr(kw.get("res")); a.ldr = kw.get("ldr", kw["Cout"]); a.resA = ptr(kw.get("resA")); a.resB = ptr(kw.get("resB"))
-    a.out = ptr(kw["out"]); a.ldo = kw["ldo"]; a.out_mode = kw.get("out_mode", OUT_ROWS)
+    """Fill an lfvdm_conv_args from keyword tensors/ints (see fill_conv_args) and launch.  Required: src0, C0, N, Hs,
+    Ws, Ho, Wo, W, Cout, out.  Everything else defaults to 'absent'."""
+    a = fill_conv_args(**kw)
     ws, cnt = splitk_workspace(kw["out"].device)
     a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
     a.tune = tuned_code(a)
@@ -212,7 +206,7 @@ _tune_saved = 0
 
 def tune_key(a):
     return (a.N, a.Hs, a.Ws, a.up, a.stride, a.ksize, a.Ho, a.Wo, a.C0, a.C1, a.Cout, a.s2C0, a.s2C1, bool(a.coefA), a.act,
-            bool(a.res), bool(a.resA), a.out_mode, bool(a.splitk_ws))
+            bool(a.res), bool(a.resA), a.out_mode, bool(a.splitk_ws), (1 + bool(a.gn_film) + 2 * bool(a.gn_skip_raw)) if a.gn_out else 0)
 
 
 def tune_cache():
@@ -301,6 +295,13 @@ def fill_conv_args(**kw):
     a.W2 = ptr(g("W2")); a.bias2 = ptr(g("bias2"))
     a.res = ptr(g("res")); a.ldr = g("ldr", kw["Cout"]); a.resA = ptr(g("resA")); a.resB = ptr(g("resB"))
     a.out = ptr(kw["out"]); a.ldo = g("ldo", kw["Cout"]); a.out_mode = g("out_mode", OUT_ROWS)
+    if g("gn_out") is not None:     # fused GroupNorm(+FiLM)(+activation) of the output (see lfvdm_conv_args)
+        film = g("gn_film")
+        a.gn_gamma = ptr(kw["gn_gamma"]); a.gn_beta = ptr(kw["gn_beta"]); a.gn_out = ptr(kw["gn_out"])
+        a.gn_film = film.data_ptr() if film is not None else None
+        a.gn_film_ld = film.stride(0) if film is not None else 0
+        a.gn_film_div = g("gn_film_div", 1); a.gn_act = g("gn_act", ACT_NONE); a.gn_skip_raw = int(g("gn_skip_raw", 0))
+        a.gn_eps = g("gn_eps", 1e-5)
     return a
 
 

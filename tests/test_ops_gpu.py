@@ -699,3 +699,51 @@ def test_conv_wgrad_matches_autograd(nat, monkeypatch, N, C0, C1, Cout, H, k, st
     scale = float(w.grad.abs().max())
     assert float((got_w - w.grad).abs().max()) < 2e-5 * max(1.0, scale), float((got_w - w.grad).abs().max())
     assert float((db.cpu() - b.grad).abs().max()) < 2e-5 * max(1.0, float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,film,skip_raw,k", [(6, 64, 128, 8, True, True, 3), (8, 128, 128, 4, True, False, 3),
+                                                         (40, 128, 64, 2, False, False, 3), (4, 64, 256, 8, True, True, 3),
+                                                         (6, 64, 64, 4, False, False, 1)])
+def test_conv_fused_output_groupnorm_every_tune_code(nat, N, Cin, Cout, H, film, skip_raw, k):
+    """Conv + the NEXT layer's GroupNorm32(+FiLM)+SiLU in the conv's epilogue (lfvdm_conv_args gn_*): the second
+    normalisation of a ResBlock, unet.py:199-203.  Every offered tile holds whole samples and groups; each variant must
+    match conv2d -> group_norm -> scale/shift -> silu in fp64."""
+    import ctypes as C
+    T = 2
+    x, w, b = rnd("gnf/x", N, Cin, H, H), rnd("gnf/w", Cout, Cin, k, k, scale=0.05), rnd("gnf/b", Cout)
+    gamma, beta = 1 + 0.1 * rnd("gnf/g", Cout), 0.1 * rnd("gnf/be", Cout)
+    fm = 0.3 * rnd("gnf/film", N // T, 2 * Cout) if film else None
+    raw = F.conv2d(x.double(), w.double(), b.double(), padding=1 if k == 3 else 0)
+    ref = F.group_norm(raw, 32, gamma.double(), beta.double(), eps=1e-5)
+    if film:
+        f = fm.double().repeat_interleave(T, dim=0)
+        ref = ref * (1 + f[:, :Cout, None, None]) + f[:, Cout:, None, None]
+    ref = F.silu(ref).float()
+    out = torch.empty(N * H * H, Cout, device="cuda")
+    gn_out = torch.empty(N * H * H, Cout, device="cuda")
+    ws = torch.empty(1 << 22, device="cuda")
+    cnt = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    keep = dict(src0=cl(x), W=packed(nat, w), bias=b.cuda(), gn_gamma=gamma.cuda(), gn_beta=beta.cuda(),
+                gn_film=fm.cuda() if film else None)
+    a = nat.fill_conv_args(C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, Cout=Cout, out=out, ldo=Cout, ksize=k, gn_out=gn_out,
+                           gn_film_div=T, gn_act=nat.ACT_SILU, gn_skip_raw=skip_raw, **keep)
+    a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+    codes = (C.c_int * 256)()
+    n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
+    assert n > 0
+    for code in [0] + [codes[i] for i in range(n)]:
+        a.tune = code
+        out.fill_(float("nan")); gn_out.fill_(float("nan"))
+        nat.conv_igemm_struct(a)
+        err = float((from_cl(gn_out, N, H, H, Cout).cpu() - ref).abs().max())
+        assert err < 1e-4, f"tune code {code}: fused GroupNorm max|d| = {err:.3e}"
+        if skip_raw:
+            assert bool(torch.isnan(out).all()), "raw output must not be written with gn_skip_raw"
+        else:
+            assert float((from_cl(out, N, H, H, Cout).cpu() - raw.float()).abs().max()) < 5e-5
+    # a 16x16 map (256 rows per sample) fits no tile: the launch must be refused, not silently wrong
+    x2 = rnd("gnf/x2", 2, Cin, 16, 16)
+    o2 = torch.empty(2 * 256, Cout, device="cuda")
+    with pytest.raises(RuntimeError):
+        nat.conv_igemm(src0=cl(x2), C0=Cin, N=2, Hs=16, Ws=16, Ho=16, Wo=16, W=keep["W"], bias=keep["bias"], Cout=Cout, out=o2,
+                       ldo=Cout, ksize=k, gn_out=torch.empty_like(o2), gn_gamma=keep["gn_gamma"], gn_beta=keep["gn_beta"])
