@@ -344,16 +344,25 @@ class Plan:
         self.add(L.lfvdm_attn_temporal, _p(self.s_qkv), _p(self.R[ta.rpe_q]), _p(self.R[ta.rpe_k]), _p(self.R[ta.rpe_v]),
                  _p(self.mask), _p(self.s_o), _p(at) if at is not None else None, B, T, P, Cc, heads)
         yt = self.buf(M, Cc)
-        self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.proj_out.weight,
-                      bias=ta.proj_out.bias, Cout=Cc, res=self.s_xn, ldr=Cc, out=yt, ldo=Cc)
-        # --- spatial: GN over (C/32 x HW) per frame, folded into the qkv GEMM operand and the residual
+        proj = dict(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.proj_out.weight,
+                    bias=ta.proj_out.bias, Cout=Cc, res=self.s_xn, ldr=Cc, out=yt, ldo=Cc)
+        # --- spatial: GN over (C/32 x HW) per frame.  Low-resolution levels: evaluated in the epilogue of the temporal
+        # projection (whole frames per tile; the raw block output is read by nothing else)
+        ysn = None
+        if not FUSED_GN:
+            ysn = self.scratch("act1", M, Cc)
+            if not self.conv_fused_gn(gn=sa.norm, gn_out=ysn, gn_act=nat.ACT_NONE, gn_skip_raw=1, **proj):
+                ysn = None
+        if ysn is None:
+            self.add_conv(**proj)
         if FUSED_GN:
             self.add(L.lfvdm_gn_coef, _p(yt), None, Cc, 0, N, P, _p(sa.norm.weight), _p(sa.norm.bias), None, 1, 0, sa.norm.eps,
                      _p(self.s_cA), _p(self.s_cB))
             self.add_conv(src0=yt, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=self.s_cA, coefB=self.s_cB,
                           W=sa.qkv.weight, bias=sa.qkv.bias, Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
         else:
-            ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
+            if ysn is None:
+                ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
             self.add_conv(src0=ysn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.qkv.weight, bias=sa.qkv.bias,
                           Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
         asp = None
