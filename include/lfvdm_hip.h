@@ -11,7 +11,13 @@
  *   - all pointers are DEVICE pointers to fp32 unless the name says otherwise
  *     (`i64` = int64_t, `i32` = int32_t); nothing is allocated or freed here;
  *   - every launcher is stream-ordered on `stream` (a hipStream_t passed as void*), is
- *     re-entrant, keeps no global state and is hipGraph-capturable (no sync, no malloc);
+ *     re-entrant and hipGraph-capturable (no sync, no malloc).  The library keeps no data
+ *     state; the only host-side state is a per-(kernel instance, device) record of the
+ *     dynamic-LDS limit that has been raised with hipFuncSetAttribute (atomic fast path,
+ *     mutex-guarded slow path: safe from several host threads and several devices), and a
+ *     handful of LFVDM_CONV_* / LFVDM_WGRAD_* environment variables - A/B and tuning aids
+ *     for developers, read at most once per process (thread-safe static initialisation),
+ *     never required, and documented where they are read;
  *   - return value: 0 = launched, non-zero = LFVDM_E_* (invalid shape / unsupported config /
  *     launch error); the Python shim turns non-zero into RuntimeError;
  *   - activations are channels-last: [N][H][W][C] with N = B*T, n = b*T + t

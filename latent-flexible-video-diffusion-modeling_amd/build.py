@@ -29,7 +29,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     objs = []
     procs = []
     for s in srcs:

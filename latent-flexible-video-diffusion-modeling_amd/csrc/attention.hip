@@ -9,7 +9,7 @@
 //                        (no LDS round trip for P); softmax reductions are wave shuffles.
 //  * attn_temporal     : one wave per (batch, pixel, head); T <= 32 frames attend with the three
 //                        RPE terms and the two-clique mask (rpe.py:143-169) on the VALU.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace {
 
@@ -650,13 +650,8 @@ int launch_temporal(const float* qkv, const float* Rq, const float* Rk, const fl
     const int RST = T * FC + 4;
     const size_t lds = (size_t)(2 * T + 4 * PPW) * RST * sizeof(float);
     if (lds > 160 * 1024) return LFVDM_E_UNSUPPORTED;
-    static size_t attr_bytes = 0;   // raise the dynamic-LDS limit of this instance when a larger T needs it
-    if (lds > attr_bytes) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_kernel<TMAX, FC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return LFVDM_E_LAUNCH;
-        attr_bytes = lds;
-    }
+    static DynLdsLimit limit;       // raised (per device) when a larger T needs it
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&attn_temporal_kernel<TMAX, FC>), lds)) return rc;
     const dim3 grid((unsigned)((P + 4 * PPW - 1) / (4 * PPW)), (unsigned)heads, (unsigned)B);
     hipLaunchKernelGGL((attn_temporal_kernel<TMAX, FC>), grid, dim3(256), lds, s, qkv, Rq, Rk, Rv, mask, o, attn_out, T, P, C,
                        heads, PPW);
@@ -681,13 +676,8 @@ extern "C" int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int tota
     // LDS sized for the largest supported C (512): A tile 32*(C+4) + 4 wave-private W chunks
     const int maxC = 512;
     const size_t lds = (size_t)(32 * (maxC + 4) + 4 * 32 * RPE_LDR) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rpe_nets_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return LFVDM_E_LAUNCH;
-        attr = true;
-    }
+    static DynLdsLimit limit;
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&rpe_nets_kernel), lds)) return rc;
     hipLaunchKernelGGL(rpe_nets_kernel, dim3(total_tiles), dim3(256), lds, (hipStream_t)stream, jobs_dev, njobs, fi, B, T);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;

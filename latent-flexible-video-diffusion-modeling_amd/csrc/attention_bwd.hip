@@ -16,7 +16,7 @@
 // R tensors [B][T][T][C]; workspace matrices [(b*P + p)*heads + h][T][T].
 #include <hip/hip_runtime.h>
 
-#include "common.cuh"
+#include "common_hip.h"
 #include "lfvdm_hip.h"
 
 namespace {
@@ -620,19 +620,9 @@ int launch_tb(const float* qkv, const float* d_o, const float* Rq, const float* 
     const size_t lds_rows = (size_t)(2 * T + 4 * PPW) * RST * sizeof(float);
     const size_t lds_cols = (size_t)(T + 8 * PPW) * RST * sizeof(float);
     if (lds_rows > 160 * 1024 || lds_cols > 160 * 1024) return LFVDM_E_UNSUPPORTED;
-    static size_t attr_rows = 0, attr_cols = 0;
-    if (lds_rows > attr_rows) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_bwd_rows_kernel<TMAX, FC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows) != hipSuccess)
-            return LFVDM_E_LAUNCH;
-        attr_rows = lds_rows;
-    }
-    if (lds_cols > attr_cols) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_temporal_bwd_cols_kernel<TMAX, FC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols) != hipSuccess)
-            return LFVDM_E_LAUNCH;
-        attr_cols = lds_cols;
-    }
+    static DynLdsLimit limit_rows, limit_cols;
+    if (int rc = limit_rows.ensure(reinterpret_cast<const void*>(&attn_temporal_bwd_rows_kernel<TMAX, FC>), lds_rows)) return rc;
+    if (int rc = limit_cols.ensure(reinterpret_cast<const void*>(&attn_temporal_bwd_cols_kernel<TMAX, FC>), lds_cols)) return rc;
     const dim3 grid((unsigned)((P + 4 * PPW - 1) / (4 * PPW)), (unsigned)heads, (unsigned)B);
     hipLaunchKernelGGL((attn_temporal_bwd_rows_kernel<TMAX, FC>), grid, dim3(256), lds_rows, s, qkv, d_o, Rq, Rk, Rv, mask, dqkv,
                        Pg, dSg, T, P, C, heads, PPW);
@@ -703,13 +693,8 @@ extern "C" int lfvdm_rpe_nets_bwd(const lfvdm_rpe_bwd_job* jobs_dev, int njobs, 
     if (!jobs_dev || !fi || njobs <= 0 || total_tiles <= 0 || B <= 0 || T <= 0 || T * T < 32) return LFVDM_E_SHAPE;
     const int maxC = 512;    // LDS sized for the largest supported C: dR tile 32*(C+4) + 4 wave-private W chunks
     const size_t lds = (size_t)(32 * (maxC + 4) + 4 * 32 * RPB_LDR) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rpe_nets_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return LFVDM_E_LAUNCH;
-        attr = true;
-    }
+    static DynLdsLimit limit;
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&rpe_nets_bwd_kernel), lds)) return rc;
     hipLaunchKernelGGL(rpe_nets_bwd_kernel, dim3(total_tiles), dim3(256), lds, (hipStream_t)stream, jobs_dev, njobs, fi, B, T);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "lfvdm_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -12,6 +15,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     do {                                                       \
         if (hipGetLastError() != hipSuccess) return LFVDM_E_LAUNCH; \
     } while (0)
+
+// Host-side record of the dynamic-LDS limit raised for ONE kernel instance, per device (hipFuncSetAttribute acts on
+// the current device's copy of the function).  One object per launcher template instance; safe to call from several
+// host threads: the fast path is an atomic load, the slow path (first launch per device, or a larger request)
+// serialises on a mutex so that the recorded limit and the attribute cannot disagree.
+#define LFVDM_MAX_DEVICES 16
+struct DynLdsLimit {
+    std::atomic<uint32_t> bytes[LFVDM_MAX_DEVICES];
+    std::mutex mu;
+    DynLdsLimit() {
+        for (auto& b : bytes) b.store(0, std::memory_order_relaxed);
+    }
+    int ensure(const void* fn, size_t need) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LFVDM_MAX_DEVICES) return LFVDM_E_LAUNCH;
+        if (need <= bytes[dev].load(std::memory_order_acquire)) return LFVDM_OK;
+        std::lock_guard<std::mutex> lock(mu);
+        if (need <= bytes[dev].load(std::memory_order_acquire)) return LFVDM_OK;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return LFVDM_E_LAUNCH;
+        bytes[dev].store((uint32_t)need, std::memory_order_release);
+        return LFVDM_OK;
+    }
+};
 
 __device__ __forceinline__ float silu_f(float v) {
     // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each <= 1 ulp)

@@ -17,7 +17,7 @@
 // D: lane l holds column j=l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r=0..15.
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common_hip.h"
 
 #ifdef LFVDM_STAMP
 // diagnostic build only: shader-clock stamps of workgroup 0 / thread 0 (never compiled into the product)
@@ -267,8 +267,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     STAMP(0);
     float* gbase = smem + wk * CF::GROUP_LDS;
 
-    // K is first split over gridDim.z workgroups (small-M layers: more workgroups than output tiles; the
-    // partial tiles are combined with float atomics into the zero-initialised output), then over the
+    // K is first split over KZ workgroups (small-M layers: more workgroups than output tiles; each writes its
+    // partial tile to a slab of the split-K workspace and the last arriver of a tile - ticket with agent-scope
+    // release/acquire - sums the slabs in a fixed order: deterministic, no float atomics), then over the
     // k-groups of the workgroup.  Every group runs `iters` iterations (same barrier count); a group that
     // owns fewer chunks replays its last chunk with everything masked to zero.
     const int zbeg = (int)(((long)NK * kz) / KZ), zend = (int)(((long)NK * (kz + 1)) / KZ);
@@ -786,13 +787,10 @@ template <int WM, int WN, int WK, int NT, int KCH, int PRO, bool SIMPLE, int GL 
 int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
     using CF = Cfg<WM, WN, WK, NT, KCH, GL>;
     if (CF::LDS_BYTES > 160 * 1024) return LFVDM_E_UNSUPPORTED;
-    static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE, GL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::LDS_BYTES) != hipSuccess)
-            return LFVDM_E_LAUNCH;
-        attr_set = true;
-    }
+    static DynLdsLimit limit;
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE, GL>),
+                              CF::LDS_BYTES))
+        return rc;
     const long MT = (M + CF::BM - 1) / CF::BM, NT2 = (a->Cout + CF::BN - 1) / CF::BN;
     if (kz == kHybridKz) {   // tail split (see the kernel): flat grid
         const HybridPlan h = hybrid_plan(MT * NT2);

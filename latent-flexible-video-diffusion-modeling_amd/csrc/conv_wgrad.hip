@@ -14,7 +14,7 @@
 // (j=k, h) reads a[m = 8g+4h+e][k] as conflict-free column reads of the row-major LDS tiles.
 #include <cstdlib>
 
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace {
 
@@ -549,13 +549,8 @@ static int launch_wgrad_dma(const lfvdm_conv_args* a, hipStream_t s, int nchunks
     if (msplit > nchunks / 2) msplit = nchunks / 2;
     if (msplit < 1) msplit = 1;
     constexpr size_t lds = (size_t)(NS * (32 * COT * 32 + 32 * KT * 32) + 8 * COT * 32) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT, KT, NS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return LFVDM_E_LAUNCH;
-        attr_set = true;
-    }
+    static DynLdsLimit limit;
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT, KT, NS>), lds)) return rc;
     hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT, KT, NS>), dim3((unsigned)(tiles * msplit)), dim3(256), lds, s, *a, (int)msplit);
     return LFVDM_OK;
 }

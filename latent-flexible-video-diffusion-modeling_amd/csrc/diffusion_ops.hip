@@ -1,6 +1,6 @@
 // Elementwise Gaussian-diffusion step math (gaussian_diffusion.py:200-218, 290-346, 369-401,
 // 787-788).  HBM-bound streaming kernels: float4 accesses, one table gather per batch row.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace {
 

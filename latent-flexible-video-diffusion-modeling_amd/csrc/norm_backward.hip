@@ -8,7 +8,7 @@
 //   S1[n,g] = sum_{c in g} g'_c s1[n,c],   S2[n,g] = sum_{c in g} g'_c s2[n,c]
 //   dx      = rstd * (g'_c dz - (S1 + xhat*S2) / (cg*P))
 // and the parameter / FiLM gradients are tiny contractions of s1, s2 done by the caller.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace {
 

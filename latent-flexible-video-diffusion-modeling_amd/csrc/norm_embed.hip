@@ -1,6 +1,6 @@
 // GroupNorm statistics, the fused input compositing + first conv, and the small-M grouped
 // linear ("row-dot") used for every embedding projection.  All HBM/L2-bound; wave = 64.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace {
 

@@ -2,7 +2,7 @@
 // Replaces per-tensor `opt.step()` (torch AdamW), `update_ema` (nn.py:55-65: 2 launches per tensor and
 // rate) and `_log_grad_norm` (train_util.py:353-357: one `.item()` host sync per parameter tensor) of the
 // reference's optimize_normal (train_util.py:346-351) with a single launch and no host synchronisation.
-#include "common.cuh"
+#include "common_hip.h"
 
 namespace {
 

@@ -79,12 +79,35 @@ class _WeightPacks:
             self.refresh_all()
         return e[1]
 
+    def _live(self, key, e):
+        """The entry's parameter is alive and its storage is still where (and what) the packed copy was made from."""
+        base = e[0]()
+        if base is None:
+            return False
+        ptr_, shape, _ = key
+        n = 1
+        for d in shape:
+            n *= d
+        lo = base.data_ptr()
+        return lo <= ptr_ and ptr_ + 4 * n <= lo + 4 * base.numel()
+
+    def refresh_if_stale(self):
+        """Re-pack (one grouped launch) if any parameter changed since the packed copies were made.  Callers that
+        replay captured launches - which run no Python and therefore never reach ``get`` - call this eagerly before
+        each replay (TrainLoop._graphed_micro_step)."""
+        if any(e[0]() is not None and e[2] != self._stamp(e[0]()) for e in self.ent.values()):
+            self.refresh_all()
+
     def refresh_all(self):
-        dead = [k for k, e in self.ent.items() if e[0]() is None]
+        # entries of freed parameters, and of live parameters whose storage moved (ParamArena re-points p.data; .to()):
+        # their recorded source pointer may be freed memory
+        dead = [k for k, e in self.ent.items() if not self._live(k, e)]
         for k in dead:
             del self.ent[k]
         if dead:
             self.table = None
+        if not self.ent:
+            return
         if self.table is None:
             if th.cuda.is_current_stream_capturing():      # cannot upload a job table now: pack one by one
                 for key, e in self.ent.items():

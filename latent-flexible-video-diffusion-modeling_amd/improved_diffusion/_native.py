@@ -198,8 +198,11 @@ def splitk_workspace(device):
 
 # ------------------------------------------------------------------------------------------- launch tuning
 # Launch shape -> tile/K-chunk/split-K code (lfvdm_conv_args.tune), measured on the device the first time a
-# shape is launched outside of stream capture and optionally persisted in the JSON file named by
-# LFVDM_TUNE_CACHE (entries are only valid for the library ABI version they were measured with).
+# shape is launched outside of stream capture.  LFVDM_TUNE_CACHE names a JSON table that is loaded READ-ONLY
+# (entries are only valid for the library ABI version they were measured with; the committed
+# profiles/tune_cache_mi355x.json is used this way by bench.py and the profiling tools, so ordinary runs never modify a
+# tracked file).  Newly measured entries are written at exit only if LFVDM_TUNE_CACHE_OUT names a file (may equal
+# LFVDM_TUNE_CACHE to refresh it in place - tools/refresh_profiles.sh does), and only by rank 0 of a multi-process job.
 _tune = None
 _tune_saved = 0
 
@@ -213,15 +216,15 @@ def tune_cache():
     global _tune, _tune_saved
     if _tune is None:
         _tune = {}
-        path = os.environ.get("LFVDM_TUNE_CACHE", "")
-        if path and os.path.exists(path):
-            try:
-                with open(path) as f:
-                    blob = json.load(f)
-                if blob.get("abi") == int(lib().lfvdm_abi_version()):
-                    _tune.update({tuple(json.loads(k)): int(v) for k, v in blob["entries"].items()})
-            except (OSError, ValueError, KeyError):
-                pass
+        for path in (os.environ.get("LFVDM_TUNE_CACHE", ""), os.environ.get("LFVDM_TUNE_CACHE_OUT", "")):
+            if path and os.path.exists(path):
+                try:
+                    with open(path) as f:
+                        blob = json.load(f)
+                    if blob.get("abi") == int(lib().lfvdm_abi_version()):
+                        _tune.update({tuple(json.loads(k)): int(v) for k, v in blob["entries"].items()})
+                except (OSError, ValueError, KeyError):
+                    pass
         _tune_saved = len(_tune)
         atexit.register(tune_cache_save)
     return _tune
@@ -229,8 +232,8 @@ def tune_cache():
 
 def tune_cache_save():
     global _tune_saved
-    path = os.environ.get("LFVDM_TUNE_CACHE", "")
-    if not path or _tune is None or len(_tune) == _tune_saved:
+    path = os.environ.get("LFVDM_TUNE_CACHE_OUT", "")
+    if not path or _tune is None or len(_tune) == _tune_saved or os.environ.get("RANK", "0") != "0":
         return
     try:
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)

@@ -1,95 +1,87 @@
-"""Timestep samplers (reference resample.py).  ``UniformSampler`` is the hot-path default; the
-loss-aware sampler is kept (with the NumPy>=1.24 ``np.int`` bug of reference :132 fixed)."""
-from abc import ABC, abstractmethod
+"""Timestep samplers behind ``create_named_schedule_sampler`` (reference resample.py).
 
+``uniform`` is what the training CLI uses by default and what the hot path is measured with.  ``loss-second-moment``
+(importance sampling by the RMS of recent losses per timestep) is kept for API completeness; it is written on
+vectorised NumPy ring buffers and one ``all_gather_object`` per update rather than the reference's padded tensor
+gathers and per-element Python loops.
+"""
 import numpy as np
 import torch as th
 import torch.distributed as dist
 
 
 def create_named_schedule_sampler(name, diffusion):
-    if name == "uniform":
-        return UniformSampler(diffusion)
-    if name == "loss-second-moment":
-        return LossSecondMomentResampler(diffusion)
-    raise NotImplementedError(f"unknown schedule sampler: {name}")
+    makers = {"uniform": UniformSampler, "loss-second-moment": LossSecondMomentResampler}
+    if name not in makers:
+        raise NotImplementedError(f"unknown schedule sampler: {name}")
+    return makers[name](diffusion)
 
 
-class ScheduleSampler(ABC):
-    """Importance sampler over diffusion timesteps (reference :23-58)."""
+class ScheduleSampler:
+    """Draws timesteps t ~ p and returns the importance weights 1 / (T p_t) that keep the loss unbiased."""
 
-    @abstractmethod
     def weights(self):
-        """Positive (unnormalised) weight per timestep, as a numpy array."""
+        raise NotImplementedError
 
     def sample(self, batch_size, device):
-        w = self.weights()
-        p = w / np.sum(w)
-        idx = np.random.choice(len(p), size=(batch_size,), p=p)
-        indices = th.from_numpy(idx).long().to(device)
-        weights = th.from_numpy(1 / (len(p) * p[idx])).float().to(device)
-        return indices, weights
+        w = np.asarray(self.weights(), dtype=np.float64)
+        p = w / w.sum()
+        t = np.random.choice(p.size, size=(batch_size,), p=p)
+        scale = 1.0 / (p.size * p[t])
+        return th.from_numpy(t).long().to(device), th.from_numpy(scale).float().to(device)
 
 
 class UniformSampler(ScheduleSampler):
     def __init__(self, diffusion):
         self.diffusion = diffusion
-        self._weights = np.ones([diffusion.num_timesteps])
+        self._weights = np.ones(diffusion.num_timesteps)
 
     def weights(self):
         return self._weights
 
 
 class LossAwareSampler(ScheduleSampler):
-    def update_with_local_losses(self, local_ts, local_losses):
-        """All-gather (ts, loss) pairs so every rank keeps the same history (reference :71-105)."""
-        world = dist.get_world_size()
-        sizes = [th.tensor([0], dtype=th.int32, device=local_ts.device) for _ in range(world)]
-        dist.all_gather(sizes, th.tensor([len(local_ts)], dtype=th.int32, device=local_ts.device))
-        sizes = [int(x.item()) for x in sizes]
-        mx = max(sizes)
-        ts_b = [th.zeros(mx).to(local_ts) for _ in sizes]
-        ls_b = [th.zeros(mx).to(local_losses) for _ in sizes]
-        pad_t = th.zeros(mx).to(local_ts)
-        pad_t[:len(local_ts)] = local_ts
-        pad_l = th.zeros(mx).to(local_losses)
-        pad_l[:len(local_losses)] = local_losses
-        dist.all_gather(ts_b, pad_t)
-        dist.all_gather(ls_b, pad_l)
-        ts = [int(x.item()) for y, n in zip(ts_b, sizes) for x in y[:n]]
-        ls = [float(x.item()) for y, n in zip(ls_b, sizes) for x in y[:n]]
-        self.update_with_all_losses(ts, ls)
+    """Samplers that learn from the training losses.  Every rank must end up with the same history, so the local
+    (t, loss) pairs are exchanged before the update."""
 
-    @abstractmethod
+    def update_with_local_losses(self, local_ts, local_losses):
+        pairs = (local_ts.detach().cpu().numpy().astype(np.int64), local_losses.detach().cpu().numpy().astype(np.float64))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            everyone = [None] * dist.get_world_size()
+            dist.all_gather_object(everyone, pairs)
+        else:
+            everyone = [pairs]
+        self.update_with_all_losses(np.concatenate([t for t, _ in everyone]), np.concatenate([l for _, l in everyone]))
+
     def update_with_all_losses(self, ts, losses):
-        ...
+        raise NotImplementedError
 
 
 class LossSecondMomentResampler(LossAwareSampler):
+    """p_t ∝ sqrt(mean of the last ``history_per_term`` squared losses at t), mixed with ``uniform_prob`` of uniform;
+    uniform until every timestep has a full history."""
+
     def __init__(self, diffusion, history_per_term=10, uniform_prob=0.001):
         self.diffusion = diffusion
         self.history_per_term = history_per_term
         self.uniform_prob = uniform_prob
-        self._loss_history = np.zeros([diffusion.num_timesteps, history_per_term], dtype=np.float64)
-        self._loss_counts = np.zeros([diffusion.num_timesteps], dtype=np.int64)
-
-    def weights(self):
-        if not self._warmed_up():
-            return np.ones([self.diffusion.num_timesteps], dtype=np.float64)
-        w = np.sqrt(np.mean(self._loss_history ** 2, axis=-1))
-        w /= np.sum(w)
-        w *= 1 - self.uniform_prob
-        w += self.uniform_prob / len(w)
-        return w
-
-    def update_with_all_losses(self, ts, losses):
-        for t, loss in zip(ts, losses):
-            if self._loss_counts[t] == self.history_per_term:
-                self._loss_history[t, :-1] = self._loss_history[t, 1:]
-                self._loss_history[t, -1] = loss
-            else:
-                self._loss_history[t, self._loss_counts[t]] = loss
-                self._loss_counts[t] += 1
+        n = diffusion.num_timesteps
+        self._ring = np.zeros((n, history_per_term))     # oldest entry of row t sits at column _head[t] once full
+        self._head = np.zeros(n, dtype=np.int64)
+        self._filled = np.zeros(n, dtype=np.int64)
 
     def _warmed_up(self):
-        return (self._loss_counts == self.history_per_term).all()
+        return bool((self._filled == self.history_per_term).all())
+
+    def weights(self):
+        n = self.diffusion.num_timesteps
+        if not self._warmed_up():
+            return np.ones(n)
+        rms = np.sqrt((self._ring ** 2).mean(axis=1))
+        return rms / rms.sum() * (1.0 - self.uniform_prob) + self.uniform_prob / n
+
+    def update_with_all_losses(self, ts, losses):
+        for t, loss in zip(np.asarray(ts).tolist(), np.asarray(losses).tolist()):   # order matters when a t repeats
+            self._ring[t, self._head[t]] = loss
+            self._head[t] = (self._head[t] + 1) % self.history_per_term
+            self._filled[t] = min(self._filled[t] + 1, self.history_per_term)

@@ -290,6 +290,11 @@ class TrainLoop:
         st["seen"] += 1
         if st["seen"] <= 2 or os.environ.get("LFVDM_TRAIN_GRAPH", "1") == "0":
             return self._micro_step(*inputs)          # eager warm-up (also sets kernel attributes)
+        # A replay runs no Python, so the version-gated re-pack of the conv weights inside the autograd blocks never
+        # fires there: bring the packed copies up to date eagerly, before the capture (which then records no pack
+        # launch, whatever micro-batch of the optimizer step it happens to land on) and before every replay.
+        from ._backward import _packs
+        _packs.refresh_if_stale()
         if "graph" not in st:
             st["static_in"] = [x.clone() for x in inputs]
             th.cuda.synchronize()

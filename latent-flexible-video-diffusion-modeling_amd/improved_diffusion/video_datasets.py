@@ -10,7 +10,9 @@ pre-encoded latents), {})``.  Differences from the reference, none visible to th
 """
 import os
 import shutil
+from dataclasses import dataclass
 from pathlib import Path
+from typing import Callable
 
 import numpy as np
 import torch as th
@@ -62,193 +64,141 @@ def _shard():
     return 0, 1
 
 
-def _data_root():
-    root = os.environ.get("DATA_ROOT", "")
-    return Path(root) if root else Path(".")
+# ------------------------------------------------------------------------------------------------ storage formats
+def _frames_uint8_to_signed_unit(frames):
+    """(T, H, W, C) uint8 frames (tensor or array) -> (T, C, H, W) float32 in [-1, 1]."""
+    v = frames if isinstance(frames, th.Tensor) else th.from_numpy(np.ascontiguousarray(frames))
+    return v.permute(0, 3, 1, 2).to(th.float32).div_(255.0).mul_(2.0).sub_(1.0)
 
 
-def _make_dataset(dataset_name, T, train, shard, num_shards, root):
+def _numbered_npy(folder, split):
+    """<folder>/<split>/<idx>.npy, idx = 0 .. n-1 (MineRL, GQN mazes)."""
+    n = sum(1 for f in (folder / split).iterdir())
+    return [f"{split}/{i}.npy" for i in range(n)]
+
+
+def _csv_listed(prefix=""):
+    """<folder>/video_<split>.csv names one .pt file per line (CARLA); ``prefix`` selects the pre-encoded copies."""
+    def lister(folder, split):
+        with open(folder / f"video_{split}.csv") as f:
+            return [prefix + line.strip().rsplit("/", 1)[-1] for line in f if ".pt" in line]
+    return lister
+
+
+@dataclass(frozen=True)
+class _Format:
+    """How one dataset family is stored: where, which files make a split, how a file becomes a (T, C, H, W) video."""
+    folder: str
+    files: Callable            # (local folder, "train" | "test") -> file names relative to the folder
+    read: Callable             # path -> raw video
+    to_video: Callable         # raw -> float (T, C, H, W) in [-1, 1] (or latents)
+    shardable: bool = True
+    index_file: str = ""       # a file the lister reads (fetched into the local copy first)
+
+
+_FORMATS = {
+    "minerl": _Format(video_data_paths_dict["minerl"], _numbered_npy, np.load, _frames_uint8_to_signed_unit, shardable=False),
+    "mazes_cwvae": _Format(video_data_paths_dict["mazes_cwvae"], _numbered_npy, np.load, _frames_uint8_to_signed_unit,
+                           shardable=False),
+    "carla_no_traffic": _Format(video_data_paths_dict["carla_no_traffic"], _csv_listed(), th.load, _frames_uint8_to_signed_unit,
+                                index_file="video_{split}.csv"),
+    "carla_no_traffic_2x": _Format(
+        video_data_paths_dict["carla_no_traffic_2x"], _csv_listed(), th.load,
+        lambda raw: th.nn.functional.interpolate(_frames_uint8_to_signed_unit(raw), scale_factor=2),   # nearest 2x
+        index_file="video_{split}.csv"),
+    "carla_no_traffic_2x_encoded": _Format(video_data_paths_dict["carla_no_traffic_2x_encoded"], _csv_listed("encoded_"), th.load,
+                                           lambda latents: latents, index_file="video_{split}.csv"),
+}
+
+
+class VideoFiles(Dataset):
+    """One video per file.  The working copy of the dataset lives under ``$DATA_ROOT`` (node-local scratch) when that
+    is set: a file that is not there yet is copied, under a lock, from the same relative path below the current
+    directory the first time it is needed.  Without DATA_ROOT the files are read in place.
+
+    Items are ``(video[T frames], {})``: a random window of T frames while training, the first T frames after
+    ``set_test()``."""
+
+    def __init__(self, fmt, split, T, shard=0, num_shards=1):
+        if not fmt.shardable and (shard, num_shards) != (0, 1):
+            raise AssertionError("Distributed training is not supported by this dataset yet.")
+        self.fmt, self.split, self.T = fmt, split, T
+        scratch = os.environ.get("DATA_ROOT", "")
+        self.origin = Path(fmt.folder)
+        self.local = Path(scratch) / fmt.folder if scratch else self.origin
+        if fmt.index_file:
+            self._fetch(fmt.index_file.format(split=split))
+        listing_root = self.local if fmt.index_file else self.origin
+        self.fnames = fmt.files(listing_root, split)[shard::num_shards]
+        self.is_test = False
+        print(f"{fmt.folder} [{split}]: {len(self.fnames)} videos in shard {shard}/{num_shards}")
+
+    def _fetch(self, rel):
+        dst = self.local / rel
+        if not dst.exists():
+            dst.parent.mkdir(parents=True, exist_ok=True)
+            with Protect(dst):
+                if not dst.exists():
+                    shutil.copyfile(self.origin / rel, dst)
+        return dst
+
+    def set_test(self):
+        self.is_test = True
+
+    def __len__(self):
+        return len(self.fnames)
+
+    def __getitem__(self, idx):
+        path = self._fetch(self.fnames[idx])
+        try:
+            video = self.fmt.to_video(self.fmt.read(path))
+        except Exception:
+            print(f"could not load {path}")
+            raise
+        return self._window(video), {}
+
+    def _window(self, video):
+        if self.T is None:
+            return video
+        n = len(video)
+        if n < self.T:
+            raise AssertionError(f"video has {n} frames, {self.T} requested")
+        first = 0 if (self.is_test or n == self.T) else int(np.random.randint(n - self.T + 1))
+        return video[first:first + self.T]
+
+
+def _open(dataset_name, T, split, shard, num_shards):
+    T = default_T_dict[dataset_name] if T is None else T
     if dataset_name.startswith("synthetic"):
-        return SyntheticVideoDataset(dataset_name, T=T, seed=1234 + shard + (0 if train else 10_000))
-    path = root / video_data_paths_dict[dataset_name] if root is not None else Path(video_data_paths_dict[dataset_name])
-    split = "train" if train else "test"
-    if dataset_name == "minerl":
-        return MineRLDataset(os.path.join(path, split), shard=shard, num_shards=num_shards, T=T)
-    if dataset_name == "mazes_cwvae":
-        return GQNMazesDataset(os.path.join(path, split), shard=shard, num_shards=num_shards, T=T)
-    if dataset_name == "carla_no_traffic":
-        return CarlaDataset(train=train, path=path, shard=shard, num_shards=num_shards, T=T)
-    if dataset_name == "carla_no_traffic_2x":
-        return Carla2xDataset(train=train, path=path, shard=shard, num_shards=num_shards, T=T)
-    if dataset_name == "carla_no_traffic_2x_encoded":
-        return Carla2xDataset(train=train, path=path, shard=shard, num_shards=num_shards, T=T, encoded=True)
-    raise Exception("no dataset", dataset_name)
+        return SyntheticVideoDataset(dataset_name, T=T, seed=1234 + shard + (0 if split == "train" else 10_000))
+    if dataset_name not in _FORMATS:
+        raise Exception("no dataset", dataset_name)
+    return VideoFiles(_FORMATS[dataset_name], split, T, shard, num_shards)
 
 
 def load_data(dataset_name, batch_size, T=None, deterministic=False, num_workers=1, return_dataset=False):
-    """Infinite generator of training batches ``(video (B, T, C, H, W), {})`` for this rank's shard
-    (reference :41-69).  With ``return_dataset=True`` the generator yields the Dataset object once - use
-    ``get_train_dataset`` for a plain return value."""
-    T = default_T_dict[dataset_name] if T is None else T
-    shard, num_shards = _shard()
-    if dataset_name not in video_data_paths_dict and not dataset_name.startswith("synthetic"):
-        raise Exception("no dataset", dataset_name)
-    dataset = _make_dataset(dataset_name, T, True, shard, num_shards, None)
+    """Endless stream of training batches ``(video (B, T, C, H, W), {})`` from this rank's shard of the train split.
+    (``return_dataset=True`` makes the generator yield the Dataset once; ``get_train_dataset`` returns it directly.)"""
+    dataset = get_train_dataset(dataset_name, T)
     if return_dataset:
         yield dataset
         return
-    loader = DataLoader(dataset, batch_size=batch_size, shuffle=not deterministic, num_workers=num_workers,
-                        drop_last=True)
+    loader = DataLoader(dataset, batch_size=batch_size, shuffle=not deterministic, num_workers=num_workers, drop_last=True)
     while True:
         yield from loader
 
 
 def get_train_dataset(dataset_name, T=None):
-    T = default_T_dict[dataset_name] if T is None else T
-    shard, num_shards = _shard()
-    return _make_dataset(dataset_name, T, True, shard, num_shards, None)
+    return _open(dataset_name, T, "train", *_shard())
 
 
 def get_test_dataset(dataset_name, T=None):
-    """Unsharded test split rooted at ``$DATA_ROOT`` with deterministic (first-T) subsequences (reference :80-101)."""
+    """The whole (unsharded) test split with deterministic first-T windows."""
     if dataset_name == "mazes":
         raise Exception("Deprecated dataset.")
-    T = default_T_dict[dataset_name] if T is None else T
-    dataset = _make_dataset(dataset_name, T, False, 0, 1, _data_root())
+    dataset = _open(dataset_name, T, "test", 0, 1)
     dataset.set_test()
     return dataset
-
-
-class BaseDataset(Dataset):
-    """One file per video under ``path``.  When ``DATA_ROOT`` is set, files are copied there on first access
-    (node-local scratch) and the original location is the path relative to DATA_ROOT (reference :104-190).
-    Subclasses provide ``getitem_path``, ``loaditem`` and ``postprocess_video``."""
-
-    def __init__(self, path, T):
-        super().__init__()
-        self.T = T
-        self.path = Path(path)
-        self.is_test = False
-
-    def __len__(self):
-        return len(list(self.get_src_path(self.path).iterdir()))
-
-    def __getitem__(self, idx):
-        path = self.getitem_path(idx)
-        self.cache_file(path)
-        try:
-            video = self.loaditem(path)
-        except Exception:
-            print(f"Failed on loading {path}")
-            raise
-        return self.get_video_subsequence(self.postprocess_video(video), self.T), {}
-
-    def getitem_path(self, idx):
-        raise NotImplementedError
-
-    def loaditem(self, path):
-        raise NotImplementedError
-
-    def postprocess_video(self, video):
-        raise NotImplementedError
-
-    def cache_file(self, path):
-        if not path.exists():
-            path.parent.mkdir(parents=True, exist_ok=True)
-            with Protect(path):
-                shutil.copyfile(str(self.get_src_path(path)), str(path))
-
-    @staticmethod
-    def get_src_path(path):
-        root = os.environ.get("DATA_ROOT", "")
-        if not root:
-            return path
-        root = Path(root)
-        assert root in path.parents, f"Expected dataset item path ({path}) to be located under the data root ({root})."
-        return Path(*path.parts[len(root.parts):])
-
-    def set_test(self):
-        self.is_test = True
-        print("setting test mode")
-
-    def get_video_subsequence(self, video, T):
-        if T is None:
-            return video
-        if T < len(video):
-            start = 0 if self.is_test else np.random.randint(len(video) - T + 1)
-            video = video[start:start + T]
-        assert len(video) == T
-        return video
-
-
-def _uint8_frames_to_unit_range(video):
-    """(T, H, W, C) uint8 array -> (T, C, H, W) float in [-1, 1]."""
-    v = th.as_tensor(np.asarray(video))
-    return v.permute(0, 3, 1, 2).float() / 255 * 2 - 1
-
-
-class CarlaDataset(BaseDataset):
-    """``video_{train,test}.csv`` lists the ``.pt`` files (uint8 T,H,W,C); sharded by rank (reference :193-212)."""
-
-    def __init__(self, train, path, shard, num_shards, T):
-        super().__init__(path=path, T=T)
-        self.split_path = self.path / f"video_{'train' if train else 'test'}.csv"
-        self.cache_file(self.split_path)
-        with open(self.split_path) as f:
-            names = [line.rstrip("\n").split("/")[-1] for line in f if ".pt" in line]
-        self.fnames = names[shard::num_shards]
-        print(f"Loading {len(self.fnames)} files (Carla dataset).")
-
-    def loaditem(self, path):
-        return th.load(path)
-
-    def getitem_path(self, idx):
-        return self.path / self.fnames[idx]
-
-    def postprocess_video(self, video):
-        return -1 + 2 * (video.permute(0, 3, 1, 2).float() / 255)
-
-    def __len__(self):
-        return len(self.fnames)
-
-
-class Carla2xDataset(CarlaDataset):
-    """CARLA upsampled 2x (nearest), or its pre-encoded latents (``encoded_<name>.pt``) (reference :215-228)."""
-
-    def __init__(self, train, path, shard, num_shards, T, encoded=False):
-        super().__init__(train, path, shard, num_shards, T)
-        self.encoded = encoded
-        if encoded:
-            self.fnames = ["encoded_" + n for n in self.fnames]
-        print(f"Loading {len(self.fnames)} files (Carla dataset).")
-
-    def postprocess_video(self, video):
-        if self.encoded:
-            return video
-        return th.nn.functional.interpolate(super().postprocess_video(video), scale_factor=2)
-
-
-class _NpyVideoDataset(BaseDataset):
-    def __init__(self, path, shard, num_shards, T):
-        assert shard == 0 and num_shards == 1, "Distributed training is not supported by this dataset yet."
-        super().__init__(path=path, T=T)
-
-    def getitem_path(self, idx):
-        return self.path / f"{idx}.npy"
-
-    def loaditem(self, path):
-        return np.load(path)
-
-    def postprocess_video(self, video):
-        return _uint8_frames_to_unit_range(video)
-
-
-class GQNMazesDataset(_NpyVideoDataset):
-    """``<idx>.npy`` uint8 (T, H, W, C) maze videos (reference :231-247)."""
-
-
-class MineRLDataset(_NpyVideoDataset):
-    """``<idx>.npy`` uint8 (T, H, W, C) MineRL videos (reference :250-264)."""
 
 
 class SyntheticVideoDataset(Dataset):

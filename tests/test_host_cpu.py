@@ -170,6 +170,32 @@ def test_samplers_logger_rng_helpers():
     with rng_util.RNG(3):
         b = torch.rand(2)
     assert torch.equal(a, b)
+    # a private stream continues where it stopped and never disturbs the caller's generators
+    torch.manual_seed(5); np.random.seed(5)
+    want_outer = (torch.rand(3), np.random.rand(3))
+    torch.manual_seed(5); np.random.seed(5)
+    priv = rng_util.RNG(9)
+    with priv:
+        p1 = (torch.rand(2), np.random.rand(2))
+    with priv:
+        p2 = (torch.rand(2), np.random.rand(2))
+    got_outer = (torch.rand(3), np.random.rand(3))
+    assert torch.equal(got_outer[0], want_outer[0]) and np.array_equal(got_outer[1], want_outer[1])
+    with rng_util.RNG(9):
+        q = (torch.rand(4), np.random.rand(4))
+    assert torch.equal(torch.cat([p1[0], p2[0]]), q[0]) and np.array_equal(np.concatenate([p1[1], p2[1]]), q[1])
+    @rng_util.rng_decorator(seed=4)
+    def draw():
+        return torch.rand(2)
+    assert torch.equal(draw(), draw())
+    # loss-aware sampler: uniform until every timestep has a full history, then RMS of the kept losses (+ uniform mix)
+    class D3: num_timesteps = 3
+    r3 = resample.LossSecondMomentResampler(D3(), history_per_term=2, uniform_prob=0.1)
+    r3.update_with_local_losses(torch.tensor([0, 1, 2, 0]), torch.tensor([1.0, 2.0, 2.0, 3.0]))
+    assert np.array_equal(r3.weights(), np.ones(3))
+    r3.update_with_all_losses([1, 2, 0], [2.0, 4.0, 5.0])          # t=0 now keeps (3, 5): the 1.0 fell out
+    rms = np.sqrt(np.array([(9 + 25) / 2, 4.0, (4 + 16) / 2]))
+    assert np.allclose(r3.weights(), rms / rms.sum() * 0.9 + 0.1 / 3)
     assert train_util.parse_resume_step_from_filename("x/model012345.pt") == 12345
     assert train_util.parse_resume_step_from_filename("x/ema.pt") == 0
     class Diff: num_timesteps = 100

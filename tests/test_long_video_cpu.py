@@ -185,8 +185,18 @@ def test_video_datasets_surface(tmp_path, monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     train = vd.get_train_dataset("carla_no_traffic", T=12)
     assert train.fnames == ["video_1.pt", "video_3.pt"]
-    x2 = vd.Carla2xDataset(train=True, path=root, shard=0, num_shards=1, T=12)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    x2 = vd.get_train_dataset("carla_no_traffic_2x", T=12)          # same files, nearest-2x frames
     assert x2[0][0].shape == (12, 3, 16, 16)
+    assert torch.equal(x2[1][0][:, :, ::2, ::2], vd.get_train_dataset("carla_no_traffic", T=12)[1][0])
+    # DATA_ROOT: files are copied into the scratch copy on first use and read from there afterwards
+    scratch = tmp_path / "scratch"
+    monkeypatch.setenv("DATA_ROOT", str(scratch))
+    cached = vd.get_test_dataset("carla_no_traffic", T=6)
+    assert torch.equal(cached[0][0], v) and (scratch / "datasets/carla/no-traffic/video_4.pt").exists()
+    assert (scratch / "datasets/carla/no-traffic/video_test.csv").exists()
+    monkeypatch.delenv("DATA_ROOT")
     it = vd.load_data("carla_no_traffic", batch_size=2, T=5, num_workers=0)
     b, _ = next(it)
     assert b.shape == (2, 5, 3, 8, 8) and float(b.abs().max()) <= 1.0

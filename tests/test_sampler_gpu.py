@@ -82,7 +82,10 @@ def test_graph_sampler_matches_eager_step():
             ref = diff.p_sample(model, before, ti, clip_denoised=True, model_kwargs=mk, noise=noise)
         # (the sampler's private plan is autotuned: other tile shapes => fp32 re-association differences)
         assert torch.allclose(out["sample"], ref["sample"], atol=2e-4), float((out["sample"] - ref["sample"]).abs().max())
-        assert torch.allclose(out["pred_xstart"], ref["pred_xstart"], atol=2e-2)
+        # x0-hat = sqrt(1/acp) x - sqrt(1/acp - 1) eps: the eps difference is amplified by sqrt(1/acp - 1) at this t
+        amp = 1.0 + float(diff.sqrt_recipm1_alphas_cumprod[i])
+        assert torch.allclose(out["pred_xstart"], ref["pred_xstart"], atol=2e-4 * amp), \
+            (float((out["pred_xstart"] - ref["pred_xstart"]).abs().max()), amp)
     # full loop through the public API (250 respaced steps), twice with the same seed -> identical
     torch.manual_seed(0)
     a, attn = diff.p_sample_loop(model, shape, clip_denoised=True, model_kwargs=mk, latent_mask=d["latent_mask"],

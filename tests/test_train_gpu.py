@@ -19,14 +19,14 @@ def synthetic_data(B, T, C, H, seed=0):
         yield (torch.randn(B, T, C, H, H, generator=g).clamp(-1, 1), {})
 
 
-def make_loop(model, batch_size=2, T_video=12, max_frames=4, lr=1e-3):
+def make_loop(model, batch_size=2, T_video=12, max_frames=4, lr=1e-3, microbatch=-1):
     from improved_diffusion import script_util as su, dist_util
     from improved_diffusion.train_util import TrainLoop
     dist_util.setup_dist()
     diffusion = su.create_gaussian_diffusion(steps=1000, rescale_timesteps=True, rescale_learned_sigmas=True)
     args = argparse.Namespace(resume_id="")
     return TrainLoop(model=model, diffusion=diffusion, data=synthetic_data(batch_size, T_video, 4, 16), batch_size=batch_size,
-                     microbatch=-1, lr=lr, ema_rate="0.9", log_interval=1000, save_interval=10 ** 9, resume_checkpoint="",
+                     microbatch=microbatch, lr=lr, ema_rate="0.9", log_interval=1000, save_interval=10 ** 9, resume_checkpoint="",
                      use_fp16=False, diffusion_space_kwargs={}, fp16_scale_growth=1e-3, schedule_sampler=None,
                      weight_decay=0.01, lr_anneal_steps=0, sample_interval=None, pad_with_random_frames=True,
                      max_frames=max_frames, enc_dec_chunk_size=20, args=args)
@@ -126,3 +126,35 @@ def test_graphed_training_step_with_dropout():
     assert loop._graph_state.get("graph") is not None, "the micro-step should be running as a captured graph by now"
     # the keep masks come from th.rand_like under capture, i.e. torch's graph-safe Philox offsets: the same mechanism
     # that gives q_sample fresh noise on every replay
+
+
+def test_graphed_microbatches_see_updated_weights():
+    """batch_size / microbatch = 3: the capture lands on the 3rd micro-batch of optimizer step 1, where the packed
+    conv weights are current, so no re-pack is recorded in the graph.  Replays run no Python; the packed copies the
+    captured GEMMs read must nevertheless follow the fused optimizer on every later step."""
+    from improved_diffusion import _backward as bw, _native as nat
+    cfg, sd, _ = load_case("micro")
+    model = build_native(cfg, sd).train()
+    loop = make_loop(model, batch_size=3, microbatch=1, lr=5e-3)
+    torch.manual_seed(11); np.random.seed(11)
+    first = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    for _ in range(5):
+        loop.run_step()
+        loop.step += 1
+    assert loop._graph_state.get("graph") is not None, "micro-step was not captured"
+    loop.forward_backward()              # three replays on the parameters of optimizer step 5
+    torch.cuda.synchronize()
+    now = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert float((now - first).abs().max()) > 1e-2, "the optimizer must have moved the parameters"
+    checked = 0
+    for (ptr_, shape, transposed), e in bw._packs.ent.items():
+        base = e[0]()
+        if base is None or not any(base is p for p in model.parameters()):
+            continue
+        Cout, Cin, k, _ = shape
+        w4 = base.detach().view(shape)
+        want = torch.empty_like(e[1])
+        (nat.pack_conv_weight_t if transposed else nat.pack_conv_weight)(w4.contiguous(), want)
+        assert torch.equal(e[1], want), f"packed copy of a {shape} weight is stale (transposed={transposed})"
+        checked += 1
+    assert checked >= 10

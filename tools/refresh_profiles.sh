@@ -10,7 +10,8 @@ set -e -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p $OUT
-export LFVDM_TUNE_CACHE=$ROOT/profiles/tune_cache_mi355x.json
+export LFVDM_TUNE_CACHE=$ROOT/profiles/tune_cache_mi355x.json      # read-only
+export LFVDM_TUNE_CACHE_OUT=$OUT/tune_cache_mi355x.json             # committed table + anything measured in these runs
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 python3 $ROOT/bench.py --pixel-steps 10 --long-video-windows 4 > $OUT/bench_line.json 2> $OUT/bench.err
 echo "bench done"
@@ -26,5 +27,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 echo "pmc write done"
 python3 $ROOT/tools/pmc_summarize.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json
 rm -rf $OUT/bp/*trace* $OUT/tp/*trace*
-cp $LFVDM_TUNE_CACHE $OUT/tune_cache_mi355x.json
+[ -f $LFVDM_TUNE_CACHE_OUT ] || cp $LFVDM_TUNE_CACHE $LFVDM_TUNE_CACHE_OUT
 echo "refresh complete"
