@@ -524,7 +524,7 @@ class TemporalAttnFn(th.autograd.Function):
     """x -> GN_t(x) + proj(attn_rpe(qkv(GN_t(x))))   (reference rpe.py:133-174, temporal instance)."""
 
     @staticmethod
-    def forward(ctx, x, gn_w, gn_b, wqkv, bqkv, wproj, bproj, Rq, Rk, Rv, mask, B, T, P, heads, dR_slots=None):
+    def forward(ctx, x, gn_w, gn_b, wqkv, bqkv, wproj, bproj, Rq, Rk, Rv, mask, B, T, P, heads, dR_slots=None, attn_sink=None):
         C = x.shape[1]
         M = B * T * P
         xn = th.empty_like(x)
@@ -532,7 +532,10 @@ class TemporalAttnFn(th.autograd.Function):
         qkv = _new(M, 3 * C, like=x)
         nat.conv_igemm(src0=xn, C0=C, N=M, Hs=1, Ws=1, Ho=1, Wo=1, ksize=1, W=wqkv, bias=bqkv, Cout=3 * C, out=qkv, ldo=3 * C)
         o = _new(M, C, like=x)
-        nat.attn_temporal(qkv, Rq, Rk, Rv, mask, o, None, B, T, P, C, heads)
+        probs = _new(B * P, heads, T, T, like=x) if attn_sink is not None else None
+        nat.attn_temporal(qkv, Rq, Rk, Rv, mask, o, probs, B, T, P, C, heads)
+        if probs is not None:       # logged summary of the reference: |mean over heads|, detached (rpe.py:128-131)
+            attn_sink.append(probs.mean(dim=1).abs())
         y = _new(M, C, like=x)
         nat.conv_igemm(src0=o, C0=C, N=M, Hs=1, Ws=1, Ho=1, Wo=1, ksize=1, W=wproj, bias=bproj, Cout=C, res=xn, ldr=C, out=y,
                        ldo=C)
@@ -589,14 +592,14 @@ class TemporalAttnFn(th.autograd.Function):
                                                   nat.ptr(tb), B, T, P, C, 0, nat.stream()), "lfvdm_gn_temporal_bwd")
         if ctx.dR_slots is not None:
             dRq = dRk = dRv = None
-        return dx, dg, db, dwq, dbq, dwp, dbp, dRq, dRk, dRv, None, None, None, None, None, None
+        return dx, dg, db, dwq, dbq, dwp, dbp, dRq, dRk, dRv, None, None, None, None, None, None, None
 
 
 class SpatialAttnFn(th.autograd.Function):
     """x -> GN_s(x) + proj(attn(qkv(GN_s(x)))) over the H*W tokens of each frame (rpe.py:133-174, spatial)."""
 
     @staticmethod
-    def forward(ctx, x, gn_w, gn_b, wqkv, bqkv, wproj, bproj, N, P, heads):
+    def forward(ctx, x, gn_w, gn_b, wqkv, bqkv, wproj, bproj, N, P, heads, attn_sink=None):
         C = x.shape[1]
         M = N * P
         xn, cA, cB, st = _gn_apply(x, None, C, 0, N, P, gn_w, gn_b, None, 1, nat.ACT_NONE)   # also the residual
@@ -604,7 +607,10 @@ class SpatialAttnFn(th.autograd.Function):
         nat.conv_igemm(src0=xn, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=wqkv, bias=bqkv, Cout=3 * C, out=qkv, ldo=3 * C)
         o = _new(M, C, like=x)
         lse = _new(N * heads, P, like=x)
-        nat.attn_spatial(qkv, o, None, N, P, C, heads, lse=lse)
+        probs = _new(N, heads, P, P, like=x) if attn_sink is not None else None
+        nat.attn_spatial(qkv, o, probs, N, P, C, heads, lse=lse)
+        if probs is not None:
+            attn_sink.append(probs.mean(dim=1).abs())
         y = _new(M, C, like=x)
         nat.conv_igemm(src0=o, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=wproj, bias=bproj, Cout=C, res=xn, ldr=C, out=y,
                        ldo=C)
@@ -642,7 +648,7 @@ class SpatialAttnFn(th.autograd.Function):
         nat.conv_igemm(src0=dqkv, C0=3 * C, ksize=1, W=_pack_t(wqkv.view(3 * C, C, 1, 1)), Cout=C, res=dy, ldr=C, out=dxn,
                        ldo=C, **geo)
         dx, _, dg, db, _ = _gn_backward(dxn, x, None, C, 0, N, P, cA, cB, st, nat.ACT_NONE, gn_w, gn_b, None, 1, inplace=inplace)
-        return dx, dg, db, dwq, dbq, dwp, dbp, None, None, None
+        return dx, dg, db, dwq, dbq, dwp, dbp, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- embedding network
@@ -923,8 +929,7 @@ class UNetFunction:
     def run(engine, x, x0, timesteps, frame_indices, obs_mask, latent_mask, return_attn_weights):
         from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
         m = engine.model
-        if return_attn_weights:
-            raise NotImplementedError("attention maps are only produced in no-grad (sampling/logging) mode")
+        attns = {"spatial": [], "temporal": [], "mixed": []} if return_attn_weights else None
         _mode.inplace = bool(getattr(m, "native_grad_accumulation", False))
         B, T, Cx, H, W = x.shape
         N = B * T
@@ -977,9 +982,10 @@ class UNetFunction:
                         dR_slots = None
                     h = TemporalAttnFn.apply(h, ta.norm.weight, ta.norm.bias, ta.qkv.weight, ta.qkv.bias, ta.proj_out.weight,
                                              ta.proj_out.bias, R[0], R[1], R[2], mask, B, T, Hc * Wc, layer.num_heads,
-                                             dR_slots)
+                                             dR_slots, attns["temporal"] if attns is not None else None)
                     h = SpatialAttnFn.apply(h, sa.norm.weight, sa.norm.bias, sa.qkv.weight, sa.qkv.bias, sa.proj_out.weight,
-                                            sa.proj_out.bias, N, Hc * Wc, layer.num_heads)
+                                            sa.proj_out.bias, N, Hc * Wc, layer.num_heads,
+                                            attns["spatial"] if attns is not None else None)
                 elif isinstance(layer, Downsample):
                     h = ConvFn.apply(h, layer.op.weight, layer.op.bias, N, Hc, Wc, 2, False)
                     Hc, Wc = Hc // 2, Wc // 2
@@ -1000,4 +1006,4 @@ class UNetFunction:
             cur = stage(blk, cur, skip=hs.pop()[0])
         h, Hc, Wc = cur
         out = HeadFn.apply(h, m.out[0].weight, m.out[0].bias, m.out[2].weight, m.out[2].bias, N, Hc, Wc)
-        return out.view(B, T, m.out_channels, H, W), None
+        return out.view(B, T, m.out_channels, H, W), attns

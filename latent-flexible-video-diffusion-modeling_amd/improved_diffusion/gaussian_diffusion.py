@@ -196,18 +196,33 @@ class GaussianDiffusion:
                      sample, pred, mean)
         return sample, pred, mean
 
+    def _p_update_denoised(self, x, eps, t, noise, clip_denoised, denoised_fn):
+        """The same update with a user function applied to x0-hat before clipping (reference process_xstart,
+        :305-309).  ``denoised_fn`` is arbitrary Python on a tensor, so this rarely used variant is composed of
+        elementwise device ops around it instead of the fused kernel."""
+        n = x.dim()
+        pred = denoised_fn(self._predict_xstart_from_eps(x, t, eps))
+        if clip_denoised:
+            pred = pred.clamp(-1, 1)
+        mean, _, _ = self.q_posterior_mean_variance(pred, x, t)
+        if noise is None:
+            return mean, pred, mean
+        nonzero = _bshape((t != 0).to(x.dtype), n)       # no noise at t == 0 (reference :397-399)
+        sample = mean + nonzero * th.exp(0.5 * self._gather("model_log_variance", t, n)) * noise
+        return sample, pred, mean
+
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                         return_attn_weights=False):
         """Model mean/variance and x0-hat at step t (reference :244-339), epsilon + fixed sigma."""
         self._check_native_modes()
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not supported on the native path")
         model_kwargs = model_kwargs or {}
         B = x.shape[0]
         assert t.shape == (B,)
         eps, attn = model(x, self._scale_timesteps(t), return_attn_weights=return_attn_weights, **model_kwargs)
-        # noise-free update: the kernel returns the posterior mean and x0-hat in one pass
-        _, pred, mean = self._p_update(x, eps, t, None, clip_denoised, want_mean=True)
+        if denoised_fn is not None:
+            _, pred, mean = self._p_update_denoised(x, eps, t, None, clip_denoised, denoised_fn)
+        else:   # noise-free update: the kernel returns the posterior mean and x0-hat in one pass
+            _, pred, mean = self._p_update(x, eps, t, None, clip_denoised, want_mean=True)
         n = x.dim()
         return {"mean": mean, "variance": self._gather("model_variance", t, n).expand(x.shape),
                 "log_variance": self._gather("model_log_variance", t, n).expand(x.shape),
@@ -218,13 +233,14 @@ class GaussianDiffusion:
         """x_{t-1} ~ p(.|x_t) (reference :369-401).  ``noise`` (extension) injects the N(0,1) draw that
         the reference takes from ``th.randn_like`` so that trajectories can be compared across devices."""
         self._check_native_modes()
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not supported on the native path")
         model_kwargs = model_kwargs or {}
         eps, attn = model(x, self._scale_timesteps(t), return_attn_weights=return_attn_weights, **model_kwargs)
         if noise is None:
             noise = th.randn_like(x)
-        sample, pred, _ = self._p_update(x, eps, t, noise, clip_denoised)
+        if denoised_fn is not None:
+            sample, pred, _ = self._p_update_denoised(x, eps, t, noise, clip_denoised, denoised_fn)
+        else:
+            sample, pred, _ = self._p_update(x, eps, t, noise, clip_denoised)
         return {"sample": sample, "pred_xstart": pred, "attn": attn}
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
@@ -342,34 +358,90 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ encode / decode boundary
     def setup_enc_dec(self):
-        """The reference downloads the SVD VAE here when diffusion_space == 'latent' (:890-911).  The
-        native build never fetches anything at construction: the VAE is only required by
-        ``encode``/``decode`` of non-pre-encoded data, which is outside the hot path."""
-        if self.diffusion_space in (None, "pixel", "latent"):
-            self.vae = None
+        """The reference downloads the SVD VAE by name here when diffusion_space == 'latent' (:890-911).  This build
+        never touches the network: the VAE is attached explicitly (``set_vae``), or loaded from a LOCAL directory named
+        by ``LFVDM_VAE_PATH`` when diffusers is installed.  Pre-encoded latents (the reference's
+        carla_no_traffic_2x_encoded dataset) train and sample without it."""
+        self.vae = self.image_processor = None
+        self.enc_dec_dtype = th.float16
+        if self.diffusion_space in (None, "pixel"):
             return
         if self.diffusion_space == "wavelet":
             raise NotImplementedError
-        raise ValueError(f"Unknown diffusion space: {self.diffusion_space}")
+        if self.diffusion_space != "latent":
+            raise ValueError(f"Unknown diffusion space: {self.diffusion_space}")
+        import os
+        path = os.environ.get("LFVDM_VAE_PATH", "")
+        if path:
+            from diffusers import StableVideoDiffusionPipeline     # optional dependency, local files only
+            pipe = StableVideoDiffusionPipeline.from_pretrained(path, torch_dtype=self.enc_dec_dtype, variant="fp16",
+                                                                local_files_only=True)
+            self.set_vae(pipe.vae, pipe.image_processor, self.enc_dec_dtype)
+
+    def set_vae(self, vae, image_processor=None, dtype=th.float16):
+        """Attach the frame autoencoder: an object with ``encode(frames).latent_dist`` (``.mean``, ``.std``) and
+        ``decode(latents, num_frames=1).sample`` (the diffusers AutoencoderKLTemporalDecoder interface), plus an
+        optional ``image_processor.preprocess`` for the pixel side."""
+        self.vae, self.image_processor, self.enc_dec_dtype = vae, image_processor, dtype
+        if hasattr(vae, "parameters"):
+            for p in vae.parameters():
+                p.requires_grad = False
+
+    def _vae_device(self, fallback):
+        if hasattr(self.vae, "parameters"):
+            for p in self.vae.parameters():
+                return p.device
+        return fallback
 
     @th.no_grad()
     def encode(self, video, chunk_size=10):
+        """Pixels (B, T, 3, H, W) in [-1, 1] -> latents; identity in pixel space and for pre-encoded data
+        (reference :914-932)."""
         if self.diffusion_space in (None, "pixel") or self.pre_encoded:
-            return video  # reference :915-919
-        raise NotImplementedError("VAE encoding needs the stabilityai/stable-video-diffusion-img2vid weights "
-                                  "(network fetch); pre-encode the dataset as the reference's datasets/carla does")
+            return video
+        if self.vae is None:
+            raise NotImplementedError("VAE encoding needs the stabilityai/stable-video-diffusion-img2vid weights: attach "
+                                      "them with set_vae() / LFVDM_VAE_PATH, or pre-encode the dataset as the reference's "
+                                      "datasets/carla does")
+        self.original_dtype = video.dtype
+        B, T = video.shape[:2]
+        frames = (video.flatten(0, 1) + 1) / 2                       # the image processor expects [0, 1]
+        if self.image_processor is not None:
+            frames = self.image_processor.preprocess(frames)
+        frames = frames.to(self.enc_dec_dtype).to(self._vae_device(video.device))
+        parts = []
+        for i in range(0, frames.shape[0], chunk_size):
+            q = self.vae.encode(frames[i:i + chunk_size]).latent_dist
+            parts.append(q.mean + th.randn_like(q.std) * q.std)     # one posterior sample per frame
+        return th.cat(parts).unflatten(0, (B, T)).to(video.device)
+
+    def denormalize_latents(self, video):
+        """Undo the per-channel normalisation of pre-encoded datasets: z * std + mean (reference :938-939; the
+        statistics come from the dataset's stats file, scripts/video_train.py:87-91)."""
+        st = self.pre_encoded_stats_dict
+        return video * st["std"].to(video.device, video.dtype) + st["mean"].to(video.device, video.dtype)
 
     @th.no_grad()
     def decode(self, video, chunk_size=20):
+        """Latents -> pixels (reference :934-947).  Without an attached VAE, pre-encoded latents come back
+        de-normalised (ready for the decoder) and a warning is printed once; non-pre-encoded latents raise."""
         if self.diffusion_space in (None, "pixel"):
             return video
         if self.pre_encoded:
-            video = video * self.pre_encoded_stats_dict["std"].to(video.device) + \
-                self.pre_encoded_stats_dict["mean"].to(video.device)  # reference :938-939
+            video = self.denormalize_latents(video)
         if self.vae is None:
-            raise NotImplementedError("VAE decoding needs the SVD VAE weights (network fetch); call "
-                                      "p_sample_loop(..., return_decoded=False) to get latents")
-        return video
+            if not self.pre_encoded:
+                raise NotImplementedError("VAE decoding needs the SVD VAE weights: attach them with set_vae() / "
+                                          "LFVDM_VAE_PATH, or call p_sample_loop(..., return_decoded=False)")
+            if not getattr(self, "_warned_no_vae", False):
+                self._warned_no_vae = True
+                print("decode(): no VAE attached - returning de-normalised latents (set_vae() / LFVDM_VAE_PATH for pixels)")
+            return video
+        B, T = video.shape[:2]
+        out_dtype = self.original_dtype if self.original_dtype is not None else video.dtype
+        z = video.flatten(0, 1).to(self.enc_dec_dtype).to(self._vae_device(video.device))
+        frames = th.cat([self.vae.decode(z[i:i + chunk_size], num_frames=1).sample for i in range(0, z.shape[0], chunk_size)])
+        return frames.unflatten(0, (B, T)).to(video.device).to(out_dtype)
 
 
 class GraphSampler:

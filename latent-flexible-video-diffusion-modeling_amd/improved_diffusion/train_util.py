@@ -505,15 +505,14 @@ class TrainLoop:
                               'latent_mask': latent_mask.to(dev)},
                 latent_mask=latent_mask, return_attn_weights=False, return_decoded=False)
             samples = samples.cpu() * latent_mask + batch * obs_mask
-            try:
+            renderable = self.diffusion.diffusion_space in (None, "pixel") or self.diffusion.vae is not None
+            if renderable:     # latent space without an attached VAE: nothing to render, only the timing is logged
                 samples = self.decode(samples).float()
                 _mark_as_observed(samples[:, :n_obs])
                 vids = ((samples + 1) * 127.5).clamp(0, 255).to(th.uint8).cpu().numpy()
                 if wandb is not None and wandb.run is not None:
                     for i, video in enumerate(vids):
                         logger.logkv(f'video-{i}', wandb.Video(video), distributed=False)
-            except NotImplementedError:
-                pass   # latent space without the VAE: keep the latents, nothing to render
             logger.logkv("timing/sampling_time", time() - sample_start, distributed=False)
             self.model.train()
             with th.no_grad():

@@ -39,6 +39,8 @@ CONFIGS = {
     "cfgA": (dict(model_channels=32, channel_mult=(1, 2, 2, 2), attention_resolutions=(2, 4)), 1, 5, 32, 0),
     "cfgB": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 20, 16, 3),
     "cfgB_T14": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 14, 16, 0),
+    # BASELINE.json configs[2]: the per-GPU training workload (ch128, 4 levels, 20 frames of which 3 are padding, batch 2)
+    "cfgC": (dict(model_channels=128, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 20, 16, 3),
     # BASELINE.json configs[4] (pixel space 128x128x3, num_channels=128, reference defaults: num_res_blocks=2,
     # channel_mult (1,1,2,3,4), attention at 16x16 and 8x8 -> head dims 96 and 128) on 2 frames
     "cfgE_T2": (dict(in_channels=3, model_channels=128, num_res_blocks=2, channel_mult=(1, 1, 2, 3, 4),
@@ -97,10 +99,10 @@ def gen_forward(only=None):
             n_params=np.int64(sum(v.numel() for v in sd.values())))
 
 
-def gen_backward():
+def gen_backward(names=("micro", "micro_rb2", "cfgC")):
     """loss = sum(out * probe); parameter gradients of reference vs oracle; compact per-tensor
     summaries are stored (full tensors would be MBs)."""
-    for name in ("micro", "micro_rb2"):
+    for name in names:
         kw, B, T, H, n_pad = CONFIGS[name]
         cfg = uo.make_cfg(**kw)
         model, sd = build_reference_model(cfg)
@@ -300,6 +302,42 @@ def gen_diffusion():
     np.savez_compressed(os.path.join(OUT, "diffusion.npz"), **out)
 
 
+def gen_decode():
+    """The encode / decode boundary (reference gaussian_diffusion.py:914-947) with a stand-in autoencoder
+    (oracle/fake_vae.py) and a synthetic stats dict: de-normalisation of pre-encoded latents, chunked decode, chunked
+    encode.  The reference object is built in pixel space (its 'latent' constructor fetches the SVD pipeline by name,
+    which must never run) and then switched to the latent attributes its encode/decode read; ``Tensor.cuda`` is the
+    identity for the duration of the calls (this container has no GPU; the reference moves chunks with ``.cuda()``)."""
+    from oracle import fake_vae
+    diff = rsu.create_gaussian_diffusion(steps=1000, diffusion_space_kwargs={
+        "diffusion_space": "pixel", "pre_encoded": False, "pre_encoded_stats_dict": None})
+    st = fake_vae.stats_dict(4)
+    diff.diffusion_space = "latent"
+    diff.pre_encoded = True
+    diff.pre_encoded_stats_dict = {"mean": st["mean"].reshape(1, 1, -1, 1, 1), "std": st["std"].reshape(1, 1, -1, 1, 1)}
+    diff.vae, diff.image_processor = fake_vae.FakeVAE(), fake_vae.FakeImageProcessor()
+    diff.enc_dec_dtype, diff.original_dtype = torch.float32, torch.float32
+    z = torch.from_numpy(recipe.gaussianish("decode/z", 2 * 7 * 4 * 4 * 4).reshape(2, 7, 4, 4, 4).astype(np.float32))
+    px = torch.from_numpy((0.5 * recipe.gaussianish("decode/px", 2 * 5 * 3 * 16 * 16)).reshape(2, 5, 3, 16, 16).astype(np.float32)).clamp(-1, 1)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        dec_pre = diff.decode(z, chunk_size=4)                 # de-normalise, then 14 frames in chunks of 4
+        calls_dec = list(diff.vae.calls)
+        assert diff.encode(px) is px                           # pre-encoded: identity (:917-919)
+        diff.pre_encoded = False
+        diff.vae.calls.clear()
+        dec_raw = diff.decode(z, chunk_size=20)
+        enc = diff.encode(px, chunk_size=3)                    # 10 frames in chunks of 3
+        calls_enc = [c for c in diff.vae.calls if c[0] == "encode"]
+    finally:
+        torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(OUT, "decode.npz"), z=z.numpy(), px=px.numpy(), dec_pre=dec_pre.numpy(),
+                        dec_raw=dec_raw.numpy(), enc=enc.numpy(), mean=st["mean"].numpy(), std=st["std"].numpy(),
+                        dec_chunks=np.array([n for _, n in calls_dec]), enc_chunks=np.array([n for _, n in calls_enc]))
+    print("[decode] ok", dec_pre.shape, enc.shape, calls_dec, calls_enc)
+
+
 SCHEME_CASES = [
     # (scheme, video_length, n_obs, max_frames, step_size)
     ("autoreg", 1000, 36, 20, 10), ("autoreg", 1000, 0, 20, 10), ("autoreg", 47, 3, 8, 3),
@@ -337,9 +375,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "forward":
         gen_forward(only=sys.argv[2:])
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "backward":
+        gen_backward(names=sys.argv[2:])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "decode":
+        gen_decode()
+        sys.exit(0)
     gen_ops()
     gen_forward()
     gen_backward()
     gen_diffusion()
+    gen_decode()
     gen_schemes()
     print("golden vectors written to", OUT)

@@ -15,10 +15,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("inplace", [False, True], ids=["autograd", "inplace"])
-@pytest.mark.parametrize("name", ["micro", "micro_rb2"])
+@pytest.mark.parametrize("name", ["micro", "micro_rb2", "cfgC"])
 def test_parameter_gradients_match_oracle(name, inplace):
     """Both gradient delivery modes (_backward._GradMode): returned to autograd (default), or accumulated into p.grad
-    by the kernels (what TrainLoop switches on)."""
+    by the kernels (what TrainLoop switches on).  cfgC is the BASELINE.json configs[2] training shape (ch128, 4 levels,
+    20 frames of which 3 are padding, batch 2): there the in-place mode also takes the grouped RPE path."""
     g = np.load(os.path.join(GOLDEN, f"backward_{name}.npz"))
     cfg, sd, inp = load_case(name)
     model = build_native(cfg, sd).train()
@@ -33,6 +34,9 @@ def test_parameter_gradients_match_oracle(name, inplace):
                           obs_mask=d["obs_mask"], latent_mask=d["latent_mask"])
     assert torch.allclose(out.detach(), out_ng, atol=2e-4), float((out.detach() - out_ng).abs().max())
     (out * probe.cuda()).sum().backward()
+    if name == "cfgC" and inplace:
+        from improved_diffusion import _backward as bw
+        assert bw._rpe_group.state is not None and bw._embed.state is not None, "grouped embedding / RPE path expected"
     # oracle gradients (CPU autograd)
     sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     o, _ = uo.unet_forward(sdo, cfg, inp["x"], inp["x0"], inp["t"].float(), inp["frame_indices"], inp["obs_mask"], inp["latent_mask"])
@@ -51,6 +55,14 @@ def test_parameter_gradients_match_oracle(name, inplace):
         assert abs(float(p.grad.double().norm()) - float(g["norms"][i])) < 3e-3 * (float(g["norms"][i]) + 1e-3 * gmax * np.sqrt(ref.numel())), k
     print(f"[{name}] worst relative gradient error vs oracle: {worst:.2e} ({worst_key})")
     assert worst < 2e-3, (worst, worst_key)
+    # gradient w.r.t. the input latents against the reference's
+    if not inplace:
+        xg = d["x"].clone().requires_grad_(True)
+        model.zero_grad(set_to_none=True)
+        o2, _ = model(xg, x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"], obs_mask=d["obs_mask"],
+                      latent_mask=d["latent_mask"])
+        (o2 * probe.cuda()).sum().backward()
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), g["dx"], atol=5e-4 * np.abs(g["dx"]).max())
 
 
 def test_dropout_training_matches_oracle_with_the_same_draws():
@@ -178,3 +190,24 @@ def test_grouped_rpe_training_path_matches_per_network_path(monkeypatch):
             ref = sdo[k].grad
             err = float((grads["1"][k].cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-3 * gmax)
             assert err < 2e-3, (k, err)
+
+
+def test_attention_maps_in_grad_mode_match_no_grad_engine():
+    """return_attn_weights=True while gradients are recorded (reference unet.py:428-464 returns the detached
+    |mean over heads| maps in every mode): same maps as the no-grad engine, and the backward still works."""
+    cfg, sd, inp = load_case("micro")
+    model = build_native(cfg, sd).train()
+    d = {k: v.cuda() for k, v in inp.items()}
+    kw = dict(x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"], obs_mask=d["obs_mask"],
+              latent_mask=d["latent_mask"])
+    out, attn = model(d["x"], return_attn_weights=True, **kw)
+    with torch.no_grad():
+        out_ng, attn_ng = model(d["x"], return_attn_weights=True, **kw)
+    assert set(attn) == {"spatial", "temporal", "mixed"} and attn["mixed"] == []
+    assert len(attn["temporal"]) == len(attn_ng["temporal"]) > 0 and len(attn["spatial"]) == len(attn_ng["spatial"]) > 0
+    for kind in ("temporal", "spatial"):
+        for a, b in zip(attn[kind], attn_ng[kind]):
+            assert a.shape == b.shape and not a.requires_grad
+            assert torch.allclose(a, b, atol=1e-5), (kind, float((a - b).abs().max()))
+    out.sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())

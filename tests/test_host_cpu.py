@@ -219,3 +219,42 @@ def test_update_ema_and_zero_grad_helpers():
     assert torch.allclose(mean_flat(x, torch.tensor([[[1.0], [0.0]]])), torch.tensor([0.25, 2.25]))
     g = np.load(os.path.join(GOLDEN, "ops.npz"))
     assert np.array_equal(timestep_embedding(torch.from_numpy(g["temb_t"]), 64).numpy(), g["temb_64"])
+
+
+def test_vae_boundary_matches_reference_golden():
+    """encode / decode around the (here: stand-in) frame autoencoder against outputs of the REFERENCE's encode / decode
+    run with the same stand-in (oracle/make_golden.py gen_decode; reference gaussian_diffusion.py:914-947): pre-encoded
+    de-normalisation with a stats dict, chunking, reshapes.  Not a HIP path: plain tensor plumbing, so it runs here."""
+    from improved_diffusion import script_util as su
+    from oracle import fake_vae
+    g = np.load(os.path.join(GOLDEN, "decode.npz"))
+    z, px = torch.from_numpy(g["z"]), torch.from_numpy(g["px"])
+    st = {"mean": torch.from_numpy(g["mean"]), "std": torch.from_numpy(g["std"])}      # as torch.load(stats file) gives it
+    diff = su.create_gaussian_diffusion(steps=1000, diffusion_space_kwargs={
+        "diffusion_space": "latent", "pre_encoded": True, "pre_encoded_stats_dict": st})
+    assert diff.vae is None and diff.pre_encoded_stats_dict["std"].shape == (1, 1, 4, 1, 1)
+    # no autoencoder attached: pre-encoded latents come back de-normalised (what the decoder would be fed)
+    want = z * st["std"].view(1, 1, 4, 1, 1) + st["mean"].view(1, 1, 4, 1, 1)
+    assert torch.equal(diff.decode(z), want) and torch.equal(diff.denormalize_latents(z), want)
+    assert diff.encode(px) is px
+    # with the stand-in attached: the reference's outputs, chunk for chunk
+    vae = fake_vae.FakeVAE()
+    diff.set_vae(vae, fake_vae.FakeImageProcessor(), dtype=torch.float32)
+    np.testing.assert_array_equal(diff.decode(z, chunk_size=4).numpy(), g["dec_pre"])
+    assert [n for k, n in vae.calls if k == "decode"] == list(g["dec_chunks"])
+    raw = su.create_gaussian_diffusion(steps=1000, diffusion_space_kwargs={
+        "diffusion_space": "latent", "pre_encoded": False, "pre_encoded_stats_dict": None})
+    with pytest.raises(NotImplementedError):
+        raw.decode(z)
+    with pytest.raises(NotImplementedError):
+        raw.encode(px)
+    vae2 = fake_vae.FakeVAE()
+    raw.set_vae(vae2, fake_vae.FakeImageProcessor(), dtype=torch.float32)
+    enc = raw.encode(px, chunk_size=3)
+    np.testing.assert_array_equal(enc.numpy(), g["enc"])
+    assert [n for k, n in vae2.calls if k == "encode"] == list(g["enc_chunks"])
+    np.testing.assert_array_equal(raw.decode(z, chunk_size=20).numpy(), g["dec_raw"])
+    # pixel space: both are the identity
+    pix = su.create_gaussian_diffusion(steps=1000, diffusion_space_kwargs={"diffusion_space": "pixel", "pre_encoded": False,
+                                                                         "pre_encoded_stats_dict": None})
+    assert pix.decode(z) is z and pix.encode(px) is px

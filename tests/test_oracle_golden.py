@@ -17,6 +17,8 @@ CONFIGS = {
     "cfgA": (dict(model_channels=32, channel_mult=(1, 2, 2, 2), attention_resolutions=(2, 4)), 1, 5, 32, 0),
     "cfgB": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 20, 16, 3),
     "cfgB_T14": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 14, 16, 0),
+    # BASELINE.json configs[2]: per-GPU training workload (ch128, 4 levels, 20 frames incl. 3 padding frames, batch 2)
+    "cfgC": (dict(model_channels=128, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 20, 16, 3),
     # BASELINE.json configs[4]: pixel space 128x128x3, num_channels=128, num_res_blocks=2 (head dims 96 / 128), 2 frames
     "cfgE_T2": (dict(in_channels=3, model_channels=128, num_res_blocks=2, channel_mult=(1, 1, 2, 3, 4),
                      attention_resolutions=(8, 16)), 1, 2, 128, 0),
@@ -50,7 +52,7 @@ def test_forward_matches_reference(name):
     np.testing.assert_allclose(attn["spatial"][0].numpy()[:1, :32, :32], g["attn_s0"], atol=5e-5)
 
 
-@pytest.mark.parametrize("name", ["micro", "micro_rb2"])
+@pytest.mark.parametrize("name", ["micro", "micro_rb2", "cfgC"])
 def test_backward_matches_reference(name):
     g = np.load(os.path.join(GOLDEN, f"backward_{name}.npz"))
     cfg, sd, inp = load_case(name)

@@ -102,3 +102,61 @@ def test_graph_sampler_matches_eager_step():
     assert set(first) == {"sample", "pred_xstart", "attn"} and torch.is_grad_enabled()
     gen.close()
     assert torch.is_grad_enabled()
+
+
+def test_denoised_fn_is_applied_to_x0_hat():
+    """denoised_fn (reference gaussian_diffusion.py:305-309): applied to x0-hat before clipping, inside p_mean_variance,
+    p_sample and the loop.  Checked against the CPU oracle's step with the same function."""
+    from oracle import diffusion_oracle as do, unet_oracle as uo
+    cfg, sd, inp = load_case("micro")
+    model = build_native(cfg, sd)
+    diff = make_diffusion(1000, "")
+    tab = do.Tables(do.linear_betas(1000))
+    d = {k: v.cuda() for k, v in inp.items()}
+    mk = dict(frame_indices=d["frame_indices"], obs_mask=d["obs_mask"], latent_mask=d["latent_mask"], x0=d["x0"])
+    fn = lambda x: 0.5 * x + 0.1
+    t = torch.tensor([700, 0])
+    noise = torch.from_numpy(recipe.gaussianish("diff/noise1", inp["x"].numel()).reshape(inp["x"].shape).astype(np.float32))
+    with torch.no_grad():
+        got = diff.p_sample(model, d["x"], t.cuda(), clip_denoised=True, denoised_fn=fn, model_kwargs=mk, noise=noise.cuda())
+        pmv = diff.p_mean_variance(model, d["x"], t.cuda(), clip_denoised=True, denoised_fn=fn, model_kwargs=mk)
+        plain = diff.p_sample(model, d["x"], t.cuda(), clip_denoised=True, model_kwargs=mk, noise=noise.cuda())
+        eps, _ = uo.unet_forward(sd, cfg, inp["x"], inp["x0"], do.model_timesteps(tab, t), inp["frame_indices"],
+                                 inp["obs_mask"], inp["latent_mask"])
+    # oracle restatement of the step with the function applied
+    bs = lambda a: torch.from_numpy(a[t.numpy()]).float().view(-1, 1, 1, 1, 1)
+    pred = fn(bs(tab.sqrt_recip_alphas_cumprod) * inp["x"] - bs(tab.sqrt_recipm1_alphas_cumprod) * eps).clamp(-1, 1)
+    mean = bs(tab.posterior_mean_coef1) * pred + bs(tab.posterior_mean_coef2) * inp["x"]
+    logvar = np.log(np.append(tab.posterior_variance[1], tab.betas[1:]))
+    want = mean + (t != 0).float().view(-1, 1, 1, 1, 1) * torch.exp(0.5 * bs(logvar)) * noise
+    amp = 1.0 + float(tab.sqrt_recipm1_alphas_cumprod[700])
+    assert torch.allclose(got["pred_xstart"].cpu(), pred, atol=2e-4 * amp)
+    assert torch.allclose(pmv["pred_xstart"].cpu(), pred, atol=2e-4 * amp) and torch.allclose(pmv["mean"].cpu(), mean, atol=2e-4 * amp)
+    assert torch.allclose(got["sample"].cpu(), want, atol=2e-4 * amp)
+    assert not torch.allclose(got["sample"], plain["sample"], atol=1e-3), "the function must change the step"
+    # the loop accepts it too (eager path: a Python callback cannot live inside the captured step)
+    short = make_diffusion(1000, "4")
+    torch.manual_seed(1)
+    s, _ = short.p_sample_loop(model, tuple(inp["x"].shape), denoised_fn=fn, model_kwargs=mk, return_decoded=False)
+    assert bool(torch.isfinite(s).all()) and float(s.abs().max()) <= 1.0 + 1e-5
+
+
+def test_latent_space_loop_returns_denormalised_latents():
+    """diffusion_space='latent', pre_encoded=True with a stats dict (scripts/video_train.py:87-91): the sampler runs
+    on the normalised latents and ``return_decoded=True`` hands back z*std+mean when no VAE is attached."""
+    from improved_diffusion import script_util as su
+    from oracle import fake_vae
+    cfg, sd, inp = load_case("micro")
+    model = build_native(cfg, sd)
+    st = fake_vae.stats_dict(4)
+    diff = su.create_gaussian_diffusion(steps=1000, timestep_respacing="3", rescale_timesteps=True, rescale_learned_sigmas=True,
+                                        diffusion_space_kwargs={"diffusion_space": "latent", "pre_encoded": True,
+                                                                "pre_encoded_stats_dict": st})
+    d = {k: v.cuda() for k, v in inp.items()}
+    mk = dict(frame_indices=d["frame_indices"], obs_mask=d["obs_mask"], latent_mask=d["latent_mask"], x0=d["x0"])
+    torch.manual_seed(2)
+    raw, _ = diff.p_sample_loop(model, tuple(inp["x"].shape), model_kwargs=mk, return_decoded=False)
+    torch.manual_seed(2)
+    dec, _ = diff.p_sample_loop(model, tuple(inp["x"].shape), model_kwargs=mk, return_decoded=True)
+    want = raw * st["std"].view(1, 1, 4, 1, 1).cuda() + st["mean"].view(1, 1, 4, 1, 1).cuda()
+    assert torch.equal(dec, want)
