@@ -7,12 +7,22 @@ Workload (BASELINE.json configs[1]): latent U-Net num_channels=64, num_res_block
 batch 2, 1000-step DDPM ancestral sampling (p_sample loop) on synthetic 4x16x16 latents.  A "step" is one
 denoising step of the whole batch: timestep remap + U-Net forward + noise draw + x_{t-1} update, i.e. one
 iteration of reference gaussian_diffusion.py:509-522.  Inputs/state are resident in HBM; the step is one
-hipGraph replay.  N > 1 (launched with torch.distributed.run, one rank per GPU): sampling does not
-communicate (the reference parallelises sampling over videos, video_sample.py:192-200), so every rank
-samples its own videos — weak scaling, value = N*K / max-over-ranks time.
+hipGraph replay.
 
-One JSON line on stdout (rank 0) with `roofline` (dominant kernel = the implicit-GEMM conv, live
-HIP-event timing) and `cpu_baseline` (the CPU oracle restatement of the same step, bounded sample).
+N > 1: one rank per GPU over RCCL.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process is one of
+the ranks; started plainly as `python bench.py --gpus N` it starts the N ranks itself (a torch.distributed.run child,
+before anything here touches the GPU) and passes their JSON line through.  Sampling does not communicate (the reference
+parallelises sampling over videos, video_sample.py:192-200): every rank samples its own videos - weak scaling,
+`value` = N*K / max-over-ranks time.  The part of the path that does exchange data - training at BASELINE.json
+configs[2], batch sharded over the ranks, bucketed gradient all-reduce overlapped with the backward pass - is timed in
+the same run and reported at top level for N > 1 (`train_videos_per_s`, `allreduce_bytes_per_step`,
+`exposed_allreduce_ms_per_step`, `collective_world_size`, `collective_backend`) and under `train` in full.
+On a box with fewer than N GPUs the ranks share the cards and the collective backend falls back to gloo (a rehearsal
+of the plumbing, labelled as such in the line).
+
+One JSON line on stdout (rank 0) with `roofline` (dominant kernel = the implicit-GEMM conv, live HIP-event timing, every
+tile-shape instance listed) and `cpu_baseline` (the CPU oracle restatement of the same step: all cores, one thread, and a
+training step; bounded samples).
 """
 import argparse
 import json
@@ -118,18 +128,27 @@ def kernel_breakdown(plan, reps=10, inner=4):
     return groups
 
 
-def cpu_baseline_sample(model, diffusion, inputs, B, T, budget_s=12.0):
-    """CPU oracle restatement of the same denoising step (kind 'port'), all host cores."""
-    from oracle import unet_oracle as uo, diffusion_oracle as do
+def _host_cores():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))  # the GPU box grants 16 host cores per GPU
-    th.set_num_threads(cores)
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    return max(1, min(cores, 16))  # the GPU box grants 16 host cores per GPU
+
+
+def _oracle_model(model):
+    from oracle import unet_oracle as uo
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     cfg = uo.make_cfg(model_channels=model.model_channels, channel_mult=model.channel_mult,
                       attention_resolutions=model.attention_resolutions, num_heads=model.num_heads)
+    return sd, cfg
+
+
+def cpu_baseline_sample(model, inputs, B, T, threads, budget_s):
+    """CPU oracle restatement of the same denoising step (kind 'port') on `threads` host threads."""
+    from oracle import unet_oracle as uo, diffusion_oracle as do
+    th.set_num_threads(threads)
+    sd, cfg = _oracle_model(model)
     tab = do.Tables(do.linear_betas(1000))
     ci = {k: v.cpu() for k, v in inputs.items()}
     x = th.randn(B, T, 4, 16, 16)
@@ -146,8 +165,52 @@ def cpu_baseline_sample(model, diffusion, inputs, B, T, budget_s=12.0):
             if t0 is not None and time.perf_counter() - t0 > budget_s:
                 break
     el = time.perf_counter() - t0
-    return dict(value=round((n - 2) / el, 3), unit="steps/s", cores=cores, kind="port",
+    return dict(value=round((n - 2) / el, 3), unit="steps/s", cores=threads, kind="port",
                 sample=f"{n - 2} p_sample steps of the same workload (oracle/unet_oracle.py + diffusion_oracle.py, torch CPU fp32)")
+
+
+def cpu_baseline_train(threads, budget_s):
+    """CPU oracle restatement of one optimizer step at BASELINE.json configs[2] (reference TrainLoop.run_step,
+    train_util.py:267-275: zero grads, q_sample, U-Net forward, masked MSE, backward, AdamW, EMA) on `threads` threads."""
+    from oracle import unet_oracle as uo, diffusion_oracle as do
+    th.set_num_threads(threads)
+    model, _ = make_model_and_diffusion(128, th.device("cpu"))
+    sd, cfg = _oracle_model(model)
+    del model
+    params = {k: v.requires_grad_(True) for k, v in sd.items()}
+    ema = {k: v.detach().clone() for k, v in params.items()}
+    opt = th.optim.AdamW(list(params.values()), lr=1e-4, weight_decay=0.0)
+    tab = do.Tables(do.linear_betas(1000))
+    B, T = 2, 20
+    g = th.Generator().manual_seed(4321)
+    obs = th.zeros(B, T, 1, 1, 1); obs[:, :6] = 1.0
+    lat = 1.0 - obs; lat[:, -3:] = 0.0                      # 3 padding frames: neither observed nor latent
+    n, t0 = 0, None
+    while True:
+        if n == 1:
+            t0 = time.perf_counter()
+        x0 = th.randn(B, T, 4, 16, 16, generator=g).clamp(-1, 1)
+        fi = th.stack([th.sort(th.randperm(40, generator=g)[:T])[0] for _ in range(B)])
+        t = th.randint(0, 1000, (B,), generator=g)
+        noise = th.randn(x0.shape, generator=g)
+        opt.zero_grad(set_to_none=True)
+
+        def model_fn(x_t, ts):
+            return uo.unet_forward(params, cfg, x_t, x0, ts, fi, obs, lat)[0]
+
+        losses = do.training_losses(tab, model_fn, x0, t, noise, 1 - obs, lat)
+        losses["loss"].mean().backward()
+        opt.step()
+        with th.no_grad():
+            for k, v in params.items():
+                ema[k].mul_(0.9999).add_(v.detach(), alpha=1 - 0.9999)
+        n += 1
+        if t0 is not None and time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return dict(value=round((n - 1) / el, 3), unit="optimizer steps/s", cores=threads, kind="port",
+                sample=f"{n - 1} training steps at configs[2] (ch128, batch 2, 20 frames): oracle forward + torch autograd "
+                       "backward + torch AdamW + EMA, torch CPU fp32")
 
 
 def synthetic_video_stream(B, T_video, seed):
@@ -197,12 +260,23 @@ def bench_train(rank, world, dev, steps, warmup):
     loss = float(logger.name2val.get("loss", float("nan")))
     logger.dumpkvs()
     P = sum(p.numel() for p in model.parameters())
-    return {"optimizer_steps_per_s": round(steps / el, 3), "ms_per_step": round(1000.0 * el / steps, 2), "steps": steps,
-            "host_issue_ms_per_step": round(1000.0 * host / steps, 2),
-            "global_batch": 2 * world, "videos_per_s": round(2 * world * steps / el, 2), "params": P,
-            "allreduce_bytes_per_step": 4 * P if world > 1 else 0, "last_loss": loss,
-            "workload": "train: U-Net num_channels=128 num_res_blocks=1 max_frames=20 batch 2/GPU, AdamW+EMA, "
-                        "one RCCL all-reduce of the fp32 gradient arena per step (BASELINE.json configs[2])"}
+    xch = loop.exchange
+    th.cuda.synchronize()
+    exposed = xch.collect_timing()[-steps:] if world > 1 else []
+    out = {"optimizer_steps_per_s": round(steps / el, 3), "ms_per_step": round(1000.0 * el / steps, 2), "steps": steps,
+           "host_issue_ms_per_step": round(1000.0 * host / steps, 2),
+           "global_batch": 2 * world, "videos_per_s": round(2 * world * steps / el, 2), "params": P,
+           "allreduce_bytes_per_step": 4 * loop.arena.numel if world > 1 else 0, "last_loss": loss,
+           "workload": "train: U-Net num_channels=128 num_res_blocks=1 max_frames=20 batch 2/GPU, AdamW+EMA, bucketed "
+                       "all-reduce of the fp32 gradient arena overlapped with the backward graph (BASELINE.json configs[2])"}
+    if world > 1:
+        out["exchange"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                           "buckets": len(xch.ranges), "bucket_bytes": [4 * (hi - lo) for lo, hi in xch.ranges],
+                           "overlap_with_backward": bool(xch.overlap),
+                           "exposed_ms_per_step": round(sum(exposed) / max(1, len(exposed)), 3) if exposed else None,
+                           "buckets_started_inside_the_backward": xch.stats["buckets_behind_event"],
+                           "buckets_started_after_the_backward": xch.stats["buckets_behind_graph_end"]}
+    return out
 
 
 def bench_long_video(dev, max_windows):
@@ -288,40 +362,99 @@ def bench_pixel(dev, steps):
 
 
 def pmc_traffic(kernel_name):
-    """HBM-side bytes per launch of one kernel from the committed rocprofv3 counter passes
-    (profiles/r01_pmc_traffic.json, produced by tools/pmc_target.py + tools/pmc_summarize.py); None if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["kernels"].get(kernel_name, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError, KeyError):
-        return None
+    """HBM-side bytes per launch of one kernel from the committed rocprofv3 counter passes (newest
+    profiles/rNN_pmc_traffic.json, produced by tools/pmc_target.py + tools/pmc_summarize.py); None if absent."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                v = json.load(f)["kernels"].get(kernel_name, {}).get("hbm_bytes_per_launch")
+            if v is not None:
+                return v
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, the way the
+    driver does) and exit with their code.  Nothing in THIS process has touched the GPU yet (device_count() does not
+    initialise it); the ranks are ordinary children, not an exec of this process."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def timed_sampling(sampler, steps, world, dev, min_seconds, start_i):
+    """Regions of EXACTLY `steps` denoising steps, each bracketed by barrier + synchronize on both sides and reduced with
+    MAX over the ranks; repeated until at least `min_seconds` have been timed (a 20-step region is 26 ms: too short to
+    quote a rate from).  -> (list of region times, next timestep)."""
+    i, times = start_i, []
+    while True:
+        th.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        th.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sampler.step(i)
+            i = max(i - 1, 0)
+        th.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        th.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:           # the slowest rank's time; every rank then takes the same decision to go on
+            tt = th.tensor([el], device=dev, dtype=th.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        times.append(el)
+        if sum(times) >= min_seconds or len(times) >= 200:
+            return times, i
 
 
 def main():
-    # tile shapes measured once on an MI355X and committed: the same kernels run in every bench / profile pass
+    # tile shapes measured once on an MI355X and committed (loaded read-only): the same kernels run in every bench /
+    # profile pass
     os.environ.setdefault("LFVDM_TUNE_CACHE", os.path.join(ROOT, "profiles", "tune_cache_mi355x.json"))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=900)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step timed region until this much is timed")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--train-steps", type=int, default=30, help="timed optimizer steps of the training leg (0 = skip)")
-    ap.add_argument("--pixel-steps", type=int, default=0, help="also time this many steps of the pixel-space stress config (0 = skip)")
-    ap.add_argument("--long-video-windows", type=int, default=0,
-                    help="also run the hierarchy-2 long-video leg with at most this many windows (97 = full; 0 = skip)")
+    ap.add_argument("--pixel-steps", type=int, default=5, help="timed steps of the pixel-space stress config, configs[4] (0 = skip)")
+    ap.add_argument("--long-video-windows", type=int, default=4,
+                    help="windows of the hierarchy-2 long-video leg, configs[3] (97 = the full 1000-frame video; 0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not th.cuda.is_available():
+    n_dev = th.cuda.device_count()          # (does not initialise the GPU)
+    if n_dev == 0 or not th.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
-    local %= max(th.cuda.device_count(), 1)   # (rehearsals of N > 1 on a one-GPU box share the card)
+    shared_cards = world > n_dev             # rehearsal of N ranks on fewer cards
+    local %= n_dev
     th.cuda.set_device(local)
     dev = th.device("cuda", local)
+    backend = None
     if world > 1:
-        backend = os.environ.get("LFVDM_BENCH_BACKEND", "nccl")   # "gloo" only for such rehearsals
+        backend = os.environ.get("LFVDM_BENCH_BACKEND") or ("gloo" if shared_cards else "nccl")   # nccl = RCCL
+        os.environ["LFVDM_DIST_BACKEND"] = backend
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -339,23 +472,8 @@ def main():
     for _ in range(args.warmup):
         sampler.step(i)
         i = max(i - 1, 0)
-    th.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    th.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sampler.step(i)
-        i = max(i - 1, 0)
-    th.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    th.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tt = th.tensor([el], device=dev, dtype=th.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    times, i = timed_sampling(sampler, args.steps, world, dev, args.min_seconds, i)
+    el, regions = sum(times), len(times)
     finite = bool(th.isfinite(sampler.plan.x_in).all().item())
     train = None
     if args.train_steps > 0:
@@ -366,58 +484,88 @@ def main():
         sampler = diffusion._graph_sampler(model, shape, True)   # for the kernel breakdown below
         sampler.begin(th.randn(*shape, device=dev), inputs)
 
+    total_steps = args.steps * regions
     out = {
-        "metric": "denoising steps/sec (train+sample) on 20-frame 4x16x16 latents", "value": round(world * args.steps / el, 2),
+        "metric": "denoising steps/sec on 20-frame 4x16x16 latents (sampling; training reported alongside)",
+        "value": round(world * total_steps / el, 2),
         "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1000.0 * el / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1000.0 * el / total_steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "timed_regions": regions, "timed_seconds": round(el, 4),
+        "region_ms_per_step_min_max": [round(1000.0 * min(times) / args.steps, 4), round(1000.0 * max(times) / args.steps, 4)],
         "config": {"workload": "sample: p_sample loop, latent U-Net num_channels=64 num_res_blocks=1 max_frames=20 "
                                "batch=2 1000-step DDPM on synthetic 4x16x16 latents (BASELINE.json configs[1])",
                    "batch": B, "frames": T, "latent": "4x16x16", "parallelism": f"replicas x{world} (no collective)",
-                   "frames_steps_per_s": round(world * args.steps * B * T / el, 1), "finite": finite},
+                   "frames_steps_per_s": round(world * total_steps * B * T / el, 1), "finite": finite,
+                   "gpus_requested": args.gpus},
     }
+    if world > 1:
+        out["collective_world_size"] = dist.get_world_size()
+        out["collective_backend"] = ("rccl (torch 'nccl')" if backend == "nccl" else
+                                     f"{backend} - REHEARSAL: {world} ranks share {n_dev} GPU(s), not a scaling measurement")
     if train is not None:
         out["train"] = train
-    if args.long_video_windows > 0 and rank == 0:
-        out["long_video"] = bench_long_video(dev, args.long_video_windows)
-    if args.pixel_steps > 0 and rank == 0:
-        out["pixel"] = bench_pixel(dev, args.pixel_steps)
+        if world > 1:       # the quantity that shards WITH an exchange, at top level
+            out["train_videos_per_s"] = train["videos_per_s"]
+            out["train_optimizer_steps_per_s"] = train["optimizer_steps_per_s"]
+            out["allreduce_bytes_per_step"] = train["allreduce_bytes_per_step"]
+            out["exposed_allreduce_ms_per_step"] = train["exchange"]["exposed_ms_per_step"]
     if rank == 0:
+        # the single-GPU legs (configs[3], configs[4]) and the CPU baselines belong to the N = 1 line only
+        if args.long_video_windows > 0 and world == 1:
+            out["long_video"] = bench_long_video(dev, args.long_video_windows)
+        if args.pixel_steps > 0 and world == 1:
+            del sampler
+            diffusion._samplers.clear()
+            th.cuda.empty_cache()
+            out["pixel"] = bench_pixel(dev, args.pixel_steps)
+            th.cuda.empty_cache()
+            sampler = diffusion._graph_sampler(model, shape, True)
+            sampler.begin(th.randn(*shape, device=dev), inputs)
         if not args.no_breakdown:
             groups = kernel_breakdown(sampler.plan)
             tot_ms = sum(g["ms"] for g in groups.values())
             convs = {k: g for k, g in groups.items() if k.startswith("conv_igemm")}
             # dominant kernel = the implicit-GEMM template (conv_igemm_kernel): its tile-shape instances together are
-            # ~60 % of the step; which instance leads depends on the tuner's picks, so the family is reported as one
+            # ~60 % of the step; which instance leads depends on the tuner's picks, so the family is the headline and
+            # every instance is listed with what is needed to recompute its fraction
             dom = {"flops": sum(g["flops"] for g in convs.values()), "ms": sum(g["ms"] for g in convs.values()),
                    "launches": sum(g["launches"] for g in convs.values()), "bytes": sum(g["bytes"] for g in convs.values())}
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             tr = [(pmc_traffic(k), g["launches"]) for k, g in convs.items()]
             traffic = (round(sum(t * n for t, n in tr if t is not None) / max(1, sum(n for t, n in tr if t is not None)))
                        if any(t is not None for t, _ in tr) else None)
-            lead_name, lead = max(convs.items(), key=lambda kv: kv[1]["ms"])
+            instances = {}
+            for k, g in sorted(convs.items(), key=lambda kv: -kv[1]["ms"]):
+                tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                instances[k] = {"launches": g["launches"], "us": round(1000.0 * g["ms"], 2),
+                                "avg_launch_us": round(1000.0 * g["ms"] / g["launches"], 2),
+                                "gflop": round(g["flops"] / 1e9, 4), "tflops": round(tf, 2),
+                                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                                "algorithmic_bytes": round(g["bytes"] / g["launches"]), "pmc_bytes": pmc_traffic(k)}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                                "algorithmic_bytes": round(dom["bytes"] / dom["launches"]),
                                "kernel": "conv_igemm_kernel (all tile-shape instances of the implicit GEMM)",
                                "launches_per_step": dom["launches"],
                                "avg_launch_us": round(1000.0 * dom["ms"] / dom["launches"], 2),
-                               "leading_instance": {"kernel": lead_name, "launches_per_step": lead["launches"],
-                                                    "tflops": round(lead["flops"] / (lead["ms"] * 1e-3) / 1e12, 2)},
+                               "instances": instances,
                                "note": "fp32 MFMA (shares the vector ALUs with VALU on gfx950: 157.3 TFLOP/s is the peak of both together); "
-                                       "achieved = algorithmic conv/GEMM FLOPs of these launches / their HIP-event time; "
-                                       "traffic = launch-weighted mean of the PMC bytes per launch (L2 fills + write-backs; every XCD "
-                                       "that runs a filter tile fetches its weights); algorithmic_bytes = operands + output once"}
-            all_conv_flops = sum(g["flops"] for g in convs.values())
-            all_conv_ms = sum(g["ms"] for g in convs.values())
+                                       "achieved = algorithmic conv/GEMM FLOPs of these launches / their HIP-event time; per instance: "
+                                       "us = time per step, gflop = FLOPs per step, algorithmic_bytes / pmc_bytes = per launch "
+                                       "(operands + output once / PMC L2 fills + write-backs, separate --pmc passes); "
+                                       "traffic = launch-weighted mean of pmc_bytes"}
             out["breakdown"] = {"eager_sum_ms": round(tot_ms, 4), "launches": len(sampler.plan.steps),
-                                "all_conv_gemm_tflops": round(all_conv_flops / (all_conv_ms * 1e-3) / 1e12, 2),
-                                "step_flops_g": round(all_conv_flops / 1e9, 2),
-                                "whole_step_frac_of_mfma_peak": round(all_conv_flops * out["value"] / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                "all_conv_gemm_tflops": round(ach, 2),
+                                "step_flops_g": round(dom["flops"] / 1e9, 2),
+                                "whole_step_frac_of_mfma_peak": round(dom["flops"] * out["value"] / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                 "kernels": {k: {"n": g["launches"], "us": round(1000 * g["ms"], 1)} for k, g in
                                             sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}}
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline_sample(model, diffusion, inputs, B, T)
+        if not args.no_cpu and world == 1:
+            cores = _host_cores()
+            out["cpu_baseline"] = cpu_baseline_sample(model, inputs, B, T, cores, 8.0)
+            out["cpu_baseline"]["one_thread"] = cpu_baseline_sample(model, inputs, B, T, 1, 5.0)
+            out["cpu_baseline"]["train"] = cpu_baseline_train(cores, 8.0)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

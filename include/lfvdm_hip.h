@@ -413,6 +413,19 @@ typedef struct lfvdm_adamw_args {
 
 int lfvdm_adamw_ema(const lfvdm_adamw_args* a, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Cross-stream events that survive stream capture (host-side plumbing of the bucketed gradient exchange that
+ * stands in for DistributedDataParallel's overlapped buckets, train_util.py:116-125,309-313).
+ * An event recorded with lfvdm_event_record INSIDE a captured region becomes an external event-record node
+ * (hipEventRecordExternal): every replay of the graph records it when the node's predecessors have finished, and a
+ * stream outside the graph can wait for it with lfvdm_stream_wait_event issued after the graph launch was enqueued.
+ * Outside of capture lfvdm_event_record is a plain hipEventRecord.  (PyTorch-ROCm refuses `Event(external=True)`.)
+ * ------------------------------------------------------------------------------------- */
+int lfvdm_event_create(void** event);
+int lfvdm_event_destroy(void* event);
+int lfvdm_event_record(void* event, void* stream);
+int lfvdm_stream_wait_event(void* stream, void* event);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,8 +154,8 @@ class _PackedGrads:
 
     def __init__(self):
         self.bufs = {}          # id(param) -> (weakref(param), packed buffer)
-        self.table = None
-        self.table_key = None
+        self.tables = {}        # job tables by (accumulator, gradient) pointer set: one per distinct fold
+        self.done = set()       # ids folded by partial folds of the running backward pass
         self.queued = False
 
     def buffer(self, w):
@@ -164,32 +164,45 @@ class _PackedGrads:
             Cout, Cin, k, _ = w.shape
             ent = (weakref.ref(w), th.zeros(Cout, k * k, Cin, device=w.device, dtype=th.float32))
             self.bufs[id(w)] = ent
-            self.table = None
         if not self.queued:     # fold at the end of the running backward pass (also under graph capture)
             self.queued = True
             th.autograd.Variable._execution_engine.queue_callback(self.flush)
         return ent[1]
 
-    def flush(self):
-        self.queued = False
+    def flush(self, only=None):
+        """Fold the packed accumulators into the OIHW ``.grad`` tensors (and re-zero them).  ``only``: a set of
+        parameter ids - a partial fold in the middle of the backward pass, issued by the gradient exchange when a
+        bucket is complete (_exchange.GradExchange.bucket_ready); the end-of-backward call then folds the rest."""
+        if only is None:
+            self.queued = False
         for k in [k for k, (r, _) in self.bufs.items() if r() is None]:     # parameters of freed models
             del self.bufs[k]
-            self.table = None
-        live = [(r(), gp) for r, gp in self.bufs.values()]
+            self.tables.clear()
+        done = self.done
+        live = [(r(), gp) for k, (r, gp) in self.bufs.items() if (k in only if only is not None else k not in done)]
         live = [(w, gp) for w, gp in live if w is not None and w.grad is not None and w.grad.is_cuda]
+        if only is None:
+            self.done = set()
+        else:
+            self.done = done | {id(w) for w, _ in live}
         if not live:
             return
         key = tuple((gp.data_ptr(), w.grad.data_ptr()) for w, gp in live)
-        if self.table is None or self.table_key != key:
+        ent = self.tables.get(key)
+        if ent is None:
+            if th.cuda.is_current_stream_capturing():
+                raise RuntimeError("packed-gradient job table missing under stream capture: run the step eagerly once first")
             jobs, row0, mx = [], 0, 0
             for w, gp in live:
                 Cout, Cin, k, _ = w.shape
                 jobs.append(nat.UnpackJob(gp.data_ptr(), w.grad.data_ptr(), Cout, Cin, k * k, row0))
                 row0 += Cout
                 mx = max(mx, k * k * Cin)
-            self.table, self.table_key, self.rows, self.mx, self.njobs = nat.jobs_to_device(jobs, live[0][0].device), key, row0, mx, len(jobs)
-        nat.check(nat.lib().lfvdm_unpack_conv_grads(self.table.data_ptr(), self.njobs, self.rows, self.mx, nat.stream()),
-                  "lfvdm_unpack_conv_grads")
+            if len(self.tables) > 64:
+                self.tables.clear()
+            ent = self.tables[key] = (nat.jobs_to_device(jobs, live[0][0].device), len(jobs), row0, mx)
+        table, njobs, rows, mx = ent
+        nat.check(nat.lib().lfvdm_unpack_conv_grads(table.data_ptr(), njobs, rows, mx, nat.stream()), "lfvdm_unpack_conv_grads")
 
 
 _packed = _PackedGrads()
@@ -998,12 +1011,22 @@ class UNetFunction:
 
         rpe_grp = _rpe_group.forward(m, views, frame_indices, B, T, x.device) if views is not None else None
 
-        for blk in list(m.input_blocks)[1:]:
-            cur = stage(blk, cur)
+        # data-parallel training: marker nodes at the inputs of the stages where a gradient bucket starts; their
+        # backward tells the exchange that the bucket is complete (_exchange.GradExchange)
+        xch = getattr(m, "_grad_exchange", None) if _mode.inplace else None
+
+        def enter(cur, key):
+            if xch is None:
+                return cur
+            return (xch.mark(cur[0], key), cur[1], cur[2])
+
+        for i, blk in enumerate(list(m.input_blocks)[1:], start=1):
+            cur = stage(blk, enter(cur, (0, i)))
             hs.append(cur)
-        cur = stage(m.middle_block, cur)
-        for blk in m.output_blocks:
-            cur = stage(blk, cur, skip=hs.pop()[0])
+        cur = stage(m.middle_block, enter(cur, (1, 0)))
+        for i, blk in enumerate(m.output_blocks):
+            cur = stage(blk, enter(cur, (2, i)), skip=hs.pop()[0])
+        cur = enter(cur, (3, 0))
         h, Hc, Wc = cur
         out = HeadFn.apply(h, m.out[0].weight, m.out[0].bias, m.out[2].weight, m.out[2].bias, N, Hc, Wc)
         return out.view(B, T, m.out_channels, H, W), attns

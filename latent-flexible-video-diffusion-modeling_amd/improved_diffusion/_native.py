@@ -125,6 +125,10 @@ _SIGS = {
     "lfvdm_q_sample": ([c_fp] * 6 + [c_i, c_i, c_fp], c_i),
     "lfvdm_p_sample": ([c_fp] * 9 + [c_i] + [c_fp] * 3 + [c_i, c_i, c_fp], c_i),
     "lfvdm_masked_mse": ([c_fp] * 4 + [c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_event_create": ([C.POINTER(c_fp)], c_i),
+    "lfvdm_event_destroy": ([c_fp], c_i),
+    "lfvdm_event_record": ([c_fp, c_fp], c_i),
+    "lfvdm_stream_wait_event": ([c_fp, c_fp], c_i),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -391,6 +395,31 @@ def p_sample(x, eps, noise, t, recip, recipm1, c1, c2, logvar, clip, sample, pre
 
 def masked_mse(a, b, mask, out, B, T, frame_inner):
     check(lib().lfvdm_masked_mse(ptr(a), ptr(b), ptr(mask), ptr(out), B, T, frame_inner, stream()), "lfvdm_masked_mse")
+
+
+class GraphEvent:
+    """Cross-stream event that can be recorded inside a captured region and waited on from outside the graph
+    (lfvdm_event_record: an external event-record node under capture, a plain record otherwise)."""
+
+    def __init__(self):
+        h = c_fp()
+        check(lib().lfvdm_event_create(C.byref(h)), "lfvdm_event_create")
+        self.handle = h
+
+    def record(self, torch_stream=None):
+        s = (torch_stream or torch.cuda.current_stream()).cuda_stream
+        check(lib().lfvdm_event_record(self.handle, s), "lfvdm_event_record")
+
+    def wait(self, torch_stream):
+        """Make ``torch_stream`` wait for the most recent record."""
+        check(lib().lfvdm_stream_wait_event(torch_stream.cuda_stream, self.handle), "lfvdm_stream_wait_event")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().lfvdm_event_destroy(self.handle)
+        except Exception:
+            pass
 
 
 def jobs_to_device(jobs, device):

@@ -45,7 +45,9 @@ def setup_dist():
     the rest of the code can call torch.distributed unconditionally, like the reference does."""
     if dist.is_initialized():
         return
-    backend = "nccl" if th.cuda.is_available() else "gloo"
+    # "nccl" is RCCL on ROCm.  LFVDM_DIST_BACKEND=gloo is for rehearsing several ranks on ONE card (RCCL refuses two
+    # ranks on the same device): tests/test_dist_gpu.py and `bench.py --gpus N` on a box with fewer than N GPUs.
+    backend = os.environ.get("LFVDM_DIST_BACKEND") or ("nccl" if th.cuda.is_available() else "gloo")
     comm = _mpi_comm()
     if comm is not None and "RANK" not in os.environ:
         hostname = "127.0.0.1" if backend == "gloo" else socket.gethostbyname(socket.getfqdn())

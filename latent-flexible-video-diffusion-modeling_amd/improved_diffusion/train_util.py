@@ -27,6 +27,7 @@ from . import _native as nat
 from .logger import logger
 from .fp16_util import zero_grad  # noqa: F401  (reference API)
 from .nn import update_ema  # noqa: F401  (reference API)
+from ._exchange import GradExchange, plan_buckets
 from .resample import LossAwareSampler, UniformSampler
 from .rng_util import rng_decorator, RNG
 
@@ -40,18 +41,25 @@ INITIAL_LOG_LOSS_SCALE = 20.0
 
 class ParamArena:
     """Flat fp32 storage for a list of parameters: ``p.data`` and ``p.grad`` become views of two
-    contiguous buffers (named_parameters order), which gives one collective per step, one fused
-    optimizer launch and a memset for zero_grad."""
+    contiguous buffers, which gives one collective per bucket, one fused optimizer launch and a memset for
+    zero_grad.  ``groups`` (lists of parameter indices) fixes the layout order: each group is one contiguous
+    slice (``bucket_ranges``) - the unit of the gradient exchange (_exchange.py); default: one group in
+    ``named_parameters`` order.  ``self.params`` / ``views()`` keep the caller's order whatever the layout."""
 
-    def __init__(self, params):
+    def __init__(self, params, groups=None):
         self.params = list(params)
         dev = self.params[0].device
         self.sizes = [p.numel() for p in self.params]
+        self.groups = [list(g) for g in groups] if groups is not None else [list(range(len(self.params)))]
+        assert sorted(i for g in self.groups for i in g) == list(range(len(self.params))), "groups must partition the parameters"
         # 16-byte aligned slots so that every parameter view stays float4-addressable for the kernels
-        self.offsets, off = [], 0
-        for n in self.sizes:
-            self.offsets.append(off)
-            off += (n + 3) // 4 * 4
+        self.offsets, self.bucket_ranges, off = [0] * len(self.params), [], 0
+        for g in self.groups:
+            lo = off
+            for i in g:
+                self.offsets[i] = off
+                off += (self.sizes[i] + 3) // 4 * 4
+            self.bucket_ranges.append((lo, off))
         self.numel = off
         self.p = th.zeros(off, device=dev, dtype=th.float32)
         self.g = th.zeros(off, device=dev, dtype=th.float32)
@@ -113,9 +121,14 @@ class TrainLoop:
         self._load_and_sync_parameters()
         self.model_params = list(self.model.parameters())
         self.master_params = self.model_params
-        self.arena = ParamArena(self.model_params)
+        # gradient arena laid out in the buckets of the data-parallel exchange (backward order, _exchange.py)
+        n_buckets = int(os.environ.get("LFVDM_GRAD_BUCKETS", "4")) if self.world > 1 else 1
+        groups, marks = plan_buckets(self.model.named_parameters(), max(1, n_buckets))
+        self.arena = ParamArena(self.model_params, groups)
+        self.exchange = GradExchange(self.arena, marks, self.world)
         if hasattr(self.model, "native_grad_accumulation"):
             self.model.native_grad_accumulation = True      # gradients accumulate in the arena, reduced in optimize_normal
+            self.model._grad_exchange = self.exchange if self.world > 1 else None   # bucket markers in the backward pass
         if hasattr(self.model, "_engine"):
             self.model._engine = None          # parameter storage moved: drop cached device pointers
         dev = self.arena.p.device
@@ -142,10 +155,7 @@ class TrainLoop:
 
         self.use_ddp = self.world > 1
         self.ddp_model = self.model            # gradient averaging is done on the arena (see optimize_normal)
-        if self.use_ddp:
-            dist.broadcast(self.arena.p, 0)    # same initial replica everywhere (DDP does this at construction)
-            for f in self.ema_flat:
-                dist.broadcast(f, 0)
+        self.exchange.broadcast(self.arena.p, *self.ema_flat)   # same initial replica everywhere (DDP: at construction)
         if self.rank == 0:
             logger.logkv("num_parameters", sum(p.numel() for p in model.parameters()), distributed=False)
 
@@ -401,9 +411,11 @@ class TrainLoop:
             log_loss_dict(self.diffusion, vals[-1], {k: vals[i] for i, k in enumerate(keys)})
 
     def optimize_normal(self):
-        """All-reduce (once) + fused AdamW/EMA/grad-norm (reference train_util.py:346-357)."""
+        """Bucketed all-reduce (overlapped with the tail of the backward pass) + fused AdamW/EMA/grad-norm
+        (reference train_util.py:346-357; the exchange is DDP's there, :116-125)."""
         if self.use_ddp:
-            dist.all_reduce(self.arena.g, op=dist.ReduceOp.SUM)   # RCCL; averaged by grad_scale below
+            self.exchange.launch()      # RCCL SUM per bucket on the side stream; averaged by grad_scale below
+            self.exchange.wait()
         self._anneal_lr()
         self.opt_step += 1
         self.grad_sqsum.zero_()

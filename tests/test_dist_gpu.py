@@ -1,0 +1,135 @@
+"""``TrainLoop`` at world size 2 on the MI355X: two fresh processes share cuda:0 (gloo backend - RCCL refuses two ranks
+on one device; everything above the collective call is the code the 8-GPU job runs).  Each rank trains on different data;
+after ``run_step`` both ranks must hold identical parameters, equal to a single-process AdamW/EMA step on the MEAN of the
+two ranks' gradients (reference train_util.py:116-125 DDP wrap + :346-357 optimizer).  Steps 3+ run the captured
+micro-step, where the bucket events are external event-record nodes of the replayed graph.  GPU only."""
+import argparse
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _data(B, T, C, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    while True:
+        yield (torch.randn(B, T, C, H, H, generator=g).clamp(-1, 1), {})
+
+
+def _worker(rank, world, port, q, microbatch):
+    try:
+        for p in (PKG, ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), LFVDM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        from improved_diffusion import dist_util, script_util as su
+        from improved_diffusion.train_util import TrainLoop
+        from test_oracle_golden import load_case
+        from test_forward_gpu import build_native
+        dist_util.setup_dist()
+        assert dist.get_world_size() == world and dist.get_backend() == "gloo" and dist_util.dev().type == "cuda"
+        cfg, sd, _ = load_case("micro")
+        if rank == 1:       # a different replica on purpose: the constructor must broadcast rank 0's
+            sd = {k: v + 0.01 for k, v in sd.items()}
+        model = build_native(cfg, sd).train()
+        diffusion = su.create_gaussian_diffusion(steps=1000, rescale_timesteps=True, rescale_learned_sigmas=True)
+        loop = TrainLoop(model=model, diffusion=diffusion, data=_data(2, 12, 4, 16, 50 + rank), batch_size=2, microbatch=microbatch,
+                         lr=1e-3, ema_rate="0.9", log_interval=1000, save_interval=10 ** 9, resume_checkpoint="", use_fp16=False,
+                         diffusion_space_kwargs={}, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.01,
+                         lr_anneal_steps=0, sample_interval=None, pad_with_random_frames=True, max_frames=4,
+                         enc_dec_chunk_size=20, args=argparse.Namespace(resume_id=""))
+        assert loop.world == world and loop.use_ddp and len(loop.arena.bucket_ranges) == 4
+        params = list(model.parameters())
+
+        def gathered(t):
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t.contiguous())
+            return out
+
+        def flat(tensors):
+            return torch.cat([t.detach().reshape(-1) for t in tensors])
+
+        p0 = gathered(flat(params))
+        assert torch.equal(p0[0], p0[1]), "parameters must be rank 0's after construction"
+        assert torch.equal(flat(loop.ema_params[0]), flat(params))
+        torch.manual_seed(100 + rank); np.random.seed(100 + rank)
+        # ---- step 1 (eager micro-steps): exchange + fused optimizer against torch AdamW on the mean gradient
+        loop.forward_backward()
+        local = flat([p.grad for p in params])
+        both = gathered(local)
+        assert not torch.allclose(both[0], both[1]), "ranks must see different data"
+        mean_grad = (both[0] + both[1]) / world
+        ref_params = [torch.nn.Parameter(p.detach().clone()) for p in params]
+        off = 0
+        for rp in ref_params:
+            rp.grad = mean_grad[off:off + rp.numel()].view_as(rp).clone()
+            off += rp.numel()
+        opt = torch.optim.AdamW(ref_params, lr=1e-3, weight_decay=0.01)
+        opt.step()
+        ref_ema = [p.detach().clone().mul_(0.9).add_(rp.detach(), alpha=0.1) for p, rp in zip(params, ref_params)]
+        loop.optimize_normal()
+        loop.step += 1
+        torch.cuda.synchronize()
+        for p, rp in zip(params, ref_params):
+            assert torch.allclose(p.detach(), rp.detach(), atol=1e-6, rtol=1e-5)
+        for e, re_ in zip(loop.ema_params[0], ref_ema):
+            assert torch.allclose(e, re_, atol=1e-6, rtol=1e-5)
+        gn_ref = float(mean_grad.double().norm())
+        assert abs(float(np.sqrt(loop.grad_sqsum.item())) - gn_ref) < 1e-3 * gn_ref, "grad norm is that of the MEAN gradient"
+        # ---- steps 2..6: the micro-step becomes a replayed graph; replicas must stay bit-identical
+        for _ in range(5):
+            loop.run_step()
+            loop.step += 1
+        torch.cuda.synchronize()
+        assert loop._graph_state.get("graph") is not None, "micro-step was not captured"
+        pn = gathered(flat(params))
+        assert torch.equal(pn[0], pn[1]), float((pn[0] - pn[1]).abs().max())
+        en = gathered(flat(loop.ema_params[0]))
+        assert torch.equal(en[0], en[1])
+        assert bool(torch.isfinite(pn[0]).all()) and float((pn[0] - p0[0]).abs().max()) > 1e-3
+        st = dict(loop.exchange.stats)
+        assert st["exchanges"] == 6
+        if loop.exchange.overlap:       # 3 early buckets behind their events, the last one behind the end of the graph
+            assert st["buckets_behind_event"] == 3 * 6 and st["buckets_behind_graph_end"] == 6, st
+        loop.exchange.collect_timing()
+        dist.barrier()
+        q.put((rank, "ok", st, bool(loop.exchange.overlap), [round(x, 3) for x in loop.exchange.exposed_ms]))
+        dist.destroy_process_group()
+    except Exception as e:      # surface the failure in the parent
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), None, None))
+        raise
+
+
+@pytest.mark.parametrize("microbatch", [-1, 1], ids=["one_microbatch", "two_microbatches"])
+def test_trainloop_world2_matches_mean_gradient_step(microbatch):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, microbatch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in range(world):
+        res.append(q.get(timeout=420))
+    for p in procs:
+        p.join(60)
+    for r in sorted(res):
+        print(r)
+    assert all(r[1] == "ok" for r in res), [r[2] for r in res if r[1] != "ok"]
+    assert all(p.exitcode == 0 for p in procs)
