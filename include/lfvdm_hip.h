@@ -414,17 +414,17 @@ typedef struct lfvdm_adamw_args {
 int lfvdm_adamw_ema(const lfvdm_adamw_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * Cross-stream events that survive stream capture (host-side plumbing of the bucketed gradient exchange that
- * stands in for DistributedDataParallel's overlapped buckets, train_util.py:116-125,309-313).
- * An event recorded with lfvdm_event_record INSIDE a captured region becomes an external event-record node
- * (hipEventRecordExternal): every replay of the graph records it when the node's predecessors have finished, and a
- * stream outside the graph can wait for it with lfvdm_stream_wait_event issued after the graph launch was enqueued.
- * Outside of capture lfvdm_event_record is a plain hipEventRecord.  (PyTorch-ROCm refuses `Event(external=True)`.)
+ * Device-side semaphores between a replayed hipGraph and another stream: host-side plumbing of the bucketed gradient
+ * exchange that stands in for DistributedDataParallel's overlapped buckets (train_util.py:116-125,309-313).
+ *   lfvdm_flag_add : *flag += 1 once everything enqueued before it on `stream` has completed.  An ordinary kernel node
+ *                    when captured, so every replay of the backward graph bumps the counter at that point.
+ *   lfvdm_flag_wait: `stream` proceeds when *flag - target >= 0 (one parked wave polls with device-scope loads), or
+ *                    after `timeout_s` seconds, in which case *timed_out is set to 1 (the host must treat that as an
+ *                    error).  Issued on the exchange's side stream in front of a bucket's all-reduce.
+ * (An external event-record node would do the same; the HIP runtime of PyTorch-ROCm 2.10 refuses it under capture.)
  * ------------------------------------------------------------------------------------- */
-int lfvdm_event_create(void** event);
-int lfvdm_event_destroy(void* event);
-int lfvdm_event_record(void* event, void* stream);
-int lfvdm_stream_wait_event(void* stream, void* event);
+int lfvdm_flag_add(int32_t* flag, void* stream);
+int lfvdm_flag_wait(const int32_t* flag, int32_t target, double timeout_s, int32_t* timed_out, void* stream);
 
 #ifdef __cplusplus
 }

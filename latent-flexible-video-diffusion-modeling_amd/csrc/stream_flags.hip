@@ -1,0 +1,50 @@
+// Device-side semaphores between a replayed hipGraph and another stream (see lfvdm_hip.h).
+//
+// Why kernels and not events: an event recorded inside a captured region only orders work INSIDE the graph; the
+// external event-record node that would do this job (hipEventRecordExternal) is refused under capture by the HIP runtime
+// that ships with PyTorch-ROCm 2.10 (and by torch itself: "External events are disallowed in rocm").  A counter in device
+// memory needs nothing from the runtime: lfvdm_flag_add is an ordinary kernel node of the graph, lfvdm_flag_wait an
+// ordinary kernel on the waiting stream.
+#include "common_hip.h"
+
+namespace {
+
+__global__ void flag_add_kernel(int* flag) {
+    // Everything the stream ran before this node has completed (kernel boundary = agent-scope release of its stores):
+    // the increment publishes "bucket complete".
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void flag_wait_kernel(const int* flag, int target, long long timeout_ticks, int* timed_out) {
+    // One lane polls with device-scope loads (served by the memory side, never by this CU's L1) and sleeps between polls:
+    // a parked wave, no measurable bandwidth.  The exit condition is always reached: the counter arrives, or the
+    // 100 MHz wall clock passes the deadline (then `timed_out` is raised and the host fails the step loudly).
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {   // wrap-safe
+            __builtin_amdgcn_s_sleep(64);
+            if (wall_clock64() - t0 > timeout_ticks) {
+                atomicExch(timed_out, 1);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
+}  // namespace
+
+extern "C" int lfvdm_flag_add(int32_t* flag, void* stream) {
+    if (!flag) return LFVDM_E_SHAPE;
+    hipLaunchKernelGGL(flag_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_flag_wait(const int32_t* flag, int32_t target, double timeout_s, int32_t* timed_out, void* stream) {
+    if (!flag || !timed_out || !(timeout_s > 0)) return LFVDM_E_SHAPE;
+    const long long ticks = (long long)(timeout_s * 1.0e8);      // wall_clock64 runs at 100 MHz on gfx950
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, target, ticks, timed_out);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}

@@ -11,11 +11,11 @@ a contiguous slice of the arena, so its exchange is one all-reduce with no packi
 
 Overlap.  ``UNetFunction`` plants an identity autograd node at the input of the first stage of every bucket.  Its
 backward runs when all gradient kernels of the bucket have been issued: it folds the bucket's packed 3x3 weight-gradient
-accumulators into the arena and records an event (``_native.GraphEvent``: PyTorch-ROCm refuses external events, the C
-ABI's lfvdm_event_record issues them).  Inside the captured micro-step the event is an EXTERNAL event node
-(hipEventRecordExternal), which other streams can wait on after ``graph.replay()`` has been enqueued: the collective of
-bucket k is issued on a side stream behind event k and runs (RCCL over xGMI) while the rest of the backward graph is still
-executing.  Only the last bucket's collective is exposed.  The SUM is turned into the mean by ``grad_scale = 1/world`` in
+accumulators into the arena and bumps a counter in device memory (``_native.StreamFlags`` -> lfvdm_flag_add: an
+ordinary kernel node, so it also fires in every REPLAY of the captured micro-step, where no Python runs.  An external
+event-record node would be the textbook tool; PyTorch-ROCm and its HIP runtime refuse it under capture).  After the last
+micro-batch the collective of bucket k is issued on a side stream behind lfvdm_flag_wait(counter k >= number of
+micro-steps so far) and runs (RCCL over xGMI) while the rest of the backward graph is still executing.  Only the last bucket's collective is exposed.  The SUM is turned into the mean by ``grad_scale = 1/world`` in
 the fused optimizer.
 
 The class is device-agnostic: on CPU tensors (gloo, the world-size-2 CPU test) there are no streams or events and the
@@ -79,42 +79,6 @@ def plan_buckets(named_params, n_buckets=4):
     return groups, marks
 
 
-_graph_events_ok = {}
-
-
-def graph_events_work(device):
-    """One-time self-test per device: an event recorded inside a captured graph must order a side stream that waits
-    for it after the replay was enqueued (see tools/external_event_probe.py for the timed version)."""
-    key = str(device)
-    if key not in _graph_events_ok:
-        from . import _native as nat
-        ok = False
-        try:
-            with th.cuda.device(device):
-                a, b = th.zeros(256, device=device), th.zeros(256, device=device)
-                ev, side, warm = nat.GraphEvent(), th.cuda.Stream(), th.cuda.Stream()
-                warm.wait_stream(th.cuda.current_stream())
-                with th.cuda.stream(warm):
-                    a.fill_(0.0)
-                th.cuda.current_stream().wait_stream(warm)
-                th.cuda.synchronize()
-                g = th.cuda.CUDAGraph()
-                with th.cuda.graph(g):
-                    a.fill_(7.0)
-                    ev.record()
-                    a.add_(0.0)
-                g.replay()
-                with th.cuda.stream(side):
-                    ev.wait(side)
-                    b.copy_(a)
-                th.cuda.synchronize()
-                ok = bool((b == 7.0).all())
-        except RuntimeError:
-            ok = False
-        _graph_events_ok[key] = ok
-    return _graph_events_ok[key]
-
-
 class _Mark(th.autograd.Function):
     """Identity; its backward tells the exchange that every gradient kernel of a bucket has been issued."""
 
@@ -142,15 +106,13 @@ class GradExchange:
         self.overlap = bool(overlap) and self.on_gpu and self.n_early > 0
         self.bucket_param_ids = [frozenset(id(arena.params[i]) for i in g) for g in arena.groups]
         self.comm = None
-        self.ev = None
+        self.flags = None
         self.fired = [False] * self.n_early
+        self.micro_steps = 0               # every micro-step (eager or replayed) bumps every early counter once
         if self.overlap:
-            if not graph_events_work(arena.g.device):      # HIP runtime without external event nodes: exchange after the graph
-                self.overlap = False
-            else:
-                from . import _native as nat
-                self.comm = th.cuda.Stream()
-                self.ev = [nat.GraphEvent() for _ in range(self.n_early)]
+            from . import _native as nat
+            self.comm = th.cuda.Stream()
+            self.flags = nat.StreamFlags(self.n_early, arena.g.device)
         self._works = []
         self._timing = []              # (start, end) event pairs of the exposed waits, read lazily
         self.exposed_ms = []
@@ -175,7 +137,7 @@ class GradExchange:
         from ._backward import _packed
         _packed.flush(only=self.bucket_param_ids[k])          # 3x3 weight gradients of this bucket -> arena
         if self.overlap:
-            self.ev[k].record()           # an external event-record node when the micro-step is being captured
+            self.flags.add(k)             # a kernel node of the graph when the micro-step is being captured
             self.fired[k] = True
 
     # ------------------------------------------------------------------ after the last micro-batch
@@ -203,7 +165,7 @@ class GradExchange:
                     continue
                 early = k < self.n_early and self.overlap and self.fired[k] and not tail_started
                 if early:
-                    self.ev[k].wait(self.comm)
+                    self.flags.wait(k, self.micro_steps, self.comm)
                     self.stats["buckets_behind_event"] += 1
                 else:
                     if not tail_started:
@@ -211,7 +173,9 @@ class GradExchange:
                         tail_started = True
                     self.stats["buckets_behind_graph_end"] += 1
                 self._works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
-        self.fired = [False] * self.n_early
+    def micro_step_done(self):
+        """Called by TrainLoop after every micro-step it has enqueued (eager or graph replay)."""
+        self.micro_steps += 1
 
     def wait(self):
         """Order the current stream (the optimizer comes next) behind the collectives; the time it stalls is the

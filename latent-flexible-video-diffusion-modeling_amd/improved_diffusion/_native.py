@@ -125,10 +125,8 @@ _SIGS = {
     "lfvdm_q_sample": ([c_fp] * 6 + [c_i, c_i, c_fp], c_i),
     "lfvdm_p_sample": ([c_fp] * 9 + [c_i] + [c_fp] * 3 + [c_i, c_i, c_fp], c_i),
     "lfvdm_masked_mse": ([c_fp] * 4 + [c_i, c_i, c_i, c_fp], c_i),
-    "lfvdm_event_create": ([C.POINTER(c_fp)], c_i),
-    "lfvdm_event_destroy": ([c_fp], c_i),
-    "lfvdm_event_record": ([c_fp, c_fp], c_i),
-    "lfvdm_stream_wait_event": ([c_fp, c_fp], c_i),
+    "lfvdm_flag_add": ([c_fp, c_fp], c_i),
+    "lfvdm_flag_wait": ([c_fp, c_i, C.c_double, c_fp, c_fp], c_i),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -397,29 +395,26 @@ def masked_mse(a, b, mask, out, B, T, frame_inner):
     check(lib().lfvdm_masked_mse(ptr(a), ptr(b), ptr(mask), ptr(out), B, T, frame_inner, stream()), "lfvdm_masked_mse")
 
 
-class GraphEvent:
-    """Cross-stream event that can be recorded inside a captured region and waited on from outside the graph
-    (lfvdm_event_record: an external event-record node under capture, a plain record otherwise)."""
+class StreamFlags:
+    """Counters in device memory that order another stream behind points INSIDE a replayed graph (lfvdm_flag_add /
+    lfvdm_flag_wait; one 128-byte line per counter)."""
 
-    def __init__(self):
-        h = c_fp()
-        check(lib().lfvdm_event_create(C.byref(h)), "lfvdm_event_create")
-        self.handle = h
+    def __init__(self, n, device):
+        self.buf = torch.zeros(n + 1, 32, device=device, dtype=torch.int32)     # row n: the timed-out word
+        self.n = n
 
-    def record(self, torch_stream=None):
-        s = (torch_stream or torch.cuda.current_stream()).cuda_stream
-        check(lib().lfvdm_event_record(self.handle, s), "lfvdm_event_record")
+    def add(self, k):
+        """Counter k += 1 behind everything enqueued so far on the current stream (capturable)."""
+        check(lib().lfvdm_flag_add(self.buf[k].data_ptr(), stream()), "lfvdm_flag_add")
 
-    def wait(self, torch_stream):
-        """Make ``torch_stream`` wait for the most recent record."""
-        check(lib().lfvdm_stream_wait_event(torch_stream.cuda_stream, self.handle), "lfvdm_stream_wait_event")
+    def wait(self, k, target, torch_stream, timeout_s=20.0):
+        """``torch_stream`` proceeds once counter k has reached ``target``."""
+        check(lib().lfvdm_flag_wait(self.buf[k].data_ptr(), int(target) & 0x7FFFFFFF, float(timeout_s), self.buf[self.n].data_ptr(),
+                                    torch_stream.cuda_stream), "lfvdm_flag_wait")
 
-    def __del__(self):
-        try:
-            if self.handle:
-                lib().lfvdm_event_destroy(self.handle)
-        except Exception:
-            pass
+    def timed_out(self):
+        """Host check (synchronises): did any wait give up?"""
+        return bool(self.buf[self.n, 0].item())
 
 
 def jobs_to_device(jobs, device):

@@ -341,6 +341,7 @@ class TrainLoop:
                 weighted, raw = self._graphed_micro_step(inputs)
             else:
                 weighted, raw = self._micro_step(*inputs)
+            self.exchange.micro_step_done()
             if isinstance(self.schedule_sampler, LossAwareSampler):
                 self.schedule_sampler.update_with_local_losses(t, raw)
             # The loss terms are logged one micro-step late (or at the next dumpkvs/save): reading them now
@@ -435,6 +436,8 @@ class TrainLoop:
         self._invalidate_engine()
         if self.step % self.log_interval == 0:   # the only host sync of the optimizer phase
             logger.logkv_mean("grad_norm", float(np.sqrt(self.grad_sqsum.item())))
+            if self.exchange.flags is not None and self.exchange.flags.timed_out():
+                raise RuntimeError("gradient exchange: a bucket's wait on the backward graph timed out (lfvdm_flag_wait)")
 
     def _invalidate_engine(self):
         nat.param_epoch[0] += 1          # cached packed weights (sampler plans, training path) are stale now

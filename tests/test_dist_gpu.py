@@ -105,6 +105,7 @@ def _worker(rank, world, port, q, microbatch):
         assert st["exchanges"] == 6
         if loop.exchange.overlap:       # 3 early buckets behind their events, the last one behind the end of the graph
             assert st["buckets_behind_event"] == 3 * 6 and st["buckets_behind_graph_end"] == 6, st
+            assert not loop.exchange.flags.timed_out()
         loop.exchange.collect_timing()
         dist.barrier()
         q.put((rank, "ok", st, bool(loop.exchange.overlap), [round(x, 3) for x in loop.exchange.exposed_ms]))

@@ -32,7 +32,7 @@ def main():
     out = th.zeros(1024, device=dev)
     out2 = th.zeros(1024, device=dev)
     res = {"torch": th.__version__}
-    ev = nat.GraphEvent()          # torch's Event(external=True) is refused on ROCm: the library records it (host_sync.hip)
+    flags = nat.StreamFlags(1, dev)     # external events are refused on ROCm: a counter bumped by a kernel node instead
     side = th.cuda.Stream()
     s = th.cuda.Stream()
     s.wait_stream(th.cuda.current_stream())
@@ -44,7 +44,7 @@ def main():
     with th.cuda.graph(g):
         spin(big, 20)
         buf.fill_(1.0)
-        ev.record()
+        flags.add(0)
         spin(big, 60)
         buf2.fill_(1.0)
     th.cuda.synchronize()
@@ -59,7 +59,7 @@ def main():
         t0.record()
         g.replay()
         with th.cuda.stream(side):
-            ev.wait(side)
+            flags.wait(0, it + 1, side)
             out.copy_(buf)
             out2.copy_(buf2)
             t_side.record(side)
@@ -71,6 +71,7 @@ def main():
         ok_all &= (a == 1.0)
     res["rounds"] = rounds
     res["ordered_after_A"] = bool(ok_all)
+    res["timed_out"] = flags.timed_out()
     res["overlaps_B"] = bool(all(r["side_done_ms"] < 0.7 * r["main_done_ms"] for r in rounds))
     print(json.dumps(res))
     return 0
