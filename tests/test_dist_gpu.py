@@ -2,7 +2,7 @@
 on one device; everything above the collective call is the code the 8-GPU job runs).  Each rank trains on different data;
 after ``run_step`` both ranks must hold identical parameters, equal to a single-process AdamW/EMA step on the MEAN of the
 two ranks' gradients (reference train_util.py:116-125 DDP wrap + :346-357 optimizer).  Steps 3+ run the captured
-micro-step, where the bucket events are external event-record nodes of the replayed graph.  GPU only."""
+micro-step, where the "bucket complete" signals are counter-bumping kernel nodes of the replayed graph.  GPU only."""
 import argparse
 import os
 import socket
@@ -52,7 +52,8 @@ def _worker(rank, world, port, q, microbatch):
                          diffusion_space_kwargs={}, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.01,
                          lr_anneal_steps=0, sample_interval=None, pad_with_random_frames=True, max_frames=4,
                          enc_dec_chunk_size=20, args=argparse.Namespace(resume_id=""))
-        assert loop.world == world and loop.use_ddp and len(loop.arena.bucket_ranges) == 4
+        n_buckets = len(loop.arena.bucket_ranges)         # up to LFVDM_GRAD_BUCKETS = 4; a two-level U-Net may give fewer
+        assert loop.world == world and loop.use_ddp and 2 <= n_buckets <= 4 and len(loop.exchange.marks) == n_buckets - 1
         params = list(model.parameters())
 
         def gathered(t):
@@ -103,8 +104,9 @@ def _worker(rank, world, port, q, microbatch):
         assert bool(torch.isfinite(pn[0]).all()) and float((pn[0] - p0[0]).abs().max()) > 1e-3
         st = dict(loop.exchange.stats)
         assert st["exchanges"] == 6
-        if loop.exchange.overlap:       # 3 early buckets behind their events, the last one behind the end of the graph
-            assert st["buckets_behind_event"] == 3 * 6 and st["buckets_behind_graph_end"] == 6, st
+        assert loop.exchange.overlap, "the overlapped exchange is the default on a GPU"
+        if loop.exchange.overlap:       # the early buckets behind their counters, the last one behind the end of the graph
+            assert st["buckets_behind_event"] == (n_buckets - 1) * 6 and st["buckets_behind_graph_end"] == 6, st
             assert not loop.exchange.flags.timed_out()
         loop.exchange.collect_timing()
         dist.barrier()
