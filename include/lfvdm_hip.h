@@ -414,6 +414,19 @@ typedef struct lfvdm_adamw_args {
 int lfvdm_adamw_ema(const lfvdm_adamw_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Training-batch assembly on the device (TrainLoop.prepare_training_batch, train_util.py:224-241, with the masks of
+ * sample_all_masks, :193-222).  The host samples the index table (same sequence of random draws as the reference);
+ * the gather and the mask / index tensors are produced here, inside the captured training step.
+ *   pool  [B][Tp][frame_elems]  candidate frames of each batch element (e.g. video1 frames followed by the frames of
+ *                               the padding video), frame_elems = C*H*W, a multiple of 4
+ *   table [B][F][4] int32       {row in the pool, frame index (-> frame_indices), observed 0/1, latent 0/1}
+ *   -> batch [B][F][frame_elems], frame_indices [B][F] int64, obs_mask / latent_mask [B][F] fp32 (the reference's
+ *      (B, F, 1, 1, 1) tensors).
+ * ------------------------------------------------------------------------------------- */
+int lfvdm_prepare_batch(const float* pool, const int32_t* table, float* batch, int64_t* frame_indices, float* obs_mask,
+                        float* latent_mask, int B, int F, int Tp, int frame_elems, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Device-side semaphores between a replayed hipGraph and another stream: host-side plumbing of the bucketed gradient
  * exchange that stands in for DistributedDataParallel's overlapped buckets (train_util.py:116-125,309-313).
  *   lfvdm_flag_add : *flag += 1 once everything enqueued before it on `stream` has completed.  An ordinary kernel node

@@ -125,6 +125,7 @@ _SIGS = {
     "lfvdm_q_sample": ([c_fp] * 6 + [c_i, c_i, c_fp], c_i),
     "lfvdm_p_sample": ([c_fp] * 9 + [c_i] + [c_fp] * 3 + [c_i, c_i, c_fp], c_i),
     "lfvdm_masked_mse": ([c_fp] * 4 + [c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_prepare_batch": ([c_fp] * 6 + [c_i] * 4 + [c_fp], c_i),
     "lfvdm_flag_add": ([c_fp, c_fp], c_i),
     "lfvdm_flag_wait": ([c_fp, c_i, C.c_double, c_fp, c_fp], c_i),
 }
@@ -389,6 +390,14 @@ def p_sample(x, eps, noise, t, recip, recipm1, c1, c2, logvar, clip, sample, pre
     check(lib().lfvdm_p_sample(ptr(x), ptr(eps), ptr(noise), ptr(t, torch.int64), ptr(recip), ptr(recipm1), ptr(c1),
                                ptr(c2), ptr(logvar), int(bool(clip)), ptr(sample), ptr(pred), ptr(mean), B,
                                x.numel() // B, stream()), "lfvdm_p_sample")
+
+
+def prepare_batch(pool, table, batch, frame_indices, obs_mask, latent_mask):
+    """pool (B, Tp, ...) fp32, table (B, F, 4) int32 -> batch (B, F, ...), frame_indices (B, F) int64, masks (B, F, 1, 1, 1)."""
+    B, Tp = pool.shape[:2]
+    F = table.shape[1]
+    check(lib().lfvdm_prepare_batch(ptr(pool), ptr(table, torch.int32), ptr(batch), ptr(frame_indices, torch.int64), ptr(obs_mask),
+                                    ptr(latent_mask), B, F, Tp, pool[0, 0].numel(), stream()), "lfvdm_prepare_batch")
 
 
 def masked_mse(a, b, mask, out, B, T, frame_inner):

@@ -199,13 +199,11 @@ class TrainLoop:
                 return indices
             print("warning: sampled invalid indices", indices, "trying again")
 
-    def sample_all_masks(self, batch1, batch2=None, gather=True, set_masks={'obs': (), 'latent': ()}):
-        """Random observed/latent frame masks with at most ``max_frames`` frames flagged per video
-        (reference train_util.py:193-222)."""
+    def _sample_masks_np(self, B, T):
+        """Observed / latent frame flags (B, T) of one batch, at most ``max_frames`` flagged per video: the random
+        process of reference train_util.py:196-207 with the same sequence of random draws.  Host-side bookkeeping in
+        numpy (the reference indexes torch rows element by element, tens of ms per step)."""
         N = self.max_frames
-        B, T, *_ = batch1.shape
-        # Host-side bookkeeping in numpy (the reference's loop indexes torch rows element by element, which
-        # costs tens of ms per step); the sequence of random draws is the reference's.
         obs_np = np.zeros((B, T), dtype=np.float32)
         lat_np = np.zeros((B, T), dtype=np.float32)
         for obs_row, latent_row in zip(obs_np, lat_np):
@@ -217,6 +215,13 @@ class TrainLoop:
                 if len(indices) > N - obs_row.sum() - latent_row.sum():
                     break
                 mask[indices] = 1.
+        return obs_np, lat_np
+
+    def sample_all_masks(self, batch1, batch2=None, gather=True, set_masks={'obs': (), 'latent': ()}):
+        """Random observed/latent frame masks with at most ``max_frames`` frames flagged per video
+        (reference train_util.py:193-222)."""
+        B, T, *_ = batch1.shape
+        obs_np, lat_np = self._sample_masks_np(B, T)
         shape5 = (B, T, 1, 1, 1)
         masks = {'obs': th.from_numpy(obs_np).to(batch1.dtype).view(shape5).to(batch1.device),
                  'latent': th.from_numpy(lat_np).to(batch1.dtype).view(shape5).to(batch1.device)}
@@ -230,6 +235,28 @@ class TrainLoop:
         batch, (obs_mask, latent_mask), frame_indices = self.prepare_training_batch(
             any_mask, batch1, batch2, (masks['obs'], masks['latent']))
         return batch, frame_indices, obs_mask, latent_mask
+
+    def sample_index_table(self, B, T):
+        """The training batch as an INDEX TABLE instead of gathered tensors (device-side batch preparation,
+        SURVEY 8f.3): int32 (B, max_frames, 4) rows {frame of video1 (< T) or T + frame of the padding video, frame
+        index, observed, latent}.  Same random draws, in the same order, as ``sample_all_masks`` followed by
+        ``prepare_training_batch`` with ``pad_with_random_frames`` (reference :196-207 then :236 per video), so a seed
+        gives the same batch on either path; like the reference, a padding slot inherits the flags of the frame
+        position it was drawn at (:239-241)."""
+        assert self.pad_with_random_frames, "the index table describes fixed-size batches (pad_with_random_frames)"
+        F = self.max_frames
+        obs_np, lat_np = self._sample_masks_np(B, T)
+        table = np.zeros((B, F, 4), dtype=np.int32)
+        for b in range(B):
+            flagged = np.flatnonzero((obs_np[b] + lat_np[b]) > 0)
+            n = len(flagged)
+            pads = th.randint_like(th.zeros(F - n, dtype=th.int64), high=T).numpy()
+            frames = np.concatenate([flagged, pads])
+            table[b, :, 0] = np.concatenate([flagged, T + pads])
+            table[b, :, 1] = frames
+            table[b, :, 2] = obs_np[b, frames]
+            table[b, :, 3] = lat_np[b, frames]
+        return table
 
     def prepare_training_batch(self, mask, batch1, batch2, tensors):
         """Gather the flagged frames of batch1 (sorted), pad to ``max_frames`` with random frames of
@@ -289,34 +316,92 @@ class TrainLoop:
         loss.backward()          # gradients accumulate in the arena across micro-batches
         return {k: (v * weights).detach() for k, v in losses.items()}, losses["loss"].detach()
 
-    def _graphed_micro_step(self, inputs):
+    def _micro_step_from_pool(self, pool, table, t, weights):
+        """Device-side batch preparation + micro-step: gather the frames named by the index table and write the mask /
+        index tensors (lfvdm_prepare_batch), then the usual micro-step.  One capturable body."""
+        B, F = table.shape[0], table.shape[1]
+        micro = th.empty((B, F) + tuple(pool.shape[2:]), device=pool.device, dtype=th.float32)
+        frame_indices = th.empty(B, F, device=pool.device, dtype=th.int64)
+        obs_mask = th.empty(B, F, 1, 1, 1, device=pool.device, dtype=th.float32)
+        latent_mask = th.empty_like(obs_mask)
+        nat.prepare_batch(pool, table, micro, frame_indices, obs_mask, latent_mask)
+        return self._micro_step(micro, frame_indices, obs_mask, latent_mask, t, weights)
+
+    def _graphed_micro_step(self, inputs, body=None, upload=None):
         """Replay the captured micro-step (forward + backward, ~1000 launches) as ONE hipGraph: the training
-        step is host-bound otherwise.  Captured once the shapes have been seen twice; static input buffers."""
-        key = tuple((tuple(x.shape), x.dtype) for x in inputs)
+        step is host-bound otherwise.  Captured once the shapes have been seen twice; static input buffers.
+        ``body``: the capturable function of the inputs (default ``_micro_step``).  ``upload``: (pinned bytes, views) of
+        inputs that are still on the host - ``inputs`` is then None and the bytes are copied straight into the static
+        buffers (one H2D copy, no staging tensor on the device)."""
+        body = body or self._micro_step
+        sig = [(shape, dt) for _, _, dt, shape in upload[1]] if upload is not None else [(tuple(x.shape), x.dtype) for x in inputs]
+        key = (body.__name__,) + tuple(sig)
         st = self._graph_state
         if st.get("key") != key:
             st.clear()
             st.update(key=key, seen=0)
         st["seen"] += 1
         if st["seen"] <= 2 or os.environ.get("LFVDM_TRAIN_GRAPH", "1") == "0":
-            return self._micro_step(*inputs)          # eager warm-up (also sets kernel attributes)
+            if upload is not None:
+                inputs = self._to_device(upload)
+            self._dev_inputs = inputs
+            return body(*inputs)          # eager warm-up (also sets kernel attributes)
         # A replay runs no Python, so the version-gated re-pack of the conv weights inside the autograd blocks never
         # fires there: bring the packed copies up to date eagerly, before the capture (which then records no pack
         # launch, whatever micro-batch of the optimizer step it happens to land on) and before every replay.
         from ._backward import _packs
         _packs.refresh_if_stale()
         if "graph" not in st:
-            st["static_in"] = [x.clone() for x in inputs]
+            if upload is not None:
+                stage, views = upload
+                st["static_bytes"] = th.empty(stage.numel(), device=dist_util.dev(), dtype=th.uint8)
+                st["static_in"] = [st["static_bytes"][o:o + nb].view(dt).view(shape) for o, nb, dt, shape in views]
+                st["static_bytes"].copy_(stage, non_blocking=True)
+            else:
+                st["static_in"] = [x.clone() for x in inputs]
             th.cuda.synchronize()
             g = th.cuda.CUDAGraph()
             with th.cuda.graph(g):
-                st["static_out"] = self._micro_step(*st["static_in"])
+                st["static_out"] = body(*st["static_in"])
             st["graph"] = g
             # the capture itself does not execute: run the step for real below
-        for dst, src in zip(st["static_in"], inputs):
-            dst.copy_(src)
+        if upload is not None:
+            st["static_bytes"].copy_(upload[0], non_blocking=True)
+            self._stage_issued()
+        else:
+            for dst, src in zip(st["static_in"], inputs):
+                dst.copy_(src)
         st["graph"].replay()
+        self._dev_inputs = st["static_in"]
         return st["static_out"]
+
+    def _device_prep_ok(self, batch1):
+        """Device-side batch preparation applies to fixed-size batches of host tensors whose encode step is the identity
+        (pixel space or pre-encoded latents); LFVDM_DEVICE_BATCH_PREP=0 restores the host gather."""
+        d = self.diffusion
+        return (self.pad_with_random_frames and not batch1.is_cuda and dist_util.dev().type == "cuda"
+                and batch1.dtype == th.float32 and batch1[0, 0].numel() % 4 == 0
+                and (getattr(d, "diffusion_space", None) in (None, "pixel") or bool(getattr(d, "pre_encoded", False)))
+                and os.environ.get("LFVDM_DEVICE_BATCH_PREP", "1") != "0")
+
+    # videos up to this many bytes travel whole and are gathered on the device; longer ones (CARLA: 1000 frames) are
+    # thinned on the host to the frames the table names, so that only those cross PCIe
+    POOL_WHOLE_VIDEO_BYTES = 2 << 20
+
+    def _pool_and_table(self, micro1, micro2, table):
+        """(pool, table) for lfvdm_prepare_batch: the whole videos [video1 | padding video] when they are short, else
+        the named frames only (one vectorised index_select per video; table rows renumbered 0..F-1)."""
+        B, T = micro1.shape[:2]
+        src2 = micro1 if micro2 is None else micro2
+        if 2 * T * micro1[0, 0].numel() * 4 <= self.POOL_WHOLE_VIDEO_BYTES:
+            return th.cat([micro1, src2], dim=1), table
+        rows = th.from_numpy(table[:, :, 0].astype(np.int64))
+        pool = th.stack([th.where((rows[b] < T).view(-1, *([1] * (micro1.dim() - 2))),
+                                  micro1[b].index_select(0, rows[b].clamp(max=T - 1)),
+                                  src2[b].index_select(0, (rows[b] - T).clamp(min=0))) for b in range(B)])
+        table = table.copy()
+        table[:, :, 0] = np.arange(table.shape[1], dtype=np.int32)[None]
+        return pool, table
 
     def forward_backward(self):
         self.arena.zero_grad()
@@ -325,22 +410,31 @@ class TrainLoop:
         for i in range(0, batch1.shape[0], self.microbatch):
             micro1 = batch1[i:i + self.microbatch]
             micro2 = batch2[i:i + self.microbatch] if batch2 is not None else None
-            micro, frame_indices, obs_mask, latent_mask = self.sample_all_masks(micro1, micro2)
-            micro = self.encode(micro)
             dev = dist_util.dev()
-            if dev.type == "cuda" and not micro.is_cuda:
-                t, weights = self.schedule_sampler.sample(micro.shape[0], th.device("cpu"))
-                inputs = self._upload_async(dev, micro, frame_indices, obs_mask, latent_mask, t, weights)
-                micro, frame_indices, obs_mask, latent_mask, t, weights = inputs
+            if self._device_prep_ok(micro1):
+                # host: the index table (same random draws as the reference's mask sampling); device: everything else
+                table = self.sample_index_table(micro1.shape[0], micro1.shape[1])
+                pool, table = self._pool_and_table(micro1, micro2, table)
+                t, weights = self.schedule_sampler.sample(micro1.shape[0], th.device("cpu"))
+                upload = self._stage(pool, th.from_numpy(table), t, weights)
+                weighted, raw = self._graphed_micro_step(None, body=self._micro_step_from_pool, upload=upload)
+                t = self._dev_inputs[2]            # the timesteps as the device saw them (loss-quartile logging)
             else:
-                micro, frame_indices = micro.to(dev), frame_indices.to(dev)
-                obs_mask, latent_mask = obs_mask.to(dev), latent_mask.to(dev)
-                t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
-                inputs = (micro, frame_indices, obs_mask, latent_mask, t, weights)
-            if micro.is_cuda and self.pad_with_random_frames:
-                weighted, raw = self._graphed_micro_step(inputs)
-            else:
-                weighted, raw = self._micro_step(*inputs)
+                micro, frame_indices, obs_mask, latent_mask = self.sample_all_masks(micro1, micro2)
+                micro = self.encode(micro)
+                if dev.type == "cuda" and not micro.is_cuda:
+                    t, weights = self.schedule_sampler.sample(micro.shape[0], th.device("cpu"))
+                    inputs = self._to_device(self._stage(micro, frame_indices, obs_mask, latent_mask, t, weights))
+                    micro, frame_indices, obs_mask, latent_mask, t, weights = inputs
+                else:
+                    micro, frame_indices = micro.to(dev), frame_indices.to(dev)
+                    obs_mask, latent_mask = obs_mask.to(dev), latent_mask.to(dev)
+                    t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
+                    inputs = (micro, frame_indices, obs_mask, latent_mask, t, weights)
+                if micro.is_cuda and self.pad_with_random_frames:
+                    weighted, raw = self._graphed_micro_step(inputs)
+                else:
+                    weighted, raw = self._micro_step(*inputs)
             self.exchange.micro_step_done()
             if isinstance(self.schedule_sampler, LossAwareSampler):
                 self.schedule_sampler.update_with_local_losses(t, raw)
@@ -349,10 +443,10 @@ class TrainLoop:
             self._flush_loss_log()
             self._stash_loss_log(t, weighted)
 
-    def _upload_async(self, dev, *host_tensors):
-        """All host inputs of a micro-step in ONE asynchronous copy from a pinned staging ring: a pageable
-        ``.to(device)`` blocks the host until the GPU has drained the previous step, which would serialise batch
-        preparation with the device work."""
+    def _stage(self, *host_tensors):
+        """All host inputs of a micro-step packed into ONE pinned buffer of a staging ring -> (pinned bytes, views):
+        a pageable ``.to(device)`` blocks the host until the GPU has drained the previous step, which would
+        serialise batch preparation with the device work."""
         ring = self.__dict__.setdefault("_stage_ring", {"slots": [], "next": 0})
         sizes = [(x.numel() * x.element_size() + 15) // 16 * 16 for x in host_tensors]
         total = sum(sizes)
@@ -362,17 +456,36 @@ class TrainLoop:
         slot = ring["slots"][ring["next"]]
         ring["next"] = (ring["next"] + 1) % len(ring["slots"])
         if slot[1] is not None:
-            slot[1].synchronize()              # copy issued 4 micro-steps ago: long finished
+            self._blocked(slot[1].synchronize)       # copy issued 4 micro-steps ago: long finished
+            slot[1] = None
         stage, off, views = slot[0], 0, []
         for x, n in zip(host_tensors, sizes):
             nb = x.numel() * x.element_size()
             stage[off:off + nb].view(x.dtype).copy_(x.reshape(-1))
             views.append((off, nb, x.dtype, tuple(x.shape)))
             off += n
-        dbuf = stage[:total].to(dev, non_blocking=True)
-        slot[1] = th.cuda.Event()
-        slot[1].record()
+        self._stage_slot = slot
+        return stage[:total], views
+
+    def _stage_issued(self):
+        """The H2D copy of the most recently staged buffer has been enqueued: mark when the slot may be reused."""
+        ev = th.cuda.Event()
+        ev.record()
+        self._stage_slot[1] = ev
+
+    def _to_device(self, upload):
+        """Asynchronous copy of a staged buffer into a fresh device tensor -> tuple of device views."""
+        stage, views = upload
+        dbuf = stage.to(dist_util.dev(), non_blocking=True)
+        self._stage_issued()
         return tuple(dbuf[o:o + nb].view(dt).view(shape) for o, nb, dt, shape in views)
+
+    def _blocked(self, fn):
+        """Run a call that may block on the GPU and account the time (``host_wait_s``): the rest of a step is host WORK."""
+        t0 = time()
+        out = fn()
+        self.host_wait_s = getattr(self, "host_wait_s", 0.0) + (time() - t0)
+        return out
 
     def _stash_loss_log(self, t, weighted):
         """Queue the per-sample loss terms for logging without stalling this stream: a side stream copies them
@@ -407,7 +520,7 @@ class TrainLoop:
         if pending is not None:
             keys, host, done = pending
             if done is not None:
-                done.synchronize()
+                self._blocked(done.synchronize)
             vals = host.numpy()
             log_loss_dict(self.diffusion, vals[-1], {k: vals[i] for i, k in enumerate(keys)})
 

@@ -158,3 +158,64 @@ def test_graphed_microbatches_see_updated_weights():
         assert torch.equal(e[1], want), f"packed copy of a {shape} weight is stale (transposed={transposed})"
         checked += 1
     assert checked >= 10
+
+
+def test_device_batch_preparation_matches_host_gather(monkeypatch):
+    """lfvdm_prepare_batch driven by the host-sampled index table builds the same training batch as the
+    reference-style host gather (sample_all_masks + prepare_training_batch, train_util.py:193-241) from the same seed -
+    frames, frame indices, both masks - for whole-video pools and for host-thinned pools (long videos)."""
+    from improved_diffusion import _native as nat
+    cfg, sd, _ = load_case("micro")
+    model = build_native(cfg, sd).train()
+    loop = make_loop(model, batch_size=3, T_video=30, max_frames=7)
+    g = torch.Generator().manual_seed(9)
+    b1, b2 = torch.randn(3, 30, 4, 16, 16, generator=g), torch.randn(3, 30, 4, 16, 16, generator=g)
+    for whole in (True, False):
+        monkeypatch.setattr(type(loop), "POOL_WHOLE_VIDEO_BYTES", (2 << 20) if whole else 0)
+        torch.manual_seed(21); np.random.seed(21)
+        want = loop.sample_all_masks(b1, b2)                 # (batch, frame_indices, obs_mask, latent_mask) on the host
+        torch.manual_seed(21); np.random.seed(21)
+        table = loop.sample_index_table(3, 30)
+        pool, tab = loop._pool_and_table(b1, b2, table)
+        assert pool.shape[1] == (60 if whole else 7)
+        micro = torch.empty(3, 7, 4, 16, 16, device="cuda")
+        fi = torch.empty(3, 7, dtype=torch.int64, device="cuda")
+        obs, lat = torch.empty(3, 7, 1, 1, 1, device="cuda"), torch.empty(3, 7, 1, 1, 1, device="cuda")
+        nat.prepare_batch(pool.cuda(), torch.from_numpy(tab).cuda(), micro, fi, obs, lat)
+        assert torch.equal(micro.cpu(), want[0]) and torch.equal(fi.cpu(), want[1])
+        assert torch.equal(obs.cpu(), want[2]) and torch.equal(lat.cpu(), want[3])
+    # invariants of the table (the reference's: <= max_frames flagged, observed and latent disjoint, flagged frames
+    # sorted and first, padding rows point into the second video)
+    for seed in range(20):
+        torch.manual_seed(seed); np.random.seed(seed)
+        tb = loop.sample_index_table(4, 30)
+        for row in tb:
+            n = int((row[:, 0] < 30).sum())
+            assert 1 <= n <= 7 and (row[:n, 0] < 30).all() and (row[n:, 0] >= 30).all()
+            assert (np.diff(row[:n, 1]) > 0).all() and (row[:, 1] == row[:, 0] % 30).all()
+            assert ((row[:, 2] + row[:, 3]) <= 1).all() and ((row[:n, 2] + row[:n, 3]) == 1).all()
+
+
+def test_training_step_with_device_batch_preparation_equals_host_path(monkeypatch):
+    """Whole training steps, device-prepared vs host-prepared batches (LFVDM_DEVICE_BATCH_PREP=0), same seeds, eager
+    micro-steps (LFVDM_TRAIN_GRAPH=0 makes the noise draws identical): same losses, same parameters (up to the order
+    of the weight-gradient atomics)."""
+    from improved_diffusion.logger import logger
+    monkeypatch.setenv("LFVDM_TRAIN_GRAPH", "0")
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LFVDM_DEVICE_BATCH_PREP", mode)
+        cfg, sd, _ = load_case("micro")
+        model = build_native(cfg, sd).train()
+        loop = make_loop(model, lr=1e-3)
+        torch.manual_seed(4); np.random.seed(4)
+        losses = []
+        for _ in range(3):
+            loop.run_step()
+            loop._flush_loss_log()
+            losses.append(logger.name2val["loss"])
+            logger.dumpkvs()
+            loop.step += 1
+        outs[mode] = (losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone())
+    assert np.allclose(outs["1"][0], outs["0"][0], rtol=1e-4), (outs["1"][0], outs["0"][0])
+    assert float((outs["1"][1] - outs["0"][1]).abs().max()) < 1e-4
