@@ -241,11 +241,14 @@ def bench_train(rank, world, dev, steps, warmup):
     if world > 1:
         dist.barrier()
     th.cuda.synchronize()
+    loop.host_wait_s = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         loop.run_step()
         loop.step += 1
-    host = time.perf_counter() - t0          # host-side issue time (the GPU runs behind asynchronously)
+    host_wall = time.perf_counter() - t0     # host side of the loop: work + waiting for the GPU (it runs one step behind)
+    host_wait = loop.host_wait_s             # ... of which blocked on GPU events (staging-slot reuse, deferred loss log)
+    host = host_wall - host_wait
     th.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -265,6 +268,7 @@ def bench_train(rank, world, dev, steps, warmup):
     exposed = xch.collect_timing()[-steps:] if world > 1 else []
     out = {"optimizer_steps_per_s": round(steps / el, 3), "ms_per_step": round(1000.0 * el / steps, 2), "steps": steps,
            "host_issue_ms_per_step": round(1000.0 * host / steps, 2),
+           "host_wait_ms_per_step": round(1000.0 * host_wait / steps, 2),
            "global_batch": 2 * world, "videos_per_s": round(2 * world * steps / el, 2), "params": P,
            "allreduce_bytes_per_step": 4 * loop.arena.numel if world > 1 else 0, "last_loss": loss,
            "workload": "train: U-Net num_channels=128 num_res_blocks=1 max_frames=20 batch 2/GPU, AdamW+EMA, bucketed "

@@ -188,16 +188,19 @@ class TrainLoop:
     # ------------------------------------------------------------------ training-batch construction (host)
     def sample_some_indices(self, max_indices, T):
         """A random arithmetic-ish progression of <= max_indices frame indices in [0, T)
-        (reference train_util.py:180-191; same sequence of random draws)."""
+        (reference train_util.py:180-191; same sequence of random draws).  The reference evaluates
+        ``int(pos + i*scale)`` with ``pos`` a float32 0-dim tensor, element by element (~5 us of tensor dispatch each);
+        the same float32 arithmetic is done here on a numpy vector."""
         while True:
             s = int(th.randint(low=1, high=max_indices + 1, size=()))
             max_scale = T / (float(s) - 0.999)
             scale = np.exp(np.random.rand() * np.log(max_scale))
-            pos = th.rand(()) * (T - scale * (s - 1))      # float32 tensor arithmetic, as in the reference
-            indices = [int(pos + i * scale) for i in range(s)]
-            if all(0 <= i < T for i in indices):
-                return indices
-            print("warning: sampled invalid indices", indices, "trying again")
+            # th.rand(()) * python float: the scalar is rounded to float32, the product is a float32 product
+            pos = np.float32(th.rand(()).item()) * np.float32(T - scale * (s - 1))
+            indices = (pos + (np.arange(s) * scale).astype(np.float32)).astype(np.int64)     # float32 sums, truncated
+            if indices[0] >= 0 and indices[-1] < T and pos + np.float32(0.0) >= 0:
+                return indices.tolist()
+            print("warning: sampled invalid indices", indices.tolist(), "trying again")
 
     def _sample_masks_np(self, B, T):
         """Observed / latent frame flags (B, T) of one batch, at most ``max_frames`` flagged per video: the random

@@ -149,6 +149,70 @@ def test_mask_sampling_invariants():
     assert batch.shape[1] == int((obs + lat).view(B, -1).sum(1).max())
 
 
+def test_sample_some_indices_equals_the_reference_formula():
+    """The vectorised float32 evaluation in TrainLoop.sample_some_indices gives exactly the indices of the reference's
+    element-by-element ``int(pos + i*scale)`` with a float32 0-dim tensor ``pos`` (train_util.py:180-191)."""
+    def reference_formula(max_indices, T):
+        while True:
+            s = int(torch.randint(low=1, high=max_indices + 1, size=()))
+            max_scale = T / (float(s) - 0.999)
+            scale = np.exp(np.random.rand() * np.log(max_scale))
+            pos = torch.rand(()) * (T - scale * (s - 1))
+            indices = [int(pos + i * scale) for i in range(s)]
+            if all(0 <= i < T for i in indices):
+                return indices
+    loop = _loop_stub()
+    for N, T in ((20, 40), (20, 1000), (6, 30), (3, 7)):
+        torch.manual_seed(N + T); np.random.seed(N + T)
+        want = [reference_formula(N, T) for _ in range(1500)]
+        torch.manual_seed(N + T); np.random.seed(N + T)
+        got = [loop.sample_some_indices(N, T) for _ in range(1500)]
+        assert got == want
+
+
+def test_index_table_sampler_invariants_and_distribution():
+    """The index table of the device-side batch preparation (TrainLoop.sample_index_table): the same
+    invariants as the host sampler above, bit-identical batches from the same seed, and - from independent seeds - the
+    same distribution of the number of flagged frames over 10 000 draws (two-sample chi-square against the host sampler;
+    the two samplers run the same random process, so this guards refactors of either one)."""
+    loop = _loop_stub(max_frames=6)
+    B, T = 4, 30
+    batch1 = torch.arange(B * T, dtype=torch.float32).view(B, T, 1, 1, 1).expand(B, T, 1, 2, 2).contiguous()
+    batch2 = -batch1 - 1
+    pool = torch.cat([batch1, batch2], dim=1)
+    for seed in range(10):
+        torch.manual_seed(seed); np.random.seed(seed)
+        want = loop.sample_all_masks(batch1, batch2)
+        torch.manual_seed(seed); np.random.seed(seed)
+        tab = loop.sample_index_table(B, T)
+        assert tab.shape == (B, 6, 4) and tab.dtype == np.int32
+        got = torch.stack([pool[b][torch.from_numpy(tab[b, :, 0]).long()] for b in range(B)])
+        assert torch.equal(got, want[0]) and np.array_equal(tab[:, :, 1], want[1].numpy())
+        assert np.array_equal(tab[:, :, 2], want[2].view(B, -1).numpy()) and np.array_equal(tab[:, :, 3], want[3].view(B, -1).numpy())
+        for row in tab:
+            n = int((row[:, 0] < T).sum())
+            assert 1 <= n <= 6 and (row[:n, 0] < T).all() and (row[n:, 0] >= T).all()            # flagged first, then padding
+            assert (np.diff(row[:n, 1]) > 0).all() and ((row[:n, 2] + row[:n, 3]) == 1).all()    # sorted; obs xor latent
+            assert ((row[:, 2] + row[:, 3]) <= 1).all()
+    draws = 2500                      # x B = 10 000 videos per sampler
+    torch.manual_seed(1000); np.random.seed(1000)
+    h_table = np.zeros(7)
+    for _ in range(draws):
+        tab = loop.sample_index_table(B, T)
+        for row in tab:
+            h_table[int((row[:, 0] < T).sum())] += 1
+    torch.manual_seed(2000); np.random.seed(2000)
+    h_host = np.zeros(7)
+    for _ in range(draws):
+        _, obs_full, lat_full = loop.sample_all_masks(batch1, batch2, gather=False)
+        for k in (obs_full + lat_full).view(B, T).sum(1).long().tolist():
+            h_host[k] += 1
+    assert h_table.sum() == h_host.sum() == draws * B and h_table[0] == h_host[0] == 0
+    keep = (h_table + h_host) > 0
+    chi2 = float((((h_table - h_host) ** 2) / (h_table + h_host))[keep].sum())
+    assert chi2 < 27.9, (chi2, h_table, h_host)          # chi-square, 6 degrees of freedom, p = 1e-4
+
+
 def test_samplers_logger_rng_helpers():
     from improved_diffusion import resample, logger as lg, rng_util, train_util
     class D: num_timesteps = 50
