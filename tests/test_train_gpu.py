@@ -209,6 +209,7 @@ def test_training_step_with_device_batch_preparation_equals_host_path(monkeypatc
         model = build_native(cfg, sd).train()
         loop = make_loop(model, lr=1e-3)
         torch.manual_seed(4); np.random.seed(4)
+        logger.dumpkvs()                    # nothing left over from earlier loops in the running means
         losses = []
         for _ in range(3):
             loop.run_step()
