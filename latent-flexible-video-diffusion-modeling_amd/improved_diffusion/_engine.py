@@ -425,13 +425,68 @@ class Plan:
             nat.check(L.lfvdm_pack_conv_weight(_p(w), _p(out), w.shape[0], w.shape[1], w.shape[2], s), "pack")
         self._sig = self.weight_signature()
 
-    def launch(self):
-        """Enqueue the whole forward on the current stream (graph-capturable: no sync, no alloc)."""
-        s = nat.stream()
-        for fn, args in self.steps:
+    def launch(self, side=None, side_head=None, side_tail=None):
+        """Enqueue the whole forward (graph-capturable: no sync, no alloc).
+
+        Default: every launch on the current stream.  With ``side`` (a second stream; used by the captured sampler
+        step): the launches that depend on the timestep and frame indices only - the three embedding row-dot
+        launches and the grouped RPE networks, ~50 us of dependent latency at the head of the chain - run on ``side``
+        beside the first convolutions of the U-Net; the main chain waits for the FiLM rows in front of their first
+        consumer and for the R tensors in front of the first temporal attention.  ``side_head`` / ``side_tail``:
+        callables enqueued on the side stream before / after those launches (the sampler's clock tick and its
+        noise draw); the caller joins the side stream itself after ``side_tail``."""
+        if side is None:
+            s = nat.stream()
+            for fn, args in self.steps:
+                rc = fn(*args, s)
+                if rc:
+                    nat.check(rc, getattr(fn, "__name__", "kernel"))
+            return
+        L = nat.lib()
+        main = th.cuda.current_stream()
+        n_time = 0
+        while n_time < len(self.steps) and self.steps[n_time][0] in (L.lfvdm_rowdot, L.lfvdm_rpe_nets):
+            n_time += 1
+        n_emb = sum(1 for fn, _ in self.steps[:n_time] if fn is L.lfvdm_rowdot)
+        ev_film, ev_R = th.cuda.Event(), th.cuda.Event()
+        side.wait_stream(main)                       # fork
+        with th.cuda.stream(side):
+            ss = side.cuda_stream
+            if side_head is not None:
+                side_head()
+            for i, (fn, args) in enumerate(self.steps[:n_time]):
+                nat.check(fn(*args, ss), getattr(fn, "__name__", "kernel"))
+                if i == n_emb - 1:
+                    ev_film.record(side)
+            ev_R.record(side)
+            if side_tail is not None:
+                side_tail()
+        s = main.cuda_stream
+        film_ptrs = {t.data_ptr() for t in self.film.values()}
+        need_film, need_R = True, True
+        for fn, args in self.steps[n_time:]:
+            if need_film and self._reads_film(fn, args, film_ptrs):
+                main.wait_event(ev_film)
+                need_film = False
+            if need_R and fn is L.lfvdm_attn_temporal:
+                main.wait_event(ev_R)
+                need_R = False
             rc = fn(*args, s)
             if rc:
                 nat.check(rc, getattr(fn, "__name__", "kernel"))
+        if need_film:
+            main.wait_event(ev_film)
+        if need_R:
+            main.wait_event(ev_R)
+
+    @staticmethod
+    def _reads_film(fn, args, film_ptrs):
+        L = nat.lib()
+        if fn is L.lfvdm_gn_apply or fn is L.lfvdm_gn_coef:
+            return args[8] in film_ptrs
+        if fn is L.lfvdm_conv_igemm:
+            return (args[0]._obj.gn_film or 0) in film_ptrs
+        return False
 
     def set_inputs(self, x, x0, timesteps, frame_indices, obs_mask, latent_mask):
         B, T = self.B, self.T

@@ -466,14 +466,26 @@ class GraphSampler:
         self.pred = th.empty(self.shape, device=dev)
         self.graph = None
         self.expected_t = None
+        import os
+        # LFVDM_SAMPLER_FORK=0: the whole step as one linear chain (A/B aid)
+        self.side = th.cuda.Stream() if os.environ.get("LFVDM_SAMPLER_FORK", "1") != "0" else None
 
     def _step_body(self):
         pl, tb = self.plan, self.tb
-        # device-side clock: t <- max(t - 1, 0), model timestep <- table[t]  (t_buf holds "previous t")
-        nat.check(nat.lib().lfvdm_sampler_tick(self.t_buf.data_ptr(), self.ts_table.data_ptr(), pl.tin.data_ptr(), pl.B,
-                                               nat.stream()), "lfvdm_sampler_tick")
-        pl.launch()
-        self.noise.normal_()
+
+        def tick():     # device-side clock: t <- max(t - 1, 0), model timestep <- table[t]  (t_buf holds "previous t")
+            nat.check(nat.lib().lfvdm_sampler_tick(self.t_buf.data_ptr(), self.ts_table.data_ptr(), pl.tin.data_ptr(), pl.B,
+                                                   nat.stream()), "lfvdm_sampler_tick")
+
+        if self.side is not None:
+            # everything that does not depend on x_t - the clock, the timestep embeddings, the RPE networks and the
+            # noise draw - runs on a second branch of the captured step, beside the head of the U-Net chain
+            pl.launch(side=self.side, side_head=tick, side_tail=self.noise.normal_)
+            th.cuda.current_stream().wait_stream(self.side)      # join: the update needs t, the noise and eps
+        else:
+            tick()
+            pl.launch()
+            self.noise.normal_()
         nat.p_sample(pl.x_in, pl.out, self.noise, self.t_buf, tb["sqrt_recip_alphas_cumprod"],
                      tb["sqrt_recipm1_alphas_cumprod"], tb["posterior_mean_coef1"], tb["posterior_mean_coef2"],
                      tb["model_log_variance"], self.clip, pl.x_in, self.pred, None)
