@@ -448,7 +448,8 @@ template <int TMAX, int FC>
 __global__ __launch_bounds__(256)
 void attn_temporal_kernel(const float* __restrict__ qkv, const float* __restrict__ Rq, const float* __restrict__ Rk,
                           const float* __restrict__ Rv, const float* __restrict__ mask, float* __restrict__ o,
-                          float* __restrict__ attn_out, int T, int P, int C, int heads, int PPW) {
+                          float* __restrict__ attn_out, int T, int P, int C, int heads, int PPW,
+                          const int64_t* __restrict__ rsel) {
     using ST = TAStage<TMAX, FC>;
     constexpr int NQ = ST::NQ, RB = ST::RB;
     extern __shared__ __attribute__((aligned(16))) float ta_smem[];
@@ -470,8 +471,9 @@ void attn_temporal_kernel(const float* __restrict__ qkv, const float* __restrict
     const float scale = rsqrtf((float)F);
     const size_t ld = (size_t)3 * C;
     const float* qrow = qkv + ((size_t)(b * T + t) * P + p) * ld + h * F;   // dereferenced only if active
-    const float* Rbase[3] = {Rk + (size_t)b * T * T * C + h * F, Rq + (size_t)b * T * T * C + h * F,
-                             Rv + (size_t)b * T * T * C + h * F};
+    // rsel: the R tensors are tables over the sampler's timesteps ([n_t][B][T][T][C]); rsel[b] picks the slice
+    const size_t rb = rsel ? (size_t)rsel[b] * gridDim.z + b : (size_t)b;
+    const float* Rbase[3] = {Rk + rb * T * T * C + h * F, Rq + rb * T * T * C + h * F, Rv + rb * T * T * C + h * F};
 
     // per-thread staging slots: global offsets (without the chunk offset) and LDS offsets, computed once.
     // Slots past the end load from offset 0 (always valid) and are simply not committed: issue() is
@@ -645,7 +647,7 @@ void attn_temporal_kernel(const float* __restrict__ qkv, const float* __restrict
 
 template <int TMAX, int FC>
 int launch_temporal(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
-                    float* attn_out, int B, int T, int P, int C, int heads, hipStream_t s) {
+                    float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
     const int PPW = 64 / T;                                  // pixels per wave
     const int RST = T * FC + 4;
     const size_t lds = (size_t)(2 * T + 4 * PPW) * RST * sizeof(float);
@@ -654,18 +656,18 @@ int launch_temporal(const float* qkv, const float* Rq, const float* Rk, const fl
     if (int rc = limit.ensure(reinterpret_cast<const void*>(&attn_temporal_kernel<TMAX, FC>), lds)) return rc;
     const dim3 grid((unsigned)((P + 4 * PPW - 1) / (4 * PPW)), (unsigned)heads, (unsigned)B);
     hipLaunchKernelGGL((attn_temporal_kernel<TMAX, FC>), grid, dim3(256), lds, s, qkv, Rq, Rk, Rv, mask, o, attn_out, T, P, C,
-                       heads, PPW);
+                       heads, PPW, rsel);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
 
 template <int FC>
 int launch_temporal_t(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
-                      float* attn_out, int B, int T, int P, int C, int heads, hipStream_t s) {
-    if (T <= 8) return launch_temporal<8, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
-    if (T <= 16) return launch_temporal<16, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
-    if (T <= 24) return launch_temporal<24, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
-    return launch_temporal<32, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
+                      float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
+    if (T <= 8) return launch_temporal<8, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
+    if (T <= 16) return launch_temporal<16, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
+    if (T <= 24) return launch_temporal<24, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
+    return launch_temporal<32, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
 }
 
 }  // namespace
@@ -748,13 +750,19 @@ extern "C" int lfvdm_attn_spatial_bwd(const float* qkv, const float* o, const fl
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_attn_temporal(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,
-                                   float* o, float* attn_out, int B, int T, int P, int C, int heads, void* stream) {
+extern "C" int lfvdm_attn_temporal_sel(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,
+                                       float* o, float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel,
+                                       void* stream) {
     if (B <= 0 || T <= 0 || T > TA_MAXT || P <= 0 || heads <= 0 || C % heads) return LFVDM_E_SHAPE;
     if (!Rq || !Rk || !Rv) return LFVDM_E_SHAPE;
     const int F = C / heads;
     hipStream_t s = (hipStream_t)stream;
-    if (F % 16 == 0 && T <= 24) return launch_temporal_t<16>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
-    if (F % 8 == 0) return launch_temporal_t<8>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, s);
+    if (F % 16 == 0 && T <= 24) return launch_temporal_t<16>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
+    if (F % 8 == 0) return launch_temporal_t<8>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     return LFVDM_E_UNSUPPORTED;
+}
+
+extern "C" int lfvdm_attn_temporal(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,
+                                   float* o, float* attn_out, int B, int T, int P, int C, int heads, void* stream) {
+    return lfvdm_attn_temporal_sel(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, nullptr, stream);
 }

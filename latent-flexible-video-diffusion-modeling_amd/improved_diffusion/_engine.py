@@ -37,7 +37,13 @@ GN_EPILOGUE = os.environ.get("LFVDM_GN_EPILOGUE", "1") != "0"
 class Plan:
     """Launch sequence + workspaces for one (B, T, H, W)."""
 
-    def __init__(self, engine, B, T, H, W, want_attn):
+    def __init__(self, engine, B, T, H, W, want_attn, time_steps=None):
+        # time_steps = n: the plan belongs to a sampler that walks a known schedule of n timesteps.  Everything the
+        # network derives from (t, frame_indices) alone is then TABULATED once per chain (build_time_tables /
+        # build_R_tables, same kernels on a virtual batch of n*B rows) and the per-step embedding / RPE launches leave
+        # the denoising step: the step's clock kernel fetches the FiLM rows of its timestep, the temporal attention reads
+        # its R slices straight from the tables (lfvdm_attn_temporal_sel).
+        self.time_steps = int(time_steps) if time_steps else 0
         self.engine = engine
         self.model = engine.model
         self.B, self.T, self.H, self.W = B, T, H, W
@@ -68,7 +74,7 @@ class Plan:
         out = self.scratch(key, N * P, C0 + C1)
         self.add(nat.lib().lfvdm_gn_apply, _p(a), _p(b) if b is not None else None, C0, C1, N, P, _p(gn.weight), _p(gn.bias),
                  _p(film) if film is not None else None, self.T if film is not None else 1,
-                 2 * (C0 + C1) if film is not None else 0, gn.eps, act, _p(out), None, None, None)
+                 self.rows_ld if film is not None else 0, gn.eps, act, _p(out), None, None, None)
         return out
 
     def packed(self, weight):
@@ -123,7 +129,7 @@ class Plan:
             gn, film = kw["gn"], g("gn_film")
             a.gn_gamma, a.gn_beta, a.gn_out = _p(gn.weight), _p(gn.bias), _p(kw["gn_out"])
             a.gn_film = _p(film) if film is not None else None
-            a.gn_film_ld = 2 * kw["Cout"] if film is not None else 0
+            a.gn_film_ld = self.rows_ld if film is not None else 0
             a.gn_film_div = self.T if film is not None else 1
             a.gn_act, a.gn_skip_raw, a.gn_eps = g("gn_act", nat.ACT_NONE), int(g("gn_skip_raw", 0)), gn.eps
         # shared split-K workspace (launches are stream-ordered, so one buffer serves every conv of the plan)
@@ -161,64 +167,98 @@ class Plan:
         self.tin.zero_()
         self.tin[self.Bpad:] = timestep_freqs(ch).to(self.dev)
 
-        # ---- embeddings: 3 row-dot launches for the whole network
+        # ---- embeddings: 3 row-dot launches for the whole network.  All FiLM rows (then all RPE time projections)
+        # live in ONE [B][rows_ld] buffer, so that a sampler can fetch a timestep's FiLM rows with one copy.
+        from .unet import ResBlock, FactorizedAttentionBlock
         e0, self.emb = self.buf(B, ted), self.buf(B, ted)
         te0, te2 = m.time_embed[0], m.time_embed[2]
-
-        def rjob(lin, inp, out, K, ldin, mode, row0):
-            O = lin.weight.shape[0]
-            return nat.RowdotJob(_p(lin.weight), _p(lin.bias), _p(inp), _p(out), K, O, B, ldin, O, mode, row0, 0)
-
-        j0 = nat.jobs_to_device([rjob(te0, self.tin, e0, ch, self.Bpad, 2, 0)], self.dev)
-        j1 = nat.jobs_to_device([rjob(te2, e0, self.emb, ted, ted, 1, 0)], self.dev)
-        self.keep += [j0, j1]
-        self.add(L.lfvdm_rowdot, _p(j0), 1, ted)
-        self.add(L.lfvdm_rowdot, _p(j1), 1, ted)
-
-        from .unet import ResBlock, FactorizedAttentionBlock
-        jobs, row0 = [], 0
-        self.film = {}
-        self.tproj = {}
+        heads = []       # (key, linear, in_mode): FiLM projections first, RPE time projections after them
         for mod in m.modules():
             if isinstance(mod, ResBlock):
-                lin = mod.emb_layers[1]
-                out = self.buf(B, lin.weight.shape[0])
-                self.film[mod] = out
-                jobs.append(rjob(lin, self.emb, out, ted, ted, 1, row0))
-                row0 += lin.weight.shape[0]
-            elif isinstance(mod, FactorizedAttentionBlock):
-                ta = mod.temporal_attention
-                for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v):
-                    lin = r.rpe_net.embed_diffusion_time
-                    out = self.buf(B, lin.weight.shape[0])
-                    self.tproj[r] = out
-                    jobs.append(rjob(lin, self.emb, out, ted, ted, 0, row0))
-                    row0 += lin.weight.shape[0]
-        jg = nat.jobs_to_device(jobs, self.dev)
-        self.keep.append(jg)
-        self.add(L.lfvdm_rowdot, _p(jg), len(jobs), row0)
-
-        # ---- all RPE networks in one launch
-        rjobs, tile0 = [], 0
-        self.R = {}
-        tiles_per = (B * T * T + 31) // 32
+                heads.append((mod, mod.emb_layers[1], 1))
+        self.film_floats = sum(lin.weight.shape[0] for _, lin, _ in heads)
         for mod in m.modules():
             if isinstance(mod, FactorizedAttentionBlock):
                 ta = mod.temporal_attention
                 for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v):
-                    net = r.rpe_net
-                    Cc = net.channels
-                    if Cc > 512:
-                        raise RuntimeError("RPE nets support at most 512 channels natively")
-                    Rb = self.buf(B, T, T, Cc)
-                    self.R[r] = Rb
-                    rjobs.append(nat.RpeJob(_p(self.tproj[r]), _p(net.embed_distances.weight), _p(net.embed_distances.bias),
-                                            _p(net.out.weight), _p(net.out.bias), _p(Rb), Cc, tile0, Cc, 0, None))
-                    tile0 += tiles_per
-        if rjobs:
-            jr = nat.jobs_to_device(rjobs, self.dev)
-            self.keep.append(jr)
-            self.add(L.lfvdm_rpe_nets, _p(jr), len(rjobs), tile0, _p(self.fi), B, T)
+                    heads.append((r, r.rpe_net.embed_diffusion_time, 0))
+        self.rows_ld = sum(lin.weight.shape[0] for _, lin, _ in heads)
+        assert self.film_floats % 4 == 0 and self.rows_ld % 4 == 0
+        self.rows = self.buf(B, self.rows_ld)
+        self.film, self.tproj, self.row_off = {}, {}, {}
+        off = 0
+        for key, lin, mode in heads:
+            O = lin.weight.shape[0]
+            (self.film if mode == 1 else self.tproj)[key] = self.rows[:, off:off + O]
+            self.row_off[key] = off
+            off += O
+        self._heads = heads
+
+        def emb_jobs(M, tin, ldin, e0_, emb_, rows_):
+            """Device job tables of the three launches for M batch rows: sinusoid + Linear, SiLU + Linear, all heads."""
+            j0 = [nat.RowdotJob(_p(te0.weight), _p(te0.bias), _p(tin), _p(e0_), ch, ted, M, ldin, ted, 2, 0, 0)]
+            j1 = [nat.RowdotJob(_p(te2.weight), _p(te2.bias), _p(e0_), _p(emb_), ted, ted, M, ted, ted, 1, 0, 0)]
+            jg, row0 = [], 0
+            for key, lin, mode in heads:
+                O = lin.weight.shape[0]
+                jg.append(nat.RowdotJob(_p(lin.weight), _p(lin.bias), _p(emb_), _p(rows_) + 4 * self.row_off[key], ted, O, M, ted,
+                                        self.rows_ld, mode, row0, 0))
+                row0 += O
+            return [nat.jobs_to_device(j, self.dev) for j in (j0, j1, jg)], len(jg), row0
+
+        self._emb_jobs = emb_jobs
+
+        def rpe_jobs(Bn, tproj_base, R_of):
+            """Job table of the grouped RPE-network launch for Bn batch rows (R_of: rpe module -> output tensor)."""
+            jobs, tile0 = [], 0
+            tiles_per = (Bn * T * T + 31) // 32
+            for mod in m.modules():
+                if isinstance(mod, FactorizedAttentionBlock):
+                    ta = mod.temporal_attention
+                    for r in (ta.rpe_q, ta.rpe_k, ta.rpe_v):
+                        net = r.rpe_net
+                        jobs.append(nat.RpeJob(_p(tproj_base) + 4 * self.row_off[r], _p(net.embed_distances.weight),
+                                               _p(net.embed_distances.bias), _p(net.out.weight), _p(net.out.bias), _p(R_of[r]),
+                                               net.channels, tile0, self.rows_ld, 0, None))
+                        tile0 += tiles_per
+            return (nat.jobs_to_device(jobs, self.dev) if jobs else None), len(jobs), tile0
+
+        self._rpe_jobs = rpe_jobs
+        rpe_mods = [r for mod in m.modules() if isinstance(mod, FactorizedAttentionBlock)
+                    for r in (mod.temporal_attention.rpe_q, mod.temporal_attention.rpe_k, mod.temporal_attention.rpe_v)]
+        for r in rpe_mods:
+            if r.rpe_net.channels > 512:
+                raise RuntimeError("RPE nets support at most 512 channels natively")
+
+        # ---- timestep tables (sampler plans): decide now, the launch sequence differs
+        self.t_sel = None
+        if self.time_steps:
+            Bv = self.time_steps * B
+            table_bytes = 4 * Bv * (self.rows_ld + T * T * sum(r.rpe_net.channels for r in rpe_mods))
+            budget = float(os.environ.get("LFVDM_TIME_TABLE_GB", "24")) * 2 ** 30
+            if os.environ.get("LFVDM_TIME_TABLES", "1") == "0" or table_bytes > budget or B > 64:
+                self.time_steps = 0
+        self.R = {}
+        if self.time_steps:
+            Bv = self.time_steps * B
+            self.t_sel = self.buf(B, dtype=th.int64).zero_()          # the sampler's device-side step counter
+            self.rows_all = self.buf(Bv, self.rows_ld)
+            for r in rpe_mods:
+                self.R[r] = self.buf(Bv, T, T, r.rpe_net.channels)     # [n_t][B][T][T][C]
+            self.tables_sig = None
+        else:
+            (j0, j1, jg), n_g, rows_g = emb_jobs(B, self.tin, self.Bpad, e0, self.emb, self.rows)
+            self.keep += [j0, j1, jg]
+            self.add(L.lfvdm_rowdot, _p(j0), 1, ted)
+            self.add(L.lfvdm_rowdot, _p(j1), 1, ted)
+            self.add(L.lfvdm_rowdot, _p(jg), n_g, rows_g)
+            # ---- all RPE networks in one launch
+            for r in rpe_mods:
+                self.R[r] = self.buf(B, T, T, r.rpe_net.channels)
+            jr, n_r, tiles_r = rpe_jobs(B, self.rows, self.R)
+            if jr is not None:
+                self.keep.append(jr)
+                self.add(L.lfvdm_rpe_nets, _p(jr), n_r, tiles_r, _p(self.fi), B, T)
 
         # ---- scratch shared by all blocks (forward-only plan)
         maxC = max(mod.channels for mod in m.modules() if isinstance(mod, FactorizedAttentionBlock))
@@ -297,7 +337,7 @@ class Plan:
                      _p(self.s_cA), _p(self.s_cB))
             self.add_conv(src0=a, src1=b, C0=C0, C1=C1, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA, coefB=self.s_cB,
                           act=nat.ACT_SILU, W=self.packed(conv1.weight), bias=conv1.bias, Cout=Cout, out=h1, ldo=Cout)
-            self.add(L.lfvdm_gn_coef, _p(h1), None, Cout, 0, N, P, _p(gn2.weight), _p(gn2.bias), _p(film), self.T, 2 * Cout,
+            self.add(L.lfvdm_gn_coef, _p(h1), None, Cout, 0, N, P, _p(gn2.weight), _p(gn2.bias), _p(film), self.T, self.rows_ld,
                      gn2.eps, _p(self.s_cA2), _p(self.s_cB2))
             kw = dict(src0=h1, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA2, coefB=self.s_cB2, act=nat.ACT_SILU,
                       W=self.packed(conv2.weight), bias=conv2.bias, Cout=Cout, out=out, ldo=Cout)
@@ -341,8 +381,12 @@ class Plan:
         if self.want_attn:
             at = self.buf(B * P, heads, T, T)
             self.attn_t.append(at)
-        self.add(L.lfvdm_attn_temporal, _p(self.s_qkv), _p(self.R[ta.rpe_q]), _p(self.R[ta.rpe_k]), _p(self.R[ta.rpe_v]),
-                 _p(self.mask), _p(self.s_o), _p(at) if at is not None else None, B, T, P, Cc, heads)
+        if self.time_steps:     # R tensors are tables over the chain's timesteps: slice t_sel[b]
+            self.add(L.lfvdm_attn_temporal_sel, _p(self.s_qkv), _p(self.R[ta.rpe_q]), _p(self.R[ta.rpe_k]), _p(self.R[ta.rpe_v]),
+                     _p(self.mask), _p(self.s_o), _p(at) if at is not None else None, B, T, P, Cc, heads, _p(self.t_sel))
+        else:
+            self.add(L.lfvdm_attn_temporal, _p(self.s_qkv), _p(self.R[ta.rpe_q]), _p(self.R[ta.rpe_k]), _p(self.R[ta.rpe_v]),
+                     _p(self.mask), _p(self.s_o), _p(at) if at is not None else None, B, T, P, Cc, heads)
         yt = self.buf(M, Cc)
         proj = dict(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.proj_out.weight,
                     bias=ta.proj_out.bias, Cout=Cc, res=self.s_xn, ldr=Cc, out=yt, ldo=Cc)
@@ -389,6 +433,50 @@ class Plan:
         self.add_conv(src0=x, C0=Cc, N=N, Hs=H, Ws=W, up=0 if down else 1, stride=2 if down else 1, Ho=Ho, Wo=Wo,
                       W=self.packed(conv.weight), bias=conv.bias, Cout=Cc, out=out, ldo=Cc)
         return dict(parts=[(out, Cc)], H=Ho, W=Wo)
+
+    # ------------------------------------------------------------------ timestep tables (sampler plans)
+    def build_time_tables(self, ts_table):
+        """FiLM rows and RPE time projections of EVERY timestep of the chain: the three embedding launches of the
+        per-step plan on a virtual batch of n_t*B rows, row (i, b) <- model timestep ts_table[i].  Bitwise the values the
+        per-step launches produce (each output row depends on its own input row only)."""
+        L, m = nat.lib(), self.model
+        n_t, B = self.time_steps, self.B
+        assert ts_table.numel() == n_t
+        Bv, ch = n_t * B, m.model_channels
+        ted, half = 4 * ch, ch // 2
+        Bvp = (Bv + 3) // 4 * 4
+        tin = th.zeros(Bvp + half, device=self.dev, dtype=th.float32)
+        tin[:Bv] = ts_table.to(self.dev, th.float32).repeat_interleave(B)
+        tin[Bvp:] = timestep_freqs(ch).to(self.dev)
+        e0, emb = th.empty(Bv, ted, device=self.dev), th.empty(Bv, ted, device=self.dev)
+        (j0, j1, jg), n_g, rows_g = self._emb_jobs(Bv, tin, Bvp, e0, emb, self.rows_all)
+        s = nat.stream()
+        nat.check(L.lfvdm_rowdot(_p(j0), 1, ted, s), "lfvdm_rowdot")
+        nat.check(L.lfvdm_rowdot(_p(j1), 1, ted, s), "lfvdm_rowdot")
+        nat.check(L.lfvdm_rowdot(_p(jg), n_g, rows_g, s), "lfvdm_rowdot")
+        th.cuda.current_stream().synchronize()      # the temporaries and job tables above die with this frame
+        self.tables_sig = (self.weight_signature(), tuple(ts_table.tolist()))       # (compared by GraphSampler.begin)
+
+    def build_R_tables(self, frame_indices):
+        """R_q / R_k / R_v of every temporal attention for every timestep of the chain (they depend on the timestep and
+        on this window's frame indices): the grouped RPE launch on the virtual batch."""
+        if not self.R:
+            return
+        n_t, B, T = self.time_steps, self.B, self.T
+        fi = frame_indices.to(self.dev, th.int64).reshape(B, T).repeat(n_t, 1).contiguous()
+        jr, n_r, tiles_r = self._rpe_jobs(n_t * B, self.rows_all, self.R)
+        nat.check(nat.lib().lfvdm_rpe_nets(_p(jr), n_r, tiles_r, _p(fi), n_t * B, T, nat.stream()), "lfvdm_rpe_nets")
+        th.cuda.current_stream().synchronize()
+
+    def tick(self, t_buf, ts_table):
+        """The sampler's clock (t <- max(t-1, 0); model timestep <- table[t]); with timestep tables it also fetches
+        the FiLM rows of the new t."""
+        L = nat.lib()
+        if self.time_steps:
+            nat.check(L.lfvdm_sampler_tick_fetch(_p(t_buf), _p(ts_table), _p(self.tin), self.B, _p(self.rows_all), self.rows_ld,
+                                                 _p(self.rows), self.film_floats, nat.stream()), "lfvdm_sampler_tick_fetch")
+        else:
+            nat.check(L.lfvdm_sampler_tick(_p(t_buf), _p(ts_table), _p(self.tin), self.B, nat.stream()), "lfvdm_sampler_tick")
 
     # ------------------------------------------------------------------ autotune
     def autotune(self, rounds=3, reps=6):

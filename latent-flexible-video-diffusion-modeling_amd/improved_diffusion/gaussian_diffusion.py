@@ -456,26 +456,30 @@ class GraphSampler:
         # a private plan: the sampler's state lives in its static buffers, so it must not be shared
         # with eager model() calls on the same shape
         self.engine = unet.native_engine()
-        self.plan = Plan(self.engine, B, T, H, W, False)
+        # the chain walks a known schedule: everything that depends on (t, frame_indices) alone is tabulated once per
+        # chain (Plan.build_time_tables / build_R_tables) instead of being recomputed by four launches in every step
+        self.plan = Plan(self.engine, B, T, H, W, False, time_steps=diffusion.num_timesteps)
         self.plan.refresh_weights()
         dev = self.plan.dev
         self.tb = diffusion.tables(dev)
         self.ts_table = diffusion.model_timestep_table(dev)
-        self.t_buf = th.zeros(B, dtype=th.int64, device=dev)
+        self.t_buf = self.plan.t_sel if self.plan.time_steps else th.zeros(B, dtype=th.int64, device=dev)
+        self.table_build_ms = 0.0      # time spent building the tables in the last begin()
+        self._ts_key = tuple(self.ts_table.tolist())
         self.noise = th.empty(self.shape, device=dev)
         self.pred = th.empty(self.shape, device=dev)
         self.graph = None
         self.expected_t = None
         import os
-        # LFVDM_SAMPLER_FORK=0: the whole step as one linear chain (A/B aid)
-        self.side = th.cuda.Stream() if os.environ.get("LFVDM_SAMPLER_FORK", "1") != "0" else None
+        # LFVDM_SAMPLER_FORK=1: timestep-only launches on a second branch of the captured step.  Measured SLOWER on MI355X
+        # (1.362 vs 1.290 ms per step at cfg B: each cross-branch edge of a hipGraph costs ~20 us), so the step stays one chain
+        self.side = th.cuda.Stream() if os.environ.get("LFVDM_SAMPLER_FORK", "0") == "1" else None
 
     def _step_body(self):
         pl, tb = self.plan, self.tb
 
-        def tick():     # device-side clock: t <- max(t - 1, 0), model timestep <- table[t]  (t_buf holds "previous t")
-            nat.check(nat.lib().lfvdm_sampler_tick(self.t_buf.data_ptr(), self.ts_table.data_ptr(), pl.tin.data_ptr(), pl.B,
-                                                   nat.stream()), "lfvdm_sampler_tick")
+        def tick():     # device-side clock: t <- max(t - 1, 0), model timestep <- table[t]  (t_buf holds "previous t");
+            pl.tick(self.t_buf, self.ts_table)      # with timestep tables it also fetches the FiLM rows of the new t
 
         if self.side is not None:
             # everything that does not depend on x_t - the clock, the timestep embeddings, the RPE networks and the
@@ -498,6 +502,17 @@ class GraphSampler:
         with th.no_grad():
             pl.set_inputs(img, model_kwargs["x0"], th.zeros(B, device=pl.dev), model_kwargs["frame_indices"],
                           model_kwargs["obs_mask"], model_kwargs["latent_mask"])
+            if pl.time_steps:
+                e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+                e0.record()
+                if pl.tables_sig != (pl.weight_signature(), self._ts_key):
+                    pl.build_time_tables(self.ts_table)          # once per set of weights
+                pl.build_R_tables(model_kwargs["frame_indices"])  # once per chain: R depends on this window's frames
+                e1.record()
+                e1.synchronize()
+                self.table_build_ms = e0.elapsed_time(e1)
+                self.t_buf.fill_(self.diffusion.num_timesteps)
+                pl.tick(self.t_buf, self.ts_table)               # valid FiLM rows for the tuning / warm-up launches
             if self.graph is None:
                 import os
                 # building the graph draws warm-up noise: keep the caller's RNG stream untouched, so that a

@@ -160,3 +160,33 @@ def test_latent_space_loop_returns_denormalised_latents():
     dec, _ = diff.p_sample_loop(model, tuple(inp["x"].shape), model_kwargs=mk, return_decoded=True)
     want = raw * st["std"].view(1, 1, 4, 1, 1).cuda() + st["mean"].view(1, 1, 4, 1, 1).cuda()
     assert torch.equal(dec, want)
+
+
+def test_timestep_tables_give_bitwise_the_per_step_result(monkeypatch):
+    """The sampler tabulates everything that depends on (t, frame_indices) alone once per chain (FiLM rows, R_q/R_k/R_v)
+    and drops the four per-step launches that computed it.  Same kernels on a virtual batch, row-independent arithmetic:
+    the samples must be BITWISE those of the per-step plan (LFVDM_TIME_TABLES=0), also for per-sample different t."""
+    cfg, sd, inp = load_case("micro")
+    d = {k: v.cuda() for k, v in inp.items()}
+    mk = dict(frame_indices=d["frame_indices"], obs_mask=d["obs_mask"], latent_mask=d["latent_mask"], x0=d["x0"])
+    shape = tuple(inp["x"].shape)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LFVDM_TIME_TABLES", mode)
+        monkeypatch.setenv("LFVDM_AUTOTUNE", "0")          # same tile shapes in both runs
+        model = build_native(cfg, sd)
+        diff = make_diffusion(1000, "25")
+        torch.manual_seed(7)
+        a, _ = diff.p_sample_loop(model, shape, clip_denoised=True, model_kwargs=mk, return_decoded=False)
+        s = diff._graph_sampler(model, shape, True)
+        assert bool(s.plan.time_steps) == (mode == "1")
+        if mode == "1":
+            assert s.table_build_ms > 0 and len(s.plan.steps) < 200
+        # arbitrary order / per-sample different t through the step API
+        s.begin(d["x"].clone(), mk)
+        s.t_buf.copy_(torch.tensor([8, 21], device="cuda"))      # next step: t = (7, 20)
+        s.expected_t = 7
+        b = s.step(7)["sample"].clone()
+        outs[mode] = (a, b, len(s.plan.steps))
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    assert outs["0"][2] - outs["1"][2] == 4, "three embedding launches and the RPE launch leave the step"
