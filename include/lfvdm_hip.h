@@ -392,12 +392,13 @@ int lfvdm_p_sample(const float* x, const float* eps, const float* noise, const i
  * gaussian_diffusion.py:509-512 and _WrappedModel's timestep map, respace.py:117-122, kept on the device):
  * t[b] <- max(t[b] - 1, 0);  model_t[b] <- model_timestep_table[t[b]]. */
 int lfvdm_sampler_tick(int64_t* t, const float* model_timestep_table, float* model_t, int B, void* stream);
-/* The same clock, plus: rows[b][0:row_floats] <- rows_all[(t[b]*B + b) * rows_all_ld + 0:row_floats] (multiples of 4; B <= 64).
+/* The same clock, plus: rows[b*rows_ld + 0:row_floats] <- rows_all[(t[b]*B + b)*rows_ld + 0:row_floats] (multiples of 4;
+ * B <= 64; both buffers have rows of rows_ld floats).
  * rows_all is a table over all timesteps of the chain of everything the network derives from the timestep alone
  * (time-embedding MLP -> FiLM rows of every ResBlock, unet.py:303-308,157-163,199-203), built once per chain by the
  * per-step kernels on a virtual batch; the per-step embedding launches disappear from the denoising step. */
 int lfvdm_sampler_tick_fetch(int64_t* t, const float* model_timestep_table, float* model_t, int B, const float* rows_all,
-                             int rows_all_ld, float* rows, int row_floats, void* stream);
+                             int rows_ld, float* rows, int row_floats, void* stream);
 /* masked mean of squared error, :787-788 + nn.py:86-92: out[b] = mean_inner((a-b)^2 * mask[b,frame]).
  * mask is (B, T) (broadcast over the per-frame block of `frame_inner` elements) or NULL. */
 int lfvdm_masked_mse(const float* a, const float* b, const float* mask, float* out, int B, int T,

@@ -97,7 +97,7 @@ __global__ void sampler_tick_kernel(int64_t* __restrict__ t, const float* __rest
 // embedding launches (the table is built once per chain with the very same kernels, _engine.Plan.build_time_tables)
 __global__ __launch_bounds__(1024) void sampler_tick_fetch_kernel(int64_t* __restrict__ t, const float* __restrict__ table,
                                                                   float* __restrict__ model_t, int B,
-                                                                  const float* __restrict__ rows_all, int rows_all_ld,
+                                                                  const float* __restrict__ rows_all, int rows_ld,
                                                                   float* __restrict__ rows, int row_floats) {
     __shared__ int64_t tnew[64];
     if ((int)threadIdx.x < B) {
@@ -111,19 +111,19 @@ __global__ __launch_bounds__(1024) void sampler_tick_fetch_kernel(int64_t* __res
     const int q4 = row_floats >> 2;
     for (int e = threadIdx.x; e < B * q4; e += 1024) {
         const int b = e / q4, i = e - b * q4;
-        const float* src = rows_all + ((size_t)tnew[b] * B + b) * rows_all_ld;
-        st4(rows + (size_t)b * row_floats + 4 * i, ld4(src + 4 * i));
+        const float* src = rows_all + ((size_t)tnew[b] * B + b) * rows_ld;      // both buffers have rows of rows_ld floats,
+        st4(rows + (size_t)b * rows_ld + 4 * i, ld4(src + 4 * i));              // of which the first row_floats are fetched
     }
 }
 
 }  // namespace
 
 extern "C" int lfvdm_sampler_tick_fetch(int64_t* t, const float* model_timestep_table, float* model_t, int B,
-                                        const float* rows_all, int rows_all_ld, float* rows, int row_floats, void* stream) {
+                                        const float* rows_all, int rows_ld, float* rows, int row_floats, void* stream) {
     if (B <= 0 || B > 64 || !t || !model_timestep_table || !model_t || !rows_all || !rows) return LFVDM_E_SHAPE;
-    if (row_floats <= 0 || (row_floats & 3) || (rows_all_ld & 3) || rows_all_ld < row_floats) return LFVDM_E_SHAPE;
+    if (row_floats <= 0 || (row_floats & 3) || (rows_ld & 3) || rows_ld < row_floats) return LFVDM_E_SHAPE;
     hipLaunchKernelGGL(sampler_tick_fetch_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, t, model_timestep_table, model_t, B,
-                       rows_all, rows_all_ld, rows, row_floats);
+                       rows_all, rows_ld, rows, row_floats);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
