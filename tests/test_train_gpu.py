@@ -219,4 +219,9 @@ def test_training_step_with_device_batch_preparation_equals_host_path(monkeypatc
             loop.step += 1
         outs[mode] = (losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone())
     assert np.allclose(outs["1"][0], outs["0"][0], rtol=1e-4), (outs["1"][0], outs["0"][0])
-    assert float((outs["1"][1] - outs["0"][1]).abs().max()) < 1e-4
+    # Adam moves every element by ~lr per step whatever the size of its gradient: where a gradient is pure rounding noise
+    # (analytically zero), the order of the weight-gradient atomics decides its sign, so single elements may differ by up
+    # to 2*lr per step; everything else agrees to fp32 accuracy
+    diff = (outs["1"][1] - outs["0"][1]).abs()
+    assert float(diff.max()) <= 2 * 1e-3 * 3 + 1e-6
+    assert float((diff > 1e-5).float().mean()) < 2e-3, float((diff > 1e-5).float().mean())
