@@ -750,6 +750,9 @@ extern "C" int lfvdm_attn_spatial_bwd(const float* qkv, const float* o, const fl
     return LFVDM_OK;
 }
 
+int lfvdm_attn_temporal2_try(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
+                             float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s);
+
 extern "C" int lfvdm_attn_temporal_sel(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,
                                        float* o, float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel,
                                        void* stream) {
@@ -757,6 +760,19 @@ extern "C" int lfvdm_attn_temporal_sel(const float* qkv, const float* Rq, const 
     if (!Rq || !Rk || !Rv) return LFVDM_E_SHAPE;
     const int F = C / heads;
     hipStream_t s = (hipStream_t)stream;
+    // second-generation kernel (attention_temporal2.hip) for head dims 8 / 16 / 32; LFVDM_ATTN_V1 forces the first one
+    static const bool force_v1 = getenv("LFVDM_ATTN_V1") != nullptr;      // A/B aid
+    if (!force_v1) {
+        const int rc = lfvdm_attn_temporal2_try(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
+        if (rc != LFVDM_E_UNSUPPORTED) return rc;
+    }
+    // head dim 32 (the 128-channel levels): the whole head in ONE chunk - two staging phases instead of four.  The R
+    // slices of a chunk are then 2 x T x (32T + 4) floats: fits the 160 KiB of LDS up to T = 24 (launch_temporal checks)
+    static const bool no_fc32 = getenv("LFVDM_ATTN_NO_FC32") != nullptr;      // A/B aid
+    if (F == 32 && T <= 24 && !no_fc32) {
+        const int rc = launch_temporal_t<32>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
+        if (rc != LFVDM_E_UNSUPPORTED) return rc;
+    }
     if (F % 16 == 0 && T <= 24) return launch_temporal_t<16>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (F % 8 == 0) return launch_temporal_t<8>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     return LFVDM_E_UNSUPPORTED;

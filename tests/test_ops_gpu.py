@@ -354,6 +354,41 @@ def test_attn_temporal_backward(nat, B, T, P, Cc, heads):
         assert err <= 3e-5 * (1.0 + float(want.abs().max())) + 3e-5, (name, err, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("B,T,P,Cc,heads", [(2, 20, 256, 64, 4), (2, 20, 64, 128, 4), (2, 20, 4, 128, 4), (1, 14, 256, 64, 4),
+                                                   (1, 20, 33, 64, 4), (2, 17, 61, 32, 4), (3, 9, 130, 64, 2), (1, 32, 70, 128, 4),
+                                                   (2, 6, 300, 32, 2), (1, 20, 256, 128, 4)])
+def test_attn_temporal_second_generation_kernel(nat, B, T, P, Cc, heads):
+    """attention_temporal2.hip (LDS-DMA staged, frame groups, XCD-aware map; head dims 8 / 16 / 32) at the network's
+    real map sizes and at ragged ones - partial strips, partial frame groups, batch 3 (plain block map) - vs the fp64
+    core; attention probabilities as well; and with the R tensors given as timestep tables (rsel)."""
+    M = B * T * P
+    qkv = rnd("t2/qkv", M, 3 * Cc)
+    Rs = [0.3 * rnd(f"t2/R{i}", B, T, T, Cc) for i in range(3)]
+    mask = (torch.from_numpy(recipe.uniform_pm1("t2/mask", B * T)).view(B, T) > 0).float()
+    ref = _temporal_core_f64(qkv.double(), Rs[0].double(), Rs[1].double(), Rs[2].double(), mask.double(), B, T, P, Cc, heads).float()
+    g = [t.cuda().contiguous() for t in (qkv, *Rs, mask)]
+    o = torch.full((M, Cc), float("nan"), device="cuda")
+    attn = torch.full((B * P, heads, T, T), float("nan"), device="cuda")
+    nat.attn_temporal(g[0], g[1], g[2], g[3], g[4], o, attn, B, T, P, Cc, heads)
+    close(o, ref, 5e-5)
+    assert bool(torch.isfinite(attn).all()) and float((attn.sum(-1) - 1).abs().max()) < 1e-5
+    o2 = torch.full((M, Cc), float("nan"), device="cuda")
+    nat.attn_temporal(g[0], g[1], g[2], g[3], None, o2, None, B, T, P, Cc, heads)          # no mask
+    ref2 = _temporal_core_f64(qkv.double(), Rs[0].double(), Rs[1].double(), Rs[2].double(), torch.ones(B, T).double(), B, T, P, Cc, heads)
+    close(o2, ref2.float(), 5e-5)
+    # R as tables over 3 timesteps [3][B][T][T][C]: slice rsel[b] per batch element
+    n_t = 3
+    tabs = [torch.stack([(0.5 + 0.25 * i) * r for i in range(n_t)]).cuda().contiguous() for r in Rs]
+    sel = torch.tensor([(2 * b + 1) % n_t for b in range(B)], dtype=torch.int64, device="cuda")
+    o3 = torch.full((M, Cc), float("nan"), device="cuda")
+    nat.check(nat.lib().lfvdm_attn_temporal_sel(g[0].data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(),
+                                                g[4].data_ptr(), o3.data_ptr(), None, B, T, P, Cc, heads, sel.data_ptr(),
+                                                nat.stream()), "lfvdm_attn_temporal_sel")
+    picked = [torch.stack([(0.5 + 0.25 * int(sel[b])) * r[b] for b in range(B)]) for r in Rs]
+    ref3 = _temporal_core_f64(qkv.double(), picked[0].double(), picked[1].double(), picked[2].double(), mask.double(), B, T, P, Cc, heads)
+    close(o3, ref3.float(), 5e-5)
+
+
 def test_spatial_attention_block(nat):
     """gn_coef + qkv GEMM (affine prologue) + spatial core + proj GEMM (affine residual) vs oracle."""
     N, P, Cc, heads = 3, 64, 64, 4
