@@ -3,7 +3,7 @@
 //   logits[t][s] = q_t . (k_s + R_k[t][s]) + scale * k_s . R_q[s][t]     (q already scaled)
 //   o[t]         = sum_s softmax_s(logits + two-clique mask)[s] * (v_s + R_v[t][s])
 //
-// per (batch b, head h, pixel p); T <= 32 frames, head dim F in {8, 16, 32}.  Same per-lane arithmetic as the first
+// per (batch b, head h, pixel p); T <= 32 frames, head dim F in {16, 32} (others: the first kernel).  Same per-lane arithmetic as the first
 // kernel (attention.hip: a lane owns one (pixel, query frame) and all T logits, softmax without cross-lane traffic),
 // restructured around what that kernel measured as its limits on MI355X (tools/attn_bench.py):
 //   * the workgroup's operands - the R_k / R_q / R_v slices of its query frames and the k / v rows of its pixels - are
@@ -23,7 +23,10 @@ struct T2Geom {
     int TG, TGN, PPW, NW;      // frame groups, frames per group, pixels per wave, waves per workgroup
     int strips;                // pixel strips of NW*PPW pixels
     int NL, HL, XPG;           // line groups (b, head / HL), heads per 128-byte line, XCDs per line group (0: plain map)
+    int dbg;                   // developer aid (tools/attn_t2_sweep.py): 1 = staging only, 2 = no staging
 };
+
+int g_t2_force_tg = 0, g_t2_force_nw = 0, g_t2_dbg = 0;      // set by lfvdm_attn_temporal2_debug (tools only)
 
 template <int F, int TCAP>
 struct T2Cfg {
@@ -32,7 +35,7 @@ struct T2Cfg {
 };
 
 template <int F, int TCAP>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 3)          // three waves per SIMD (<= 168 VGPRs): the waves hide each other's LDS latency
 void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restrict__ Rq, const float* __restrict__ Rk,
                            const float* __restrict__ Rv, const float* __restrict__ mask, float* __restrict__ o,
                            float* __restrict__ attn_out, const int64_t* __restrict__ rsel, T2Geom g) {
@@ -70,8 +73,9 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
     const int tq0 = tg * g.TGN;
     const int p0 = strip * NPX;
     // LDS images, in slots of 4 floats: R[tq][3][RS] (R_k | R_q transposed | R_v), then KV[pixel][2][RS]
+    // (each image is padded to whole 64-slot DMA pieces: a piece always writes 1 KiB)
     float* Rimg = t2_smem;
-    float* KVimg = t2_smem + (size_t)g.TGN * 3 * RS * 4;
+    float* KVimg = t2_smem + (size_t)((g.TGN * 3 * RS + 63) & ~63) * 4;
     const float invRS = 1.0f / (float)RS;
 
     // ---- LDS-DMA staging (global_load_lds_dwordx4: 16 bytes per lane from a per-lane address to the wave's next 1 KiB
@@ -81,12 +85,14 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
         const size_t rb = rsel ? (size_t)rsel[b] * g.B + b : (size_t)b;
         const float* Rsrc[3] = {Rk + rb * T * T * C + h * F, Rq + rb * T * T * C + h * F, Rv + rb * T * T * C + h * F};
         const float* kvsrc = qkv + (size_t)b * T * P * 3 * C + C + h * F;     // k of (b, frame 0, pixel 0); v is C further
-        const int nR = (g.TGN * 3 * RS + 63) >> 6, nKV = (NPX * 2 * RS + 63) >> 6;
+        const int vpx = min(NPX, P - p0);                              // pixel rows that exist
+        const int nR = (min(g.TGN, T - tq0) * 3 * RS + 63) >> 6, nKV = (vpx * 2 * RS + 63) >> 6;
         const int TNQ = T * NQ;
         auto dma = [](const float* src, float* dst) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         };
+        if (g.dbg < 2)
         for (int pc = wave; pc < nR; pc += g.NW) {
             const int ps = pc * 64 + lane;
             const int row3 = (int)(((float)ps + 0.5f) * invRS);        // (query frame, array) row
@@ -101,6 +107,7 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
             const float* base = arr == 0 ? Rsrc[0] : (arr == 1 ? Rsrc[1] : Rsrc[2]);
             dma(ok ? base + (size_t)row * C + 4 * u : qkv, Rimg + (size_t)pc * 256);
         }
+        if (g.dbg < 2)
         for (int pc = wave; pc < nKV; pc += g.NW) {
             const int ps = pc * 64 + lane;
             const int row2 = (int)(((float)ps + 0.5f) * invRS);        // (pixel, k | v) row
@@ -114,9 +121,14 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
         }
     }
 
-    // ---- this lane's (pixel, query frame); q straight to registers while the DMA is in flight
+    // ---- FOUR lanes per (pixel, query frame): lane = (pair << 2) | sq, pair = (pixel j, frame tq), and lane sq owns
+    // the key frames s = sq, sq + 4, ...  The whole problem is only ~700 (pixel, frame) waves for 1024 SIMDs, and a lone
+    // wave cannot hide the ~100-cycle LDS latency of its ~400 dependent-looking reads (measured: the math phase took as
+    // long on an empty chip as on a full one); a quarter of the keys per lane gives four times the waves with chains a
+    // quarter as long.  Softmax and the output sum cross the four lanes with quad DPP moves.
     const float invN = 1.0f / (float)g.TGN;
-    const int j = (int)(((float)lane + 0.5f) * invN), tq = lane - j * g.TGN;
+    const int sq = lane & 3, pair = lane >> 2;
+    const int j = (int)(((float)pair + 0.5f) * invN), tq = pair - j * g.TGN;
     const int jw = wave * g.PPW + j;
     const int t = tq0 + tq, p = p0 + jw;
     const bool active = j < g.PPW && p < P && t < T;
@@ -126,90 +138,132 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
     f32x4 q4[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) q4[u] = ld4(qrow + 4 * u) * scale;
-    // swizzled slot addresses (floats) of the 16 low slot patterns: reads are base[cl] + immediate
-    int kb[16], rbs[16];
+    // slot of (key s = sq + 4 i, quad u) in a row: c = NQ s + u = 4 NQ i + (NQ sq + u).  NQ = 4: the low four bits are
+    // NQ sq + u for every i; NQ = 8: they are 8 (sq & 1) + u, bit 4 is sq >> 1.  So the swizzled address is a per-lane base
+    // per quad (computed once) plus an immediate per i.
+    constexpr int KQ = (TCAP + 3) / 4;                      // keys per lane
+    constexpr int ISTRIDE = 4 * NQ * 4;                     // floats between consecutive i
+    int kb[NQ], rbs[NQ];
     {
-        const int jr = active ? jw : 0, tr = active ? tq : 0;
+        const int jr = (active && g.dbg != 3) ? jw : 0, tr = (active && g.dbg != 3) ? tq : 0;   // dbg 3: every lane reads row 0
 #pragma unroll
-        for (int cl = 0; cl < 16; ++cl) {
-            kb[cl] = (jr * 2 * RS + (cl ^ (jr & 15))) * 4;
-            rbs[cl] = (tr * 3 * RS + (cl ^ (tr & 15))) * 4;
+        for (int u = 0; u < NQ; ++u) {
+            const int low = NQ == 4 ? 4 * sq + u : 8 * (sq & 1) + u, high = NQ == 4 ? 0 : 16 * (sq >> 1);
+            kb[u] = (jr * 2 * RS + high + (low ^ (jr & 15))) * 4;
+            rbs[u] = (tr * 3 * RS + high + (low ^ (tr & 15))) * 4;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed (q too)
     __syncthreads();                                       // ... and everybody else's
 
-    float logit[TCAP];
-    if (active) {
+    // quad exchanges (DPP quad_perm): partner lanes sq ^ 1 and sq ^ 2
+    auto quad_x1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); };
+    auto quad_x2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); };
+
+    if (g.dbg != 1) {            // (inactive lanes run along on row 0: the quad exchanges need all four lanes)
+        float logit[KQ];
+        // packed fp32 math on naturally adjacent register pairs (q, k, R rows arrive as b128 = two aligned pairs)
 #pragma unroll
-        for (int s = 0; s < TCAP; ++s) {
-            float a0 = 0.f, a1 = 0.f;
-            if (s < T) {
+        for (int i = 0; i < KQ; ++i) {
+            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    const int c = s * NQ + u, cl = c & 15, ch = (c >> 4) * 64;
-                    const f32x4 k4 = ld4(KVimg + kb[cl] + ch);
-                    const f32x4 rk4 = ld4(Rimg + rbs[cl] + ch);
-                    const f32x4 rq4 = ld4(Rimg + rbs[cl] + RS * 4 + ch);
-                    a0 += q4[u].x * (k4.x + rk4.x) + q4[u].y * (k4.y + rk4.y) + q4[u].z * (k4.z + rk4.z) + q4[u].w * (k4.w + rk4.w);
-                    a1 += k4.x * rq4.x + k4.y * rq4.y + k4.z * rq4.z + k4.w * rq4.w;
-                }
+            for (int u = 0; u < NQ; ++u) {
+                const f32x4 k4 = ld4(KVimg + kb[u] + i * ISTRIDE);
+                const f32x4 r4 = ld4(Rimg + rbs[u] + i * ISTRIDE);
+                const f32x4 g4 = ld4(Rimg + rbs[u] + RS * 4 + i * ISTRIDE);
+                a0 = __builtin_elementwise_fma(q4[u].xy, k4.xy + r4.xy, a0);
+                a0 = __builtin_elementwise_fma(q4[u].zw, k4.zw + r4.zw, a0);
+                a1 = __builtin_elementwise_fma(k4.xy, g4.xy, a1);
+                a1 = __builtin_elementwise_fma(k4.zw, g4.zw, a1);
             }
-            logit[s] = a0 + a1 * scale;
+            logit[i] = (a0.x + a0.y) + (a1.x + a1.y) * scale;
+            // Left alone, the scheduler hoists all ~100 reads of the unrolled loops to the top and the register allocator
+            // spills them straight to scratch (ds_read -> lgkmcnt(0) -> scratch_store): keep every key's reads with its math;
+            // the other waves of the SIMD cover the latency.
+            // ... the fence has to CONSUME the result, or instruction selection sinks the (side-effect free) math below it
+            asm volatile("" : "+v"(logit[i]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // two-clique mask + softmax, all in this lane's registers (rpe.py:156-163)
-        const float mt = mask ? mask[b * T + t] : 1.f;
+        // two-clique mask + softmax over the keys of the four lanes (rpe.py:156-163)
+        const int tm = active ? t : 0;
+        const float mt = mask ? mask[b * T + tm] : 1.f;
         float mx = -INFINITY;
 #pragma unroll
-        for (int s = 0; s < TCAP; ++s) {
+        for (int i = 0; i < KQ; ++i) {
+            const int sk = sq + 4 * i;
             float v = -INFINITY;
-            if (s < T) {
-                v = logit[s];
+            if (sk < T) {
+                v = logit[i];
                 if (mask) {
-                    const float ms = mask[b * T + s];
+                    const float ms = mask[b * T + sk];
                     const float pen = 1.f - (mt * ms + (1.f - mt) * (1.f - ms));
                     v -= (pen == 1.f) ? INFINITY : pen;
                 }
             }
-            logit[s] = v;
+            logit[i] = v;
             mx = fmaxf(mx, v);
         }
+        mx = fmaxf(mx, quad_x1(mx));
+        mx = fmaxf(mx, quad_x2(mx));
         float sum = 0.f;
 #pragma unroll
-        for (int s = 0; s < TCAP; ++s) {
-            const float e = (logit[s] == -INFINITY) ? 0.f : __expf(logit[s] - mx);
-            logit[s] = e;
+        for (int i = 0; i < KQ; ++i) {
+            const float e = (logit[i] == -INFINITY) ? 0.f : __expf(logit[i] - mx);
+            logit[i] = e;
             sum += e;
         }
+        sum += quad_x1(sum);
+        sum += quad_x2(sum);
         const float inv = 1.0f / sum;
 #pragma unroll
-        for (int s = 0; s < TCAP; ++s) logit[s] *= inv;
-        if (attn_out) {
+        for (int i = 0; i < KQ; ++i) logit[i] *= inv;
+        if (attn_out && active) {
             float* ar = attn_out + ((((size_t)b * P + p) * g.heads + h) * T + t) * T;
 #pragma unroll
-            for (int s = 0; s < TCAP; ++s)
-                if (s < T) ar[s] = logit[s];
+            for (int i = 0; i < KQ; ++i)
+                if (sq + 4 * i < T) ar[sq + 4 * i] = logit[i];
         }
-        // o[t][f] = sum_s p[s] * (v[s][f] + R_v[t][s][f])
+        // o[t][f] = sum_s p[s] * (v[s][f] + R_v[t][s][f]): partial sums over this lane's keys, then over the quad
         f32x4 acc[NQ];
 #pragma unroll
         for (int u = 0; u < NQ; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < TCAP; ++s) {
-            if (s < T) {
-                float pr = logit[s];
-                asm volatile("" : "+v"(pr));       // keeps the broadcast operand out of hoisted packed-FMA pairs (spills)
+        for (int i = 0; i < KQ; ++i) {
+            const f32x2 pr = {logit[i], logit[i]};       // exactly 0 for key frames >= T (their slots hold finite filler)
 #pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    const int c = s * NQ + u, cl = c & 15, ch = (c >> 4) * 64;
-                    acc[u] += pr * (ld4(KVimg + kb[cl] + RS * 4 + ch) + ld4(Rimg + rbs[cl] + 2 * RS * 4 + ch));
-                }
+            for (int u = 0; u < NQ; ++u) {
+                const f32x4 v4 = ld4(KVimg + kb[u] + RS * 4 + i * ISTRIDE);
+                const f32x4 r4 = ld4(Rimg + rbs[u] + 2 * RS * 4 + i * ISTRIDE);
+                f32x2 lo = acc[u].xy, hi = acc[u].zw;
+                lo = __builtin_elementwise_fma(pr, v4.xy + r4.xy, lo);
+                hi = __builtin_elementwise_fma(pr, v4.zw + r4.zw, hi);
+                acc[u] = (f32x4){lo.x, lo.y, hi.x, hi.y};
+                asm volatile("" : "+v"(acc[u]) : : "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[u][e];
+                v += quad_x1(v);
+                v += quad_x2(v);
+                acc[u][e] = v;
             }
         }
-        float* orow = o + ((size_t)(b * T + t) * P + p) * C + h * F;
+        if (active) {            // lane sq stores quads sq, sq + 4, ...: the four lanes write 64 contiguous bytes
+            float* orow = o + ((size_t)(b * T + t) * P + p) * C + h * F;
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) st4(orow + 4 * u, acc[u]);
+            for (int u = 0; u < NQ; ++u)
+                if ((u & 3) == sq) st4(orow + 4 * u, acc[u]);
+        }
     }
+}
+
+// LDS of a workgroup: the R image and the k / v image, each padded to whole DMA pieces of 64 slots (1 KiB)
+inline size_t t2_lds_bytes(int TGN, int NPX, int RS) {
+    return ((size_t)((TGN * 3 * RS + 63) & ~63) + (size_t)((NPX * 2 * RS + 63) & ~63)) * 16;
 }
 
 template <int F, int TCAP>
@@ -217,48 +271,34 @@ int launch_t2(const float* qkv, const float* Rq, const float* Rk, const float* R
               int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
     using CF = T2Cfg<F, TCAP>;
     constexpr int RS = CF::RS;
-    // Frame groups TG and waves per workgroup NW by a small cost model (us): the kernel is bound by the CU's LDS read
-    // path (5 b128 reads per (s, 4 channels) per lane: `cw` per wave) and by the DMA fill of the workgroup's images
-    // (~70 GB/s per CU from L2), so what counts is the number of waves and of staged bytes on the BUSIEST CU.
+    // Frame groups TG and waves per workgroup NW.  Measured on MI355X (tools/attn_t2_sweep.py, T = 14 / 20, maps of 4 to
+    // 256 pixels, head dims 16 / 32): groups of <= 5 query frames (three pixels per wave, 15 of 16 lane quads busy, a
+    // small R image) with FOUR waves per workgroup were the fastest or within 5 % of it everywhere - four waves issue
+    // the image's DMA pieces in parallel and share one copy of the R slices, also where the map has fewer pixels than
+    // the workgroup has slots.  Fewer waves only when the images of four do not fit the LDS.
     T2Geom g{};
     g.T = T; g.P = P; g.C = C; g.heads = heads; g.B = B;
-    int best_tg = 0, best_nw = 0;
-    double best = 1e30;
-    const double cw = (double)T * CF::NQ * 5 * 4 / 2400.0;
-    for (int TG = 1; TG <= 5; ++TG) {
-        const int TGN = (T + TG - 1) / TG;
-        if (TG > 1 && TGN * (TG - 1) >= T) continue;              // an empty last group
-        const int PPW = 64 / TGN;
-        if (PPW < 1) continue;
-        for (int NW = 1; NW <= 4; NW *= 2) {
-            const int NPX = NW * PPW;
-            if (NW > 1 && (NW / 2) * PPW >= P) continue;          // waves without pixels
-            const size_t lds = ((size_t)TGN * 3 + (size_t)NPX * 2) * RS * 16;
-            if (lds > 160 * 1024) continue;
-            const long strips = (P + NPX - 1) / NPX;
-            const long wgs = strips * TG * B * heads;
-            int per_cu = (int)(160 * 1024 / lds);
-            per_cu = per_cu > 8 ? 8 : per_cu;
-            if (per_cu * NW > 8) per_cu = 8 / NW;
-            const double fill = (double)lds / 70e3;
-            double t;
-            if (wgs <= 256L * per_cu) {
-                const long maxr = (wgs + 255) / 256;
-                t = maxr * NW * cw + fill * (1.0 + 0.5 * (maxr - 1));
-            } else {
-                const long rounds = (wgs + 256L * per_cu - 1) / (256L * per_cu);
-                t = rounds * (per_cu * NW * cw + fill * (1.0 + 0.5 * (per_cu - 1)));
-            }
-            if (t < best) { best = t; best_tg = TG; best_nw = NW; }
-        }
+    int best_tg = (T + 4) / 5, best_nw = 0;
+    {
+        const int TGN = (T + best_tg - 1) / best_tg, PPW = 16 / TGN;
+        for (int NW = 4; NW >= 1 && best_nw == 0; NW /= 2)
+            if (t2_lds_bytes(TGN, NW * PPW, RS) <= 160 * 1024) best_nw = NW;
+        if (best_nw == 0) best_tg = 0;
     }
+    if (g_t2_force_tg > 0) {
+        best_tg = g_t2_force_tg;
+        best_nw = g_t2_force_nw;
+        const int TGN = (T + best_tg - 1) / best_tg, PPW = 16 / (TGN > 16 ? 16 : TGN);
+        if (TGN > 16 || t2_lds_bytes(TGN, best_nw * PPW, RS) > 160 * 1024) return LFVDM_E_SHAPE;
+    }
+    g.dbg = g_t2_dbg;
     if (best_tg == 0) return LFVDM_E_UNSUPPORTED;
     g.TG = best_tg; g.NW = best_nw;
     g.TGN = (T + g.TG - 1) / g.TG;
-    g.PPW = 64 / g.TGN;
+    g.PPW = 16 / g.TGN;
     const int NPX = g.NW * g.PPW;
     g.strips = (P + NPX - 1) / NPX;
-    const size_t lds = ((size_t)g.TGN * 3 + (size_t)NPX * 2) * RS * 16;
+    const size_t lds = t2_lds_bytes(g.TGN, NPX, RS);
     // XCD-aware placement (speed only): heads that share 128-byte lines and all frame groups of a strip on one XCD
     g.HL = F >= 32 ? 1 : 32 / F;
     if (g.HL > heads || heads % g.HL) g.HL = 1;
@@ -291,12 +331,18 @@ int launch_t2_f(const float* qkv, const float* Rq, const float* Rk, const float*
 
 }  // namespace
 
+// Developer aid: force the decomposition / switch off phases (tools/attn_t2_sweep.py).  Not part of the product ABI.
+extern "C" void lfvdm_attn_temporal2_debug(int tg, int nw, int dbg) {
+    g_t2_force_tg = tg;
+    g_t2_force_nw = nw;
+    g_t2_dbg = dbg;
+}
+
 // Internal entry (attention.hip dispatches here first): LFVDM_E_UNSUPPORTED = shape not covered, use the first kernel.
 int lfvdm_attn_temporal2_try(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
                              float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
     const int F = C / heads;
     if (F == 16) return launch_t2_f<16>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (F == 32) return launch_t2_f<32>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
-    if (F == 8) return launch_t2_f<8>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     return LFVDM_E_UNSUPPORTED;
 }

@@ -22,28 +22,29 @@ def timeit(fn, reps=20, rounds=5):
     return best
 
 
-for (B, T, P, C, heads) in [(2, 20, 256, 64, 4), (2, 20, 64, 128, 4), (2, 20, 4, 128, 4), (2, 20, 256, 128, 4), (2, 20, 64, 256, 4)]:
-    M = B * T * P
-    qkv = th.randn(M, 3 * C, device=dev)
-    R = [th.randn(B, T, T, C, device=dev) * 0.1 for _ in range(3)]
-    mask = (th.rand(B, T, device=dev) < 0.5).float()
-    o = th.empty(M, C, device=dev)
-    t_t = timeit(lambda: nat.attn_temporal(qkv, R[0], R[1], R[2], mask, o, None, B, T, P, C, heads))
-    t_s = timeit(lambda: nat.attn_spatial(qkv, o, None, B * T, P, C, heads))
-    print(f"B={B} T={T} P={P} C={C} heads={heads}: temporal {t_t:7.1f} us   spatial {t_s:7.1f} us", flush=True)
+if __name__ == "__main__":
+  for (B, T, P, C, heads) in [(2, 20, 256, 64, 4), (2, 20, 64, 128, 4), (2, 20, 4, 128, 4), (2, 20, 256, 128, 4), (2, 20, 64, 256, 4)]:
+      M = B * T * P
+      qkv = th.randn(M, 3 * C, device=dev)
+      R = [th.randn(B, T, T, C, device=dev) * 0.1 for _ in range(3)]
+      mask = (th.rand(B, T, device=dev) < 0.5).float()
+      o = th.empty(M, C, device=dev)
+      t_t = timeit(lambda: nat.attn_temporal(qkv, R[0], R[1], R[2], mask, o, None, B, T, P, C, heads))
+      t_s = timeit(lambda: nat.attn_spatial(qkv, o, None, B * T, P, C, heads))
+      print(f"B={B} T={T} P={P} C={C} heads={heads}: temporal {t_t:7.1f} us   spatial {t_s:7.1f} us", flush=True)
 
-# optional: debug variants of the temporal kernel built into devlibs/ (developer experiments)
-import ctypes as C, glob
-for path in sorted(glob.glob(os.path.join(ROOT, "devlibs", "libatt_v*.so"))):
-    L = C.CDLL(path)
-    f = L.lfvdm_attn_temporal
-    f.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]
-    f.restype = C.c_int
-    res = []
-    for (B, T, P, Cc, heads) in [(2, 20, 256, 64, 4), (2, 20, 4, 128, 4), (2, 20, 64, 256, 4)]:
-        M = B * T * P
-        qkv = th.randn(M, 3 * Cc, device=dev); R = [th.randn(B, T, T, Cc, device=dev) * 0.1 for _ in range(3)]
-        mask = (th.rand(B, T, device=dev) < 0.5).float(); o = th.empty(M, Cc, device=dev)
-        res.append(timeit(lambda: f(qkv.data_ptr(), R[0].data_ptr(), R[1].data_ptr(), R[2].data_ptr(), mask.data_ptr(),
-                                    o.data_ptr(), None, B, T, P, Cc, heads, nat.stream())))
-    print(os.path.basename(path), " ".join(f"{r:7.1f}" for r in res), flush=True)
+  # optional: debug variants of the temporal kernel built into devlibs/ (developer experiments)
+  import ctypes as C, glob
+  for path in sorted(glob.glob(os.path.join(ROOT, "devlibs", "libatt_v*.so"))):
+      L = C.CDLL(path)
+      f = L.lfvdm_attn_temporal
+      f.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]
+      f.restype = C.c_int
+      res = []
+      for (B, T, P, Cc, heads) in [(2, 20, 256, 64, 4), (2, 20, 4, 128, 4), (2, 20, 64, 256, 4)]:
+          M = B * T * P
+          qkv = th.randn(M, 3 * Cc, device=dev); R = [th.randn(B, T, T, Cc, device=dev) * 0.1 for _ in range(3)]
+          mask = (th.rand(B, T, device=dev) < 0.5).float(); o = th.empty(M, Cc, device=dev)
+          res.append(timeit(lambda: f(qkv.data_ptr(), R[0].data_ptr(), R[1].data_ptr(), R[2].data_ptr(), mask.data_ptr(),
+                                      o.data_ptr(), None, B, T, P, Cc, heads, nat.stream())))
+      print(os.path.basename(path), " ".join(f"{r:7.1f}" for r in res), flush=True)
