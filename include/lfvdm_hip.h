@@ -426,19 +426,6 @@ typedef struct lfvdm_adamw_args {
 int lfvdm_adamw_ema(const lfvdm_adamw_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * GroupNorm32 + Linear in one launch: xn = GN32(x), y = xn W^T + bias - the head of an RPEAttention half
- * (rpe.py:133-141: `x = self.norm(x)`, `qkv = self.qkv(x)`); xn is also the block's residual (rpe.py:172).
- *   mode 0 (temporal instance): x rows [(b*T + t)*P + p][C], BN = B; statistics per (b, pixel) over T frames x C/32 channels
- *   mode 1 (spatial instance):  x rows [n*P + p][C],          BN = N frames; statistics per frame over P pixels x C/32 channels
- * W [Nout][C], bias [Nout] or NULL, xn [rows][C] or NULL, y [rows][Nout].  C in {64, 128}; mode 1 needs P <= 256 and the
- * frame to fit the LDS: lfvdm_norm_linear_supported tells (otherwise LFVDM_E_UNSUPPORTED; use lfvdm_gn_temporal /
- * lfvdm_gn_apply followed by lfvdm_conv_igemm).
- * ------------------------------------------------------------------------------------- */
-int lfvdm_norm_linear(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias,
-                      float* xn, float* y, int mode, int BN, int T, int P, int C, int Nout, void* stream);
-int lfvdm_norm_linear_supported(int mode, int T, int P, int C);
-
-/* ---------------------------------------------------------------------------------------
  * Training-batch assembly on the device (TrainLoop.prepare_training_batch, train_util.py:224-241, with the masks of
  * sample_all_masks, :193-222).  The host samples the index table (same sequence of random draws as the reference);
  * the gather and the mask / index tensors are produced here, inside the captured training step.

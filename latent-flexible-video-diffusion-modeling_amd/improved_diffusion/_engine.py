@@ -32,8 +32,6 @@ def _p(t):
 FUSED_GN = os.environ.get("LFVDM_FUSED_GN", "0") == "1"
 # LFVDM_GN_EPILOGUE=0: never evaluate a GroupNorm in the epilogue of the GEMM that produces its input (A/B aid)
 GN_EPILOGUE = os.environ.get("LFVDM_GN_EPILOGUE", "1") != "0"
-# LFVDM_NORM_LINEAR=0: GroupNorm and the qkv projection of the attention halves as two launches (A/B aid)
-NORM_LINEAR = os.environ.get("LFVDM_NORM_LINEAR", "1") != "0"
 
 
 class Plan:
@@ -376,13 +374,9 @@ class Plan:
         heads = ab.num_heads
         ta, sa = ab.temporal_attention, ab.spatial_attention
         # --- temporal: GN over (C/32 x T) per (b, pixel); residual on the normalised tensor (rpe.py:136,172)
-        if NORM_LINEAR and L.lfvdm_norm_linear_supported(0, T, P, Cc):     # GroupNorm + qkv projection in one launch
-            self.add(L.lfvdm_norm_linear, _p(x), _p(ta.norm.weight), _p(ta.norm.bias), ta.norm.eps, _p(ta.qkv.weight),
-                     _p(ta.qkv.bias), _p(self.s_xn), _p(self.s_qkv), 0, B, T, P, Cc, 3 * Cc)
-        else:
-            self.add(L.lfvdm_gn_temporal, _p(x), _p(ta.norm.weight), _p(ta.norm.bias), ta.norm.eps, _p(self.s_xn), B, T, P, Cc)
-            self.add_conv(src0=self.s_xn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.qkv.weight, bias=ta.qkv.bias,
-                          Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
+        self.add(L.lfvdm_gn_temporal, _p(x), _p(ta.norm.weight), _p(ta.norm.bias), ta.norm.eps, _p(self.s_xn), B, T, P, Cc)
+        self.add_conv(src0=self.s_xn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.qkv.weight, bias=ta.qkv.bias,
+                      Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
         at = None
         if self.want_attn:
             at = self.buf(B * P, heads, T, T)
@@ -410,10 +404,6 @@ class Plan:
                      _p(self.s_cA), _p(self.s_cB))
             self.add_conv(src0=yt, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=self.s_cA, coefB=self.s_cB,
                           W=sa.qkv.weight, bias=sa.qkv.bias, Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
-        elif ysn is None and NORM_LINEAR and L.lfvdm_norm_linear_supported(1, T, P, Cc):
-            ysn = self.scratch("act1", M, Cc)          # normalised tensor = the residual; GroupNorm + qkv in one launch
-            self.add(L.lfvdm_norm_linear, _p(yt), _p(sa.norm.weight), _p(sa.norm.bias), sa.norm.eps, _p(sa.qkv.weight),
-                     _p(sa.qkv.bias), _p(ysn), _p(self.s_qkv), 1, N, T, P, Cc, 3 * Cc)
         else:
             if ysn is None:
                 ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual

@@ -128,8 +128,6 @@ _SIGS = {
     "lfvdm_p_sample": ([c_fp] * 9 + [c_i] + [c_fp] * 3 + [c_i, c_i, c_fp], c_i),
     "lfvdm_masked_mse": ([c_fp] * 4 + [c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_prepare_batch": ([c_fp] * 6 + [c_i] * 4 + [c_fp], c_i),
-    "lfvdm_norm_linear": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp], c_i),
-    "lfvdm_norm_linear_supported": ([c_i] * 4, c_i),
     "lfvdm_flag_add": ([c_fp, c_fp], c_i),
     "lfvdm_flag_wait": ([c_fp, c_i, C.c_double, c_fp, c_fp], c_i),
 }

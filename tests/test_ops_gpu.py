@@ -389,35 +389,6 @@ def test_attn_temporal_second_generation_kernel(nat, B, T, P, Cc, heads):
     close(o3, ref3.float(), 5e-5)
 
 
-@pytest.mark.parametrize("mode,BN,T,P,Cc,Nout", [(0, 2, 20, 256, 64, 192), (0, 2, 20, 64, 128, 384), (0, 2, 20, 4, 128, 384),
-                                                    (0, 1, 14, 256, 64, 192), (0, 3, 7, 37, 64, 100), (0, 1, 32, 5, 128, 70),
-                                                    (1, 40, 20, 256, 64, 192), (1, 5, 1, 64, 128, 384), (1, 3, 1, 50, 64, 130),
-                                                    (1, 2, 1, 4, 128, 384), (1, 7, 1, 200, 128, 64)])
-def test_norm_linear_fused(nat, mode, BN, T, P, Cc, Nout):
-    """lfvdm_norm_linear = GroupNorm32 + nn.Linear of an RPEAttention half in one launch (rpe.py:133-141) vs torch:
-    temporal units (b, pixel) over T frames, spatial units = frames over P pixels; ragged strips / column slices."""
-    rows = BN * T * P if mode == 0 else BN * P
-    x = rnd("nl/x", rows, Cc) * 1.7 + 0.3
-    gamma, beta = 1 + 0.2 * rnd("nl/g", Cc), 0.1 * rnd("nl/b", Cc)
-    W, bias = rnd("nl/W", Nout, Cc) * Cc ** -0.5, 0.1 * rnd("nl/bias", Nout)
-    if mode == 0:      # (B, T, P, C) -> groups over (T, C/32) per (b, p): GroupNorm on (B*P, C, T)
-        xr = x.view(BN, T, P, Cc).permute(0, 2, 3, 1).reshape(BN * P, Cc, T)
-        xn_ref = F.group_norm(xr.double(), 32, gamma.double(), beta.double(), 1e-5).view(BN, P, Cc, T).permute(0, 3, 1, 2).reshape(rows, Cc)
-    else:              # frames (N, P, C): GroupNorm on (N, C, P)
-        xr = x.view(BN, P, Cc).permute(0, 2, 1)
-        xn_ref = F.group_norm(xr.double(), 32, gamma.double(), beta.double(), 1e-5).permute(0, 2, 1).reshape(rows, Cc)
-    y_ref = xn_ref @ W.double().t() + bias.double()
-    if not nat.lib().lfvdm_norm_linear_supported(mode, T, P, Cc):
-        pytest.skip("shape not covered by the fused kernel (the plan uses the two-launch path)")
-    d = [t.cuda().contiguous() for t in (x, gamma, beta, W, bias)]
-    xn = torch.full((rows, Cc), float("nan"), device="cuda")
-    y = torch.full((rows, Nout), float("nan"), device="cuda")
-    nat.check(nat.lib().lfvdm_norm_linear(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 1e-5, d[3].data_ptr(), d[4].data_ptr(),
-                                          xn.data_ptr(), y.data_ptr(), mode, BN, T, P, Cc, Nout, nat.stream()), "lfvdm_norm_linear")
-    close(xn, xn_ref.float(), 2e-5)
-    close(y, y_ref.float(), 5e-5)
-
-
 def test_spatial_attention_block(nat):
     """gn_coef + qkv GEMM (affine prologue) + spatial core + proj GEMM (affine residual) vs oracle."""
     N, P, Cc, heads = 3, 64, 64, 4
