@@ -266,6 +266,9 @@ typedef struct lfvdm_rowdot_job {
 } lfvdm_rowdot_job;
 
 int lfvdm_rowdot(const lfvdm_rowdot_job* jobs_dev, int njobs, int total_rows, void* stream);
+/* out = silu(in) elementwise (n a multiple of 4), with the exact silu of in_mode 1 above: a launch over many batch rows
+ * materialises it once and runs in in_mode 0 (bitwise the same results). */
+int lfvdm_silu(const float* in, float* out, int64_t n, void* stream);
 
 /* Backward of the same grouped linears (autograd of nn.Linear, train_util.py:328): per job
  *   dW[o][k] += sum_m dout[m][o] * actin(in[m][k]);  db[o] += sum_m dout[m][o]   (single writer, plain +=)
@@ -304,6 +307,10 @@ typedef struct lfvdm_rpe_job {
 
 int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, const int64_t* frame_indices_i64,
                    int B, int T, void* stream);
+/* The same, told the largest `C` among the jobs (<= 512): the launch then reserves LDS for that width only, which lets
+ * several workgroups share a CU.  lfvdm_rpe_nets assumes 512. */
+int lfvdm_rpe_nets_maxc(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, const int64_t* frame_indices_i64,
+                        int B, int T, int max_channels, void* stream);
 
 /* Backward of the RPE networks of a training step in ONE launch (autograd of rpe.py:20-31 through the output layer's
  * input and the hidden layer): per job, from dR [B*T*T][C],

@@ -672,17 +672,25 @@ int launch_temporal_t(const float* qkv, const float* Rq, const float* Rk, const 
 
 }  // namespace
 
-extern "C" int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, const int64_t* fi, int B, int T,
-                              void* stream) {
-    if (njobs <= 0 || total_tiles <= 0 || B <= 0 || T <= 0) return LFVDM_E_SHAPE;
-    // LDS sized for the largest supported C (512): A tile 32*(C+4) + 4 wave-private W chunks
-    const int maxC = 512;
+extern "C" int lfvdm_rpe_nets_maxc(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, const int64_t* fi, int B, int T,
+                                   int max_channels, void* stream) {
+    if (njobs <= 0 || total_tiles <= 0 || B <= 0 || T <= 0 || max_channels <= 0 || max_channels > 512) return LFVDM_E_SHAPE;
+    // LDS for the widest network of the launch: A tile 32*(C+4) + 4 wave-private W chunks.  (Sized for 512 channels the
+    // 84 KB allow one workgroup per CU; at the 64..128 channels of the latent models four fit, which is what hides the
+    // latency of the row generation: 19 -> 6 ms for the 21 networks x 1000 timesteps of a sampler's R tables.)
+    const int maxC = (max_channels + 31) / 32 * 32;
     const size_t lds = (size_t)(32 * (maxC + 4) + 4 * 32 * RPE_LDR) * sizeof(float);
     static DynLdsLimit limit;
-    if (int rc = limit.ensure(reinterpret_cast<const void*>(&rpe_nets_kernel), lds)) return rc;
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&rpe_nets_kernel), (size_t)(32 * (512 + 4) + 4 * 32 * RPE_LDR) * sizeof(float)))
+        return rc;
     hipLaunchKernelGGL(rpe_nets_kernel, dim3(total_tiles), dim3(256), lds, (hipStream_t)stream, jobs_dev, njobs, fi, B, T);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
+}
+
+extern "C" int lfvdm_rpe_nets(const lfvdm_rpe_job* jobs_dev, int njobs, int total_tiles, const int64_t* fi, int B, int T,
+                              void* stream) {
+    return lfvdm_rpe_nets_maxc(jobs_dev, njobs, total_tiles, fi, B, T, 512, stream);
 }
 
 extern "C" int lfvdm_attn_spatial(const float* qkv, float* o, float* attn_out, float* lse_out, int N, int P, int C, int heads,

@@ -442,6 +442,28 @@ extern "C" int lfvdm_conv_in(const float* x, const float* x0, const float* obs, 
     return LFVDM_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void silu_kernel(const float* __restrict__ in, float* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = ld4(in + 4 * i);
+        v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
+        st4(out + 4 * i, v);
+    }
+}
+}  // namespace
+
+// out = x * sigmoid(x), the very silu_f the row-dot launches apply to their inputs in in_mode 1: materialising it once
+// lets a launch with MANY batch rows (the sampler's per-chain tables) run in in_mode 0 instead of re-evaluating it per
+// output row.  n must be a multiple of 4.
+extern "C" int lfvdm_silu(const float* in, float* out, int64_t n, void* stream) {
+    if (!in || !out || n <= 0 || (n & 3)) return LFVDM_E_SHAPE;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, (long)(n / 4));
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
 extern "C" int lfvdm_rowdot(const lfvdm_rowdot_job* jobs_dev, int njobs, int total_rows, void* stream) {
     if (njobs <= 0 || total_rows <= 0) return LFVDM_E_SHAPE;
     hipLaunchKernelGGL(rowdot_kernel, dim3((total_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs,

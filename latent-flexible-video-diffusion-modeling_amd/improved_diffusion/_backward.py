@@ -835,6 +835,7 @@ class _RpeGroup:
             tile0 += tiles
             task0 += (C // 32) * (C // 32) * msplit
         st.update(nets=nets, flat=flat, params=params, tiles=tile0, tasks=task0, n=len(flat),
+                  maxC=max(n.out.weight.shape[0] for n in flat),
                   j_f=nat.jobs_to_device(fj, dev), j_b=nat.jobs_to_device(bj, dev), j_w=nat.jobs_to_device(wj, dev),
                   key=self._key(m, views, flat, params, B, T, dev))
         return st
@@ -862,8 +863,8 @@ class _RpeGroup:
                 return None
         fi = frame_indices.to(th.int64).contiguous()
         st["fi"] = fi
-        nat.check(nat.lib().lfvdm_rpe_nets(st["j_f"].data_ptr(), st["n"], st["tiles"], nat.ptr(fi, th.int64), B, T, nat.stream()),
-                  "lfvdm_rpe_nets")
+        nat.check(nat.lib().lfvdm_rpe_nets_maxc(st["j_f"].data_ptr(), st["n"], st["tiles"], nat.ptr(fi, th.int64), B, T,
+                                                st["maxC"], nat.stream()), "lfvdm_rpe_nets")
         st["BT"] = (B, T)
         return {layer: ([st["bufs"][n][0] for n in trio], [st["bufs"][n][1] for n in trio]) for layer, trio in st["nets"]}
 

@@ -194,15 +194,19 @@ class Plan:
             off += O
         self._heads = heads
 
-        def emb_jobs(M, tin, ldin, e0_, emb_, rows_):
-            """Device job tables of the three launches for M batch rows: sinusoid + Linear, SiLU + Linear, all heads."""
+        def emb_jobs(M, tin, ldin, e0_, emb_, rows_, se0_=None, semb_=None):
+            """Device job tables of the three launches for M batch rows: sinusoid + Linear, SiLU + Linear, all heads.
+            se0_ / semb_: silu(e0) / silu(emb) materialised by the caller (lfvdm_silu) - the launches then read them in
+            in_mode 0 instead of evaluating the SiLU once per OUTPUT row (what makes M = thousands of rows affordable)."""
             j0 = [nat.RowdotJob(_p(te0.weight), _p(te0.bias), _p(tin), _p(e0_), ch, ted, M, ldin, ted, 2, 0, 0)]
-            j1 = [nat.RowdotJob(_p(te2.weight), _p(te2.bias), _p(e0_), _p(emb_), ted, ted, M, ted, ted, 1, 0, 0)]
+            j1 = [nat.RowdotJob(_p(te2.weight), _p(te2.bias), _p(se0_ if se0_ is not None else e0_), _p(emb_), ted, ted, M, ted, ted,
+                                0 if se0_ is not None else 1, 0, 0)]
             jg, row0 = [], 0
             for key, lin, mode in heads:
                 O = lin.weight.shape[0]
-                jg.append(nat.RowdotJob(_p(lin.weight), _p(lin.bias), _p(emb_), _p(rows_) + 4 * self.row_off[key], ted, O, M, ted,
-                                        self.rows_ld, mode, row0, 0))
+                src, md = (semb_, 0) if (mode == 1 and semb_ is not None) else (emb_, mode)
+                jg.append(nat.RowdotJob(_p(lin.weight), _p(lin.bias), _p(src), _p(rows_) + 4 * self.row_off[key], ted, O, M, ted,
+                                        self.rows_ld, md, row0, 0))
                 row0 += O
             return [nat.jobs_to_device(j, self.dev) for j in (j0, j1, jg)], len(jg), row0
 
@@ -258,7 +262,7 @@ class Plan:
             jr, n_r, tiles_r = rpe_jobs(B, self.rows, self.R)
             if jr is not None:
                 self.keep.append(jr)
-                self.add(L.lfvdm_rpe_nets, _p(jr), n_r, tiles_r, _p(self.fi), B, T)
+                self.add(L.lfvdm_rpe_nets_maxc, _p(jr), n_r, tiles_r, _p(self.fi), B, T, max(r.rpe_net.channels for r in rpe_mods))
 
         # ---- scratch shared by all blocks (forward-only plan)
         maxC = max(mod.channels for mod in m.modules() if isinstance(mod, FactorizedAttentionBlock))
@@ -449,10 +453,13 @@ class Plan:
         tin[:Bv] = ts_table.to(self.dev, th.float32).repeat_interleave(B)
         tin[Bvp:] = timestep_freqs(ch).to(self.dev)
         e0, emb = th.empty(Bv, ted, device=self.dev), th.empty(Bv, ted, device=self.dev)
-        (j0, j1, jg), n_g, rows_g = self._emb_jobs(Bv, tin, Bvp, e0, emb, self.rows_all)
+        se0, semb = th.empty_like(e0), th.empty_like(emb)
+        (j0, j1, jg), n_g, rows_g = self._emb_jobs(Bv, tin, Bvp, e0, emb, self.rows_all, se0, semb)
         s = nat.stream()
         nat.check(L.lfvdm_rowdot(_p(j0), 1, ted, s), "lfvdm_rowdot")
+        nat.check(L.lfvdm_silu(_p(e0), _p(se0), e0.numel(), s), "lfvdm_silu")
         nat.check(L.lfvdm_rowdot(_p(j1), 1, ted, s), "lfvdm_rowdot")
+        nat.check(L.lfvdm_silu(_p(emb), _p(semb), emb.numel(), s), "lfvdm_silu")
         nat.check(L.lfvdm_rowdot(_p(jg), n_g, rows_g, s), "lfvdm_rowdot")
         th.cuda.current_stream().synchronize()      # the temporaries and job tables above die with this frame
         self.tables_sig = (self.weight_signature(), tuple(ts_table.tolist()))       # (compared by GraphSampler.begin)
@@ -465,7 +472,8 @@ class Plan:
         n_t, B, T = self.time_steps, self.B, self.T
         fi = frame_indices.to(self.dev, th.int64).reshape(B, T).repeat(n_t, 1).contiguous()
         jr, n_r, tiles_r = self._rpe_jobs(n_t * B, self.rows_all, self.R)
-        nat.check(nat.lib().lfvdm_rpe_nets(_p(jr), n_r, tiles_r, _p(fi), n_t * B, T, nat.stream()), "lfvdm_rpe_nets")
+        nat.check(nat.lib().lfvdm_rpe_nets_maxc(_p(jr), n_r, tiles_r, _p(fi), n_t * B, T, max(r.rpe_net.channels for r in self.R),
+                                                nat.stream()), "lfvdm_rpe_nets")
         th.cuda.current_stream().synchronize()
 
     def tick(self, t_buf, ts_table):
@@ -533,7 +541,7 @@ class Plan:
         L = nat.lib()
         main = th.cuda.current_stream()
         n_time = 0
-        while n_time < len(self.steps) and self.steps[n_time][0] in (L.lfvdm_rowdot, L.lfvdm_rpe_nets):
+        while n_time < len(self.steps) and self.steps[n_time][0] in (L.lfvdm_rowdot, L.lfvdm_rpe_nets, L.lfvdm_rpe_nets_maxc):
             n_time += 1
         n_emb = sum(1 for fn, _ in self.steps[:n_time] if fn is L.lfvdm_rowdot)
         ev_film, ev_R = th.cuda.Event(), th.cuda.Event()

@@ -111,7 +111,9 @@ _SIGS = {
     "lfvdm_gn_temporal_bwd": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_temporal": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rowdot": ([c_fp, c_i, c_i, c_fp], c_i),
+    "lfvdm_silu": ([c_fp, c_fp, C.c_int64, c_fp], c_i),
     "lfvdm_rpe_nets": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
+    "lfvdm_rpe_nets_maxc": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_nets_bwd": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_conv_wgrad_grouped": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_attn_spatial": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
