@@ -42,6 +42,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
     __shared__ __attribute__((aligned(16))) float shA[GN_MAXCW], shB[GN_MAXCW];
 
     const size_t pos0 = (size_t)n * P;
+    const bool pow2q = (Q & (Q - 1)) == 0 && Q <= 64;      // workgroup-uniform
     constexpr int KEEP = 8;
     const bool cached = P <= KEEP * PL;       // workgroup-uniform
     f32x4 keep[KEEP];
@@ -71,12 +72,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
                     if (pass) { v = v - mu; s += v * v; } else { s += v; }
                 }
             }
-            st4(part + (pl * Q + q) * 4, s);
+            if (pow2q) {
+                // quads of a wave repeat every Q lanes: butterfly over the pixel lanes of the wave, then one partial
+                // row per wave (a serial sum over all PL pixel lanes - 64 dependent LDS reads at C = 64 - was half of
+                // this kernel's time)
+                for (int off = Q; off < 64; off <<= 1) {
+                    s.x += __shfl_xor(s.x, off, 64); s.y += __shfl_xor(s.y, off, 64);
+                    s.z += __shfl_xor(s.z, off, 64); s.w += __shfl_xor(s.w, off, 64);
+                }
+                if ((tid & 63) < Q) st4(part + ((tid >> 6) * Q + q) * 4, s);
+            } else {
+                st4(part + (pl * Q + q) * 4, s);
+            }
         }
         __syncthreads();
+        const int rows = pow2q ? GN_THREADS / 64 : PL;
         for (int cc = tid; cc < CW; cc += GN_THREADS) {
             float t = 0.f;
-            for (int i = 0; i < PL; ++i) t += part[i * CW + cc];
+            for (int i = 0; i < rows; ++i) t += part[i * CW + cc];
             chs[cc] = t;
         }
         __syncthreads();
@@ -209,6 +222,82 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
     }
 }
 
+// Register-resident variant for C <= 256 (the channel quads of a frame fit one wave): the (b, pixel) sample - T x C
+// floats, <= TIT float4 per lane - is read ONCE and both statistic passes and the normalisation run on registers
+// (the kernel above reads it three times from L2, each pass a dependent round trip).  Same lane layout and same
+// summation order as above: bitwise the same result.
+template <int TIT>
+__global__ __launch_bounds__(256) void gn_temporal_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ y, int B, int T, int P, int C) {
+    __shared__ float chs_all[4][256];
+    __shared__ float gstat_all[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long sample = (long)blockIdx.x * 4 + wave;
+    if (sample >= (long)B * P) return;  // whole wave exits together
+    float* chs = chs_all[wave];
+    float* gstat = gstat_all[wave];
+    const int b = (int)(sample / P), p = (int)(sample % P);
+    const int cg = C / 32;
+    const int Q = C / 4;                 // <= 64, divides 64
+    const size_t base = ((size_t)b * T * P + p) * C;
+    const size_t tstride = (size_t)P * C;
+    const int TL = 64 / Q;
+    const int q = lane % Q, tl = lane / Q;
+    f32x4 keep[TIT];
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+        const int t = tl + i * TL;
+        keep[i] = t < T ? ld4(x + base + t * tstride + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TIT; ++i) {
+            if (tl + i * TL < T) {
+                if (pass) { const f32x4 v = keep[i] - mu; s += v * v; } else { s += keep[i]; }
+            }
+        }
+        for (int o = Q; o < 64; o <<= 1) {
+            s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+            s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+        }
+        if (tl == 0) st4(chs + q * 4, s);
+        wave_lds_fence();
+        if (lane < 32) {
+            float t = 0.f;
+            for (int i = 0; i < cg; ++i) t += chs[lane * cg + i];
+            const float inv = 1.0f / (float)(cg * T);
+            if (pass == 0) gstat[lane] = t * inv;
+            else gstat[32 + lane] = 1.0f / sqrtf(t * inv + eps);
+        }
+        wave_lds_fence();
+        if (pass == 0) {
+            mu.x = gstat[(q * 4 + 0) / cg]; mu.y = gstat[(q * 4 + 1) / cg];
+            mu.z = gstat[(q * 4 + 2) / cg]; mu.w = gstat[(q * 4 + 3) / cg];
+        } else {
+            rs.x = gstat[32 + (q * 4 + 0) / cg]; rs.y = gstat[32 + (q * 4 + 1) / cg];
+            rs.z = gstat[32 + (q * 4 + 2) / cg]; rs.w = gstat[32 + (q * 4 + 3) / cg];
+        }
+    }
+    const f32x4 ga = ld4(gamma + q * 4), be = ld4(beta + q * 4);
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+        const int t = tl + i * TL;
+        if (t < T) {
+            f32x4 o;
+            o.x = (keep[i].x - mu.x) * rs.x * ga.x + be.x;
+            o.y = (keep[i].y - mu.y) * rs.y * ga.y + be.y;
+            o.z = (keep[i].z - mu.z) * rs.z * ga.z + be.z;
+            o.w = (keep[i].w - mu.w) * rs.w * ga.w + be.w;
+            st4(y + base + t * tstride + q * 4, o);
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------
 // conv_in: x*(1-obs)+x0*obs, indicator channel = obs, 3x3 pad-1 conv, channels-last output.
 // Thread = (pixel, quad of 4 output channels); weights [(C+1)*9][Cout] in LDS.
@@ -220,9 +309,11 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [k = ci*9+tap][Cout]
     const int Ci = C + 1;
     const int K = Ci * 9;
+    // w is OIHW = [co][k]; consecutive threads take consecutive co, so the LDS writes are bank-conflict free (walking
+    // k fastest put every write of a wave into one bank: stride Cout)
     for (int i = threadIdx.x; i < K * Cout; i += blockDim.x) {
-        const int co = i / K, k = i - co * K;  // w is OIHW: [co][ci][tap]
-        wl[k * Cout + co] = w[i];
+        const int k = i / Cout, co = i - k * Cout;
+        wl[i] = w[(size_t)co * K + k];
     }
     __syncthreads();
     const int QC = Cout / 4;
@@ -424,8 +515,28 @@ extern "C" int lfvdm_gn_temporal(const float* x, const float* gamma, const float
                                  int P, int C, void* stream) {
     if (B <= 0 || T <= 0 || P <= 0 || C % 32 || C > GT_MAXC) return LFVDM_E_SHAPE;
     const long samples = (long)B * P;
-    hipLaunchKernelGGL(gn_temporal_kernel, dim3((unsigned)((samples + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                       beta, eps, y, B, T, P, C);
+    const dim3 grid((unsigned)((samples + 3) / 4));
+    const int Q = C / 4;
+    if (Q <= 64 && 64 % Q == 0) {           // register-resident sample: frames per lane = ceil(T / (64 / Q))
+        const int per_lane = (T + 64 / Q - 1) / (64 / Q);
+        hipStream_t s = (hipStream_t)stream;
+        if (per_lane <= 8) {
+            hipLaunchKernelGGL(gn_temporal_reg_kernel<8>, grid, dim3(256), 0, s, x, gamma, beta, eps, y, B, T, P, C);
+            LFVDM_CHECK_LAUNCH();
+            return LFVDM_OK;
+        }
+        if (per_lane <= 16) {
+            hipLaunchKernelGGL(gn_temporal_reg_kernel<16>, grid, dim3(256), 0, s, x, gamma, beta, eps, y, B, T, P, C);
+            LFVDM_CHECK_LAUNCH();
+            return LFVDM_OK;
+        }
+        if (per_lane <= 32) {
+            hipLaunchKernelGGL(gn_temporal_reg_kernel<32>, grid, dim3(256), 0, s, x, gamma, beta, eps, y, B, T, P, C);
+            LFVDM_CHECK_LAUNCH();
+            return LFVDM_OK;
+        }
+    }
+    hipLaunchKernelGGL(gn_temporal_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, y, B, T, P, C);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -5,7 +5,8 @@ bracketed by two q_sample launches that serve as markers in the dispatch list.
     cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/pmc_target.py
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/pmc_target.py
-    python3 tools/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python3 tools/pmc_target.py
+    python3 tools/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_pmc_traffic.json gpurun_out/pmc_mfma
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
