@@ -32,6 +32,8 @@ def _p(t):
 FUSED_GN = os.environ.get("LFVDM_FUSED_GN", "0") == "1"
 # LFVDM_GN_EPILOGUE=0: never evaluate a GroupNorm in the epilogue of the GEMM that produces its input (A/B aid)
 GN_EPILOGUE = os.environ.get("LFVDM_GN_EPILOGUE", "1") != "0"
+# LFVDM_NEXT_GN_EPILOGUE=0: never evaluate the NEXT ResBlock's first GroupNorm in a producer's epilogue (A/B aid)
+NEXT_GN_EPILOGUE = os.environ.get("LFVDM_NEXT_GN_EPILOGUE", "1") != "0"
 
 
 class Plan:
@@ -281,14 +283,19 @@ class Plan:
                  N, Cx, H, W, ch)
         cur = dict(parts=[(h0, ch)], H=H, W=W)
         hs = [cur]
-        for blk in list(m.input_blocks)[1:]:
-            cur = self._stage(blk, cur)
-            hs.append(cur)
-        cur = self._stage(m.middle_block, cur)
+        stages = list(m.input_blocks)[1:] + [m.middle_block]
+        for i, blk in enumerate(stages):
+            # the layer that consumes this stage's output (when it is not a concat): lets the stage's last GEMM
+            # evaluate that layer's first GroupNorm + SiLU in its epilogue at the low-resolution levels
+            nxt = stages[i + 1][0] if i + 1 < len(stages) else None
+            cur = self._stage(blk, cur, after=nxt)
+            if blk is not m.middle_block:
+                hs.append(dict(parts=cur["parts"], H=cur["H"], W=cur["W"]))      # (the skip carries no pre-activation)
         for blk in m.output_blocks:
             skip = hs.pop()
             assert skip["H"] == cur["H"] and len(cur["parts"]) == 1 and len(skip["parts"]) == 1
             cur = self._stage(blk, dict(parts=cur["parts"] + skip["parts"], H=cur["H"], W=cur["W"]))
+            cur.pop("act1", None)
         # head: GN + SiLU + 3x3 conv straight into the (B,T,C,H,W) layout
         (hb, hc), = cur["parts"]
         gn, conv = m.out[0], m.out[2]
@@ -304,22 +311,35 @@ class Plan:
             self.add_conv(src0=act, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv.weight), bias=conv.bias,
                           Cout=m.out_channels, out=self.out, ldo=m.out_channels, out_mode=nat.OUT_NCHW)
 
-    def _stage(self, blk, cur):
+    def _stage(self, blk, cur, after=None):
         from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
-        for layer in blk:
+        layers = list(blk)
+        for i, layer in enumerate(layers):
+            nxt = layers[i + 1] if i + 1 < len(layers) else after
+            ngn = nxt.in_layers[0] if (isinstance(nxt, ResBlock) and NEXT_GN_EPILOGUE and not FUSED_GN) else None
             if isinstance(layer, ResBlock):
-                cur = self._res(layer, cur)
+                cur = self._res(layer, cur, ngn)
             elif isinstance(layer, FactorizedAttentionBlock):
-                cur = self._attn(layer, cur)
+                cur = self._attn(layer, cur, ngn)
             elif isinstance(layer, Downsample):
-                cur = self._resample(layer.op, cur, down=True)
+                cur = self._resample(layer.op, cur, True, ngn)
             elif isinstance(layer, Upsample):
-                cur = self._resample(layer.conv, cur, down=False)
+                cur = self._resample(layer.conv, cur, False, None)
             else:
                 raise NotImplementedError(type(layer))
         return cur
 
-    def _res(self, rb, cur):
+    def _final_conv(self, kw, next_gn, M):
+        """Add a layer's last GEMM; if the consumer is a ResBlock, try to evaluate its first GroupNorm + SiLU in the
+        epilogue (whole samples per tile: maps of <= 64 pixels) -> the pre-activated tensor, or None."""
+        if next_gn is not None and next_gn.weight.shape[0] == kw["Cout"]:
+            actn = self.scratch("actn", M, kw["Cout"])
+            if self.conv_fused_gn(gn=next_gn, gn_out=actn, gn_act=nat.ACT_SILU, gn_skip_raw=0, **kw):
+                return actn
+        self.add_conv(**kw)
+        return None
+
+    def _res(self, rb, cur, next_gn=None):
         L = nat.lib()
         N, H, W = self.B * self.T, cur["H"], cur["W"]
         P = H * W
@@ -348,7 +368,9 @@ class Plan:
         else:
             # GroupNorm(+FiLM)+SiLU evaluated ONCE into a scratch tensor (the concat of the two sources becomes
             # real); the implicit GEMMs then stage raw operands (see lfvdm_gn_apply for why this wins on gfx950)
-            act1 = self.gn_apply(a, b, C0, C1, N, P, gn1, None, nat.ACT_SILU, "act1")
+            act1 = cur.get("act1")          # already evaluated by the producer's epilogue?
+            if act1 is None:
+                act1 = self.gn_apply(a, b, C0, C1, N, P, gn1, None, nat.ACT_SILU, "act1")
             c1 = dict(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight), bias=conv1.bias,
                       Cout=Cout, out=h1, ldo=Cout)
             # low-resolution levels: GroupNorm-2 + FiLM + SiLU in the epilogue of conv1 (whole samples per tile);
@@ -365,10 +387,13 @@ class Plan:
         else:
             sk = rb.skip_connection
             kw.update(s2src0=a, s2src1=b, s2C0=C0, s2C1=C1, W2=sk.weight, bias2=sk.bias)
-        self.add_conv(**kw)
-        return dict(parts=[(out, Cout)], H=H, W=W)
+        nact = self._final_conv(kw, next_gn, N * P)
+        res = dict(parts=[(out, Cout)], H=H, W=W)
+        if nact is not None:
+            res["act1"] = nact
+        return res
 
-    def _attn(self, ab, cur):
+    def _attn(self, ab, cur, next_gn=None):
         L = nat.lib()
         B, T = self.B, self.T
         N, H, W = B * T, cur["H"], cur["W"]
@@ -422,21 +447,27 @@ class Plan:
         if FUSED_GN:
             self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
                           bias=sa.proj_out.bias, Cout=Cc, res=yt, ldr=Cc, resA=self.s_cA, resB=self.s_cB, out=ys, ldo=Cc)
-        else:
-            self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
-                          bias=sa.proj_out.bias, Cout=Cc, res=ysn, ldr=Cc, out=ys, ldo=Cc)
-        return dict(parts=[(ys, Cc)], H=H, W=W)
+            return dict(parts=[(ys, Cc)], H=H, W=W)
+        nact = self._final_conv(dict(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
+                                     bias=sa.proj_out.bias, Cout=Cc, res=ysn, ldr=Cc, out=ys, ldo=Cc), next_gn, M)
+        res = dict(parts=[(ys, Cc)], H=H, W=W)
+        if nact is not None:
+            res["act1"] = nact
+        return res
 
-    def _resample(self, conv, cur, down):
+    def _resample(self, conv, cur, down, next_gn=None):
         if not isinstance(conv, nn.Conv2d):
             raise NotImplementedError("conv_resample=False (pooling) is not on the native path")
         N, H, W = self.B * self.T, cur["H"], cur["W"]
         (x, Cc), = cur["parts"]
         Ho, Wo = (((H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1) if down else (2 * H, 2 * W))
         out = self.buf(N * Ho * Wo, Cc)
-        self.add_conv(src0=x, C0=Cc, N=N, Hs=H, Ws=W, up=0 if down else 1, stride=2 if down else 1, Ho=Ho, Wo=Wo,
-                      W=self.packed(conv.weight), bias=conv.bias, Cout=Cc, out=out, ldo=Cc)
-        return dict(parts=[(out, Cc)], H=Ho, W=Wo)
+        nact = self._final_conv(dict(src0=x, C0=Cc, N=N, Hs=H, Ws=W, up=0 if down else 1, stride=2 if down else 1, Ho=Ho, Wo=Wo,
+                                     W=self.packed(conv.weight), bias=conv.bias, Cout=Cc, out=out, ldo=Cc), next_gn, N * Ho * Wo)
+        res = dict(parts=[(out, Cc)], H=Ho, W=Wo)
+        if nact is not None:
+            res["act1"] = nact
+        return res
 
     # ------------------------------------------------------------------ timestep tables (sampler plans)
     def build_time_tables(self, ts_table):
