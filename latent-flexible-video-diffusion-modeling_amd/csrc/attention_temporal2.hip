@@ -3,7 +3,7 @@
 //   logits[t][s] = q_t . (k_s + R_k[t][s]) + scale * k_s . R_q[s][t]     (q already scaled)
 //   o[t]         = sum_s softmax_s(logits + two-clique mask)[s] * (v_s + R_v[t][s])
 //
-// per (batch b, head h, pixel p); T <= 32 frames, head dim F in {16, 32} (others: the first kernel).  Same per-lane arithmetic as the first
+// per (batch b, head h, pixel p); T <= 32 frames, head dim F in {16, 32, 64} (others: the first kernel).  Same per-lane arithmetic as the first
 // kernel (attention.hip: a lane owns one (pixel, query frame) and all T logits, softmax without cross-lane traffic),
 // restructured around what that kernel measured as its limits on MI355X (tools/attn_bench.py):
 //   * the workgroup's operands - the R_k / R_q / R_v slices of its query frames and the k / v rows of its pixels - are
@@ -138,9 +138,9 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
     f32x4 q4[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) q4[u] = ld4(qrow + 4 * u) * scale;
-    // slot of (key s = sq + 4 i, quad u) in a row: c = NQ s + u = 4 NQ i + (NQ sq + u).  NQ = 4: the low four bits are
-    // NQ sq + u for every i; NQ = 8: they are 8 (sq & 1) + u, bit 4 is sq >> 1.  So the swizzled address is a per-lane base
-    // per quad (computed once) plus an immediate per i.
+    // slot of (key s = sq + 4 i, quad u) in a row: c = NQ s + u = 4 NQ i + (NQ sq + u), NQ a power of two >= 4: the low
+    // four bits of c are those of NQ sq + u for every i and the bits above them add without carry.  So the swizzled address
+    // is a per-lane base per quad (computed once) plus an immediate per i.
     constexpr int KQ = (TCAP + 3) / 4;                      // keys per lane
     constexpr int ISTRIDE = 4 * NQ * 4;                     // floats between consecutive i
     int kb[NQ], rbs[NQ];
@@ -148,7 +148,7 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
         const int jr = (active && g.dbg != 3) ? jw : 0, tr = (active && g.dbg != 3) ? tq : 0;   // dbg 3: every lane reads row 0
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
-            const int low = NQ == 4 ? 4 * sq + u : 8 * (sq & 1) + u, high = NQ == 4 ? 0 : 16 * (sq >> 1);
+            const int low = (NQ * sq + u) & 15, high = (NQ * sq + u) & ~15;
             kb[u] = (jr * 2 * RS + high + (low ^ (jr & 15))) * 4;
             rbs[u] = (tr * 3 * RS + high + (low ^ (tr & 15))) * 4;
         }
@@ -342,7 +342,11 @@ extern "C" void lfvdm_attn_temporal2_debug(int tg, int nw, int dbg) {
 int lfvdm_attn_temporal2_try(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
                              float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
     const int F = C / heads;
+    // Large launches (e.g. 16x16 maps at 128 channels, batch 2: 25.9 us vs 30) keep every CU busy in the first kernel
+    // too, which stages each R slice once per 12 pixels instead of once per 12 pixels AND frame group: use it there.
+    if ((long)B * P * F >= 16384 && g_t2_force_tg == 0) return LFVDM_E_UNSUPPORTED;
     if (F == 16) return launch_t2_f<16>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (F == 32) return launch_t2_f<32>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
+    if (F == 64) return launch_t2_f<64>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     return LFVDM_E_UNSUPPORTED;
 }

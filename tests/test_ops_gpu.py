@@ -356,7 +356,7 @@ def test_attn_temporal_backward(nat, B, T, P, Cc, heads):
 
 @pytest.mark.parametrize("B,T,P,Cc,heads", [(2, 20, 256, 64, 4), (2, 20, 64, 128, 4), (2, 20, 4, 128, 4), (1, 14, 256, 64, 4),
                                                    (1, 20, 33, 64, 4), (2, 17, 61, 32, 4), (3, 9, 130, 64, 2), (1, 32, 70, 128, 4),
-                                                   (2, 6, 300, 32, 2), (1, 20, 256, 128, 4)])
+                                                   (2, 6, 300, 32, 2), (1, 20, 256, 128, 4), (2, 20, 64, 256, 4), (1, 13, 21, 128, 2)])
 def test_attn_temporal_second_generation_kernel(nat, B, T, P, Cc, heads):
     """attention_temporal2.hip (LDS-DMA staged, frame groups, XCD-aware map; head dims 8 / 16 / 32) at the network's
     real map sizes and at ragged ones - partial strips, partial frame groups, batch 3 (plain block map) - vs the fp64

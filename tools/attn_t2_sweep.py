@@ -8,7 +8,7 @@ from improved_diffusion import _native as nat
 from attn_bench import timeit
 L = nat.lib()
 dev = th.device("cuda")
-shapes = [(2, 20, 256, 64, 4), (2, 20, 64, 128, 4), (2, 20, 4, 128, 4), (2, 20, 256, 128, 4), (1, 14, 256, 64, 4)]
+shapes = [(2, 20, 256, 64, 4), (2, 20, 64, 128, 4), (2, 20, 4, 128, 4), (2, 20, 256, 128, 4), (1, 14, 256, 64, 4), (2, 20, 64, 256, 4), (2, 20, 16, 256, 4)]
 cfgs = [(tg, nw) for tg in (2, 3, 4, 5) for nw in (1, 2, 4)]
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     shapes, cfgs = shapes[:3], [(4, 4), (4, 2), (5, 4)]
