@@ -164,6 +164,129 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
     }
 }
 
+// Both passes in ONE launch for the training path (same grid: a workgroup owns a (sample, 8 groups) slice, so nothing
+// crosses workgroups): pass 1 leaves the per-channel sums in LDS, the parameter / FiLM gradients go out as float atomics,
+// pass 2 re-reads the slice (L2-hot: this workgroup has just streamed it).  Saves a launch and the second ramp-up per
+// GroupNorm (36 per training micro-step); loads are issued four positions deep in both passes.
+__global__ __launch_bounds__(GB_THREADS) void gn_bwd_fused_kernel(
+    const float* __restrict__ da, const float* __restrict__ s0, const float* __restrict__ s1p, int C0, int C1, int P,
+    const float* __restrict__ coefA, const float* __restrict__ coefB, const float* __restrict__ stats, int act,
+    float* __restrict__ out0, float* __restrict__ out1, GnParamGradArgs pg) {
+    const int C = C0 + C1;
+    const int cg = C / 32;
+    const int CW = GB_GPW * cg;
+    const int Q = CW / 4;
+    const int n = blockIdx.x;
+    const int cbase = blockIdx.y * CW;
+    const int PL = GB_THREADS / Q;
+    const int tid = threadIdx.x;
+    const bool active = tid < PL * Q;
+    const int q = active ? tid % Q : 0;
+    const int pl = active ? tid / Q : 0;
+    const int c = cbase + q * 4;
+    __shared__ float part[2][GB_THREADS * 4];
+    __shared__ float chS[2][GB_GPW * 32];            // per-channel s1, s2 of the slice (cg <= 32)
+    __shared__ float gS1[GB_GPW], gS2[GB_GPW];
+
+    const f32x4 A = ld4(coefA + (size_t)n * C + c), B = ld4(coefB + (size_t)n * C + c);
+    f32x4 mu, rs;
+    const float* st = stats + (size_t)n * 64;
+    mu.x = st[2 * ((c + 0) / cg)]; rs.x = st[2 * ((c + 0) / cg) + 1];
+    mu.y = st[2 * ((c + 1) / cg)]; rs.y = st[2 * ((c + 1) / cg) + 1];
+    mu.z = st[2 * ((c + 2) / cg)]; rs.z = st[2 * ((c + 2) / cg) + 1];
+    mu.w = st[2 * ((c + 3) / cg)]; rs.w = st[2 * ((c + 3) / cg) + 1];
+    const size_t pos0 = (size_t)n * P;
+    const bool silu = act == LFVDM_ACT_SILU;
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (int p = pl; p < P; p += 4 * PL) {
+            f32x4 x[4], dz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = min(p + u * PL, P - 1);
+                x[u] = ldcat(s0, s1p, C0, C1, pos0 + pp, c);
+                dz[u] = ld4(da + (pos0 + pp) * C + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p + u * PL < P) {
+                    if (silu) {
+                        const f32x4 z = x[u] * A + B;
+                        dz[u].x *= dsilu(z.x); dz[u].y *= dsilu(z.y); dz[u].z *= dsilu(z.z); dz[u].w *= dsilu(z.w);
+                    }
+                    a1 += dz[u];
+                    a2 += dz[u] * ((x[u] - mu) * rs);
+                }
+            }
+        }
+        st4(part[0] + (pl * Q + q) * 4, a1);
+        st4(part[1] + (pl * Q + q) * 4, a2);
+    }
+    __syncthreads();
+    for (int cc = tid; cc < CW; cc += GB_THREADS) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int i = 0; i < PL; ++i) { t1 += part[0][i * CW + cc]; t2 += part[1][i * CW + cc]; }
+        chS[0][cc] = t1;
+        chS[1][cc] = t2;
+        const int ch = cbase + cc;
+        float sc1 = 1.0f;
+        if (pg.film != nullptr) {
+            const int b = n / pg.T;
+            sc1 += pg.film[(size_t)b * pg.film_ld + ch];
+            atomicAdd(pg.dfilm + (size_t)b * pg.dfilm_ld + ch, t2 * pg.gamma[ch] + t1 * pg.beta[ch]);
+            atomicAdd(pg.dfilm + (size_t)b * pg.dfilm_ld + C + ch, t1);
+        }
+        atomicAdd(pg.dgamma + ch, t2 * sc1);
+        atomicAdd(pg.dbeta + ch, t1 * sc1);
+    }
+    __syncthreads();
+    if (tid < GB_GPW) {
+        const int g = blockIdx.y * GB_GPW + tid;
+        const float rstd = stats[((size_t)n * 32 + g) * 2 + 1];
+        float S1 = 0.f, S2 = 0.f;
+        for (int i = 0; i < cg; ++i) {
+            const float gp = coefA[(size_t)n * C + g * cg + i] / rstd;   // g' = A / rstd (rstd > 0)
+            S1 += gp * chS[0][tid * cg + i];
+            S2 += gp * chS[1][tid * cg + i];
+        }
+        const float inv = 1.0f / (float)(cg * P);
+        gS1[tid] = S1 * inv;
+        gS2[tid] = S2 * inv;
+    }
+    __syncthreads();
+    if (!active) return;
+    f32x4 S1, S2;
+    S1.x = gS1[(q * 4 + 0) / cg]; S2.x = gS2[(q * 4 + 0) / cg];
+    S1.y = gS1[(q * 4 + 1) / cg]; S2.y = gS2[(q * 4 + 1) / cg];
+    S1.z = gS1[(q * 4 + 2) / cg]; S2.z = gS2[(q * 4 + 2) / cg];
+    S1.w = gS1[(q * 4 + 3) / cg]; S2.w = gS2[(q * 4 + 3) / cg];
+    const bool first = c < C0;
+    float* out = first ? out0 : out1;
+    const int Cd = first ? C0 : C1;
+    const int cd = first ? c : c - C0;
+    for (int p = pl; p < P; p += 4 * PL) {
+        f32x4 x[4], dz[4], ad[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pp = min(p + u * PL, P - 1);
+            x[u] = ldcat(s0, s1p, C0, C1, pos0 + pp, c);
+            dz[u] = ld4(da + (pos0 + pp) * C + c);
+            ad[u] = pg.add != nullptr ? ld4(pg.add + (pos0 + pp) * pg.add_ld + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p + u * PL < P) {
+                if (silu) {
+                    const f32x4 z = x[u] * A + B;
+                    dz[u].x *= dsilu(z.x); dz[u].y *= dsilu(z.y); dz[u].z *= dsilu(z.z); dz[u].w *= dsilu(z.w);
+                }
+                const f32x4 xh = (x[u] - mu) * rs;
+                st4(out + (pos0 + p + u * PL) * Cd + cd, A * dz[u] - rs * (S1 + xh * S2) + ad[u]);
+            }
+        }
+    }
+}
+
 // temporal GroupNorm backward (rpe.py:135-137): sample = (b, pixel), elements [T][C/32-group]; one wave per sample.
 // y = (x-mean)*rstd*gamma + beta.  Writes dx and accumulates dgamma/dbeta with atomics.
 constexpr int GTB_MAXC = 512;
@@ -380,6 +503,24 @@ extern "C" int lfvdm_gn_bwd_apply_params(const float* da, const float* src0, con
     const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1, add, add_ld};
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
                        C0, C1, P, coefA, coefB, stats, sums, act, out0, out1, acc0, acc1, pg);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_bwd_fused(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                                  const float* coefA, const float* coefB, const float* stats, int act, float* out0,
+                                  float* out1, const float* gamma, const float* beta, const float* film, int film_ld, int T,
+                                  float* dgamma, float* dbeta, float* dfilm, int dfilm_ld, const float* add, int add_ld,
+                                  void* stream) {
+    const int C = C0 + C1;
+    if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
+    if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
+    if (!dgamma || !dbeta) return LFVDM_E_SHAPE;
+    if (add && (add_ld < C || add_ld % 4)) return LFVDM_E_SHAPE;
+    if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T || film_ld < 2 * C || dfilm_ld < 2 * C)) return LFVDM_E_SHAPE;
+    const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1, add, add_ld};
+    hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
+                       C0, C1, P, coefA, coefB, stats, act, out0, out1, pg);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

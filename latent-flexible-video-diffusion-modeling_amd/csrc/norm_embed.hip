@@ -398,72 +398,125 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const lfvdm_rowdot_job* __r
 // Backward of the grouped small-M linears: one wave per block of RDB_ROWS output rows of one job.
 //   dW[o][k] += sum_m dout[m][o] * actin(in[m][k]);  db[o] += sum_m dout[m][o];
 //   din[m][k] += sum_o dout[m][o] * W[o][k]        (gradient w.r.t. the ACTIVATED input; float atomics, may be NULL)
-// Every W row is read once; the din partial of the wave's rows lives in registers and is added once per wave.
-constexpr int RDB_ROWS = 8;    // rows per wave: the dW read-modify-write chain of a wave is serial, so keep it short
+// Every W row is read once.  din is tiny (M x K) and EVERY wave of a job adds to it: done per wave that is ~1250 waves
+// hammering the same 1024 addresses (measured 63 us per launch, all of it atomic contention).  So a workgroup walks
+// RDB_TPW tasks per wave, keeps its din partial in registers across them, sums the partials of its four waves in LDS
+// and issues ONE set of atomics - 16x fewer.  (Workgroups whose tasks span two jobs fall back to per-task atomics.)
+constexpr int RDB_ROWS = 8;    // rows per wave and task: the dW read-modify-write chain of a wave is serial, so keep it short
+constexpr int RDB_TPW = 4;     // tasks per wave
+constexpr int RDB_KIT = 4;     // K <= 1024 on the grouped path (256 floats per lane sweep)
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_job* __restrict__ jobs, int njobs, int total_tasks) {
+    __shared__ f32x4 red[3][4][RDB_KIT][64];         // waves 1..3 -> wave 0: [wave - 1][m][k sweep][lane]
     const int lane = threadIdx.x & 63;
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= total_tasks) return;
-    int j = 0;
-    while (j + 1 < njobs && jobs[j + 1].task0 <= task) ++j;
-    const lfvdm_rowdot_bwd_job J = jobs[j];
-    const int o0 = (task - J.task0) * RDB_ROWS;
-    const int o1 = min(o0 + RDB_ROWS, J.O);
-    for (int m0 = 0; m0 < J.M; m0 += 4) {
-        const int mc = min(4, J.M - m0);
-        for (int k = lane * 4; k < J.K; k += 256) {
-            f32x4 inv[4], accD[4];
+    const int wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * (4 * RDB_TPW);
+    const int last = min(first + 4 * RDB_TPW, total_tasks) - 1;
+    int jf = 0, jl = 0;
+    while (jf + 1 < njobs && jobs[jf + 1].task0 <= first) ++jf;
+    while (jl + 1 < njobs && jobs[jl + 1].task0 <= last) ++jl;
+    const lfvdm_rowdot_bwd_job J0 = jobs[jf];
+    const bool grouped = jf == jl && J0.din != nullptr && J0.M <= 4 && J0.K <= 256 * RDB_KIT;   // workgroup-uniform
+    f32x4 accG[4][RDB_KIT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                accD[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                inv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (i < mc) {
-                    if (J.in_mode == 2) {
-                        const float t = J.in[m0 + i];
-                        const float* fr = J.in + J.ldin;
-                        const int half = J.K >> 1;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int kk = k + u;
-                            inv[i][u] = kk < half ? cosf(t * fr[kk]) : sinf(t * fr[kk - half]);
+        for (int it = 0; it < RDB_KIT; ++it) accG[i][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RDB_TPW; ++r) {
+        const int task = first + wave + 4 * r;
+        if (task >= total_tasks) break;
+        int j = jf;
+        while (j + 1 < njobs && jobs[j + 1].task0 <= task) ++j;
+        const lfvdm_rowdot_bwd_job J = jobs[j];
+        const int o0 = (task - J.task0) * RDB_ROWS;
+        const int o1 = min(o0 + RDB_ROWS, J.O);
+        for (int m0 = 0; m0 < J.M; m0 += 4) {
+            const int mc = min(4, J.M - m0);
+            int it = 0;
+            for (int k = lane * 4; k < J.K; k += 256, ++it) {
+                f32x4 inv[4], accD[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    accD[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    inv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (i < mc) {
+                        if (J.in_mode == 2) {
+                            const float t = J.in[m0 + i];
+                            const float* fr = J.in + J.ldin;
+                            const int half = J.K >> 1;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int kk = k + u;
+                                inv[i][u] = kk < half ? cosf(t * fr[kk]) : sinf(t * fr[kk - half]);
+                            }
+                        } else {
+                            f32x4 v = ld4(J.in + (size_t)(m0 + i) * J.ldin + k);
+                            if (J.in_mode == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                            inv[i] = v;
                         }
-                    } else {
-                        f32x4 v = ld4(J.in + (size_t)(m0 + i) * J.ldin + k);
-                        if (J.in_mode == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                        inv[i] = v;
                     }
                 }
-            }
-            for (int o = o0; o < o1; ++o) {
-                const f32x4 wv = ld4(J.W + (size_t)o * J.K + k);
-                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                for (int o = o0; o < o1; ++o) {
+                    const f32x4 wv = ld4(J.W + (size_t)o * J.K + k);
+                    f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < mc) {
-                        const float d = J.dout[(size_t)(m0 + i) * J.lddout + o];
-                        g += inv[i] * d;
-                        accD[i] += wv * d;
+                    for (int i = 0; i < 4; ++i) {
+                        if (i < mc) {
+                            const float d = J.dout[(size_t)(m0 + i) * J.lddout + o];
+                            g += inv[i] * d;
+                            accD[i] += wv * d;
+                        }
                     }
+                    float* gw = J.dW + (size_t)o * J.K + k;
+                    st4(gw, ld4(gw) + g);
                 }
-                float* gw = J.dW + (size_t)o * J.K + k;
-                st4(gw, ld4(gw) + g);
-            }
-            if (J.din) {
+                if (grouped) {                       // (M <= 4: a single m0 pass; `it` < RDB_KIT)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < mc) {
-                        float* dst = J.din + (size_t)(m0 + i) * J.lddin + k;
-                        atomicAdd(dst + 0, accD[i].x); atomicAdd(dst + 1, accD[i].y);
-                        atomicAdd(dst + 2, accD[i].z); atomicAdd(dst + 3, accD[i].w);
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < RDB_KIT; ++q)
+                            if (q == it) accG[i][q] += accD[i];
+                } else if (J.din) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i < mc) {
+                            float* dst = J.din + (size_t)(m0 + i) * J.lddin + k;
+                            atomicAdd(dst + 0, accD[i].x); atomicAdd(dst + 1, accD[i].y);
+                            atomicAdd(dst + 2, accD[i].z); atomicAdd(dst + 3, accD[i].w);
+                        }
                     }
                 }
             }
         }
+        if (J.db && lane < o1 - o0) {
+            float t = 0.f;
+            for (int m = 0; m < J.M; ++m) t += J.dout[(size_t)m * J.lddout + o0 + lane];
+            J.db[o0 + lane] += t;
+        }
     }
-    if (J.db && lane < o1 - o0) {
-        float t = 0.f;
-        for (int m = 0; m < J.M; ++m) t += J.dout[(size_t)m * J.lddout + o0 + lane];
-        J.db[o0 + lane] += t;
+    if (!grouped) return;                            // workgroup-uniform: no barrier is skipped by part of the workgroup
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < RDB_KIT; ++q) red[wave - 1][i][q][lane] = accG[i][q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < RDB_KIT; ++q) {
+            const int k = lane * 4 + 256 * q;
+            if (k < J0.K) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < J0.M) {
+                        const f32x4 t = accG[i][q] + red[0][i][q][lane] + red[1][i][q][lane] + red[2][i][q][lane];
+                        float* dst = J0.din + (size_t)i * J0.lddin + k;
+                        atomicAdd(dst + 0, t.x); atomicAdd(dst + 1, t.y);
+                        atomicAdd(dst + 2, t.z); atomicAdd(dst + 3, t.w);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -471,8 +524,8 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_
 
 extern "C" int lfvdm_rowdot_bwd(const lfvdm_rowdot_bwd_job* jobs_dev, int njobs, int total_tasks, void* stream) {
     if (!jobs_dev || njobs <= 0 || total_tasks <= 0) return LFVDM_E_SHAPE;
-    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((total_tasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs,
-                       total_tasks);
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((total_tasks + 4 * RDB_TPW - 1) / (4 * RDB_TPW)), dim3(256), 0, (hipStream_t)stream,
+                       jobs_dev, njobs, total_tasks);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

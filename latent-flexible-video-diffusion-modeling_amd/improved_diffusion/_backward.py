@@ -368,25 +368,25 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
     """Returns (dx_a, dx_b, dgamma, dbeta, dfilm).  da: [N*P][C] gradient w.r.t. act(GN(x)).  add: optional
     [N*P][C] rows (a second gradient of the same input) folded into dx by the in-place kernel."""
     C = C0 + C1
-    sums = _new(N, C, 2, like=da)
     L = nat.lib()
-    nat.check(L.lfvdm_gn_bwd_stats(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
-                                   act, nat.ptr(sums), nat.stream()), "lfvdm_gn_bwd_stats")
     dxa = _new(N * P, C0, like=da)
     dxb = _new(N * P, C1, like=da) if C1 else None
     if inplace:
-        # dx and the parameter gradients in ONE launch (float atomics into .grad / the FiLM gradient slot)
+        # statistics, dx and the parameter gradients in ONE launch (float atomics into .grad / the FiLM gradient slot)
         dfilm = None
         if film is not None:       # accumulated into the caller's (zeroed) slot of the embedding network's gradient buffer
             dfilm = dfilm_out if dfilm_out is not None else th.zeros(N // T, 2 * C, device=da.device, dtype=th.float32)
-        nat.check(L.lfvdm_gn_bwd_apply_params(
-            nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats), nat.ptr(sums), act,
-            nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.ptr(gamma), nat.ptr(beta),
+        nat.check(L.lfvdm_gn_bwd_fused(
+            nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats), act,
+            nat.ptr(dxa), nat.ptr(dxb), nat.ptr(gamma), nat.ptr(beta),
             film.data_ptr() if film is not None else None, film.stride(0) if film is not None else 0, T,
             nat.ptr(_grad_of(gamma)), nat.ptr(_grad_of(beta)), dfilm.data_ptr() if dfilm is not None else None,
             dfilm.stride(0) if dfilm is not None else 0, nat.ptr(add), add.stride(0) if add is not None else 0,
-            nat.stream()), "lfvdm_gn_bwd_apply_params")
+            nat.stream()), "lfvdm_gn_bwd_fused")
         return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
+    sums = _new(N, C, 2, like=da)
+    nat.check(L.lfvdm_gn_bwd_stats(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
+                                   act, nat.ptr(sums), nat.stream()), "lfvdm_gn_bwd_stats")
     nat.check(L.lfvdm_gn_bwd_apply(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
                                    nat.ptr(sums), act, nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.stream()), "lfvdm_gn_bwd_apply")
     if add is not None:
