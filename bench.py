@@ -586,8 +586,9 @@ def main():
             out["cpu_baseline"]["one_thread"] = cpu_baseline_sample(model, inputs, B, T, 1, 5.0)
             out["cpu_baseline"]["train"] = cpu_baseline_train(cores, 8.0)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():            # (the training leg initialises a world-1 group too)
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

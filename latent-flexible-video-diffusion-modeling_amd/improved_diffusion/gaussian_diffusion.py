@@ -532,7 +532,8 @@ class GraphSampler:
                     self._step_body()
                 th.cuda.current_stream().wait_stream(s)
                 g = th.cuda.CUDAGraph()
-                with th.cuda.graph(g):
+                # thread-local capture: a process group's watchdog thread may query events while this thread captures
+                with th.cuda.graph(g, capture_error_mode="thread_local"):
                     self._step_body()
                 self.graph = g
                 pl.x_in.copy_(saved)

@@ -364,7 +364,8 @@ class TrainLoop:
                 st["static_in"] = [x.clone() for x in inputs]
             th.cuda.synchronize()
             g = th.cuda.CUDAGraph()
-            with th.cuda.graph(g):
+            # thread-local capture: the RCCL watchdog thread queries the events of earlier collectives meanwhile
+            with th.cuda.graph(g, capture_error_mode="thread_local"):
                 st["static_out"] = body(*st["static_in"])
             st["graph"] = g
             # the capture itself does not execute: run the step for real below

@@ -497,9 +497,11 @@ def test_gn_apply(nat, N, P, C0, C1, film, act):
     close(F.silu(pre) if act else pre, ref.float(), 5e-5)
 
 
-def test_rowdot_backward(nat):
-    """lfvdm_rowdot_bwd (grouped nn.Linear backward) vs autograd: two jobs sharing one input, one with SiLU in front."""
-    M, K = 3, 256
+@pytest.mark.parametrize("M,K", [(3, 256), (2, 1024), (6, 512)])
+def test_rowdot_backward(nat, M, K):
+    """lfvdm_rowdot_bwd (grouped nn.Linear backward) vs autograd: two jobs sharing one input, one with SiLU in front.
+    The 17 tasks make one workgroup that spans both jobs (per-task atomics) and one inside a job (workgroup-level sum of the
+    input-gradient partials); M = 6 takes the path for more than four batch rows."""
     x = rnd("rb/x", M, K)
     Ws = [0.1 * rnd("rb/w0", 96, K), 0.1 * rnd("rb/w1", 40, K)]
     douts = [rnd("rb/d0", M, 96), rnd("rb/d1", M, 40)]
