@@ -152,6 +152,165 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
 }
 
 // -------------------------------------------------------------------------------------
+// Large maps (P > 8 pixel lanes' worth: pixel space, 32x32 latents): the (sample, 8 groups) decomposition above gives
+// N*4 workgroups that each walk their whole slice three times, one load at a time - 80 workgroups streaming 2 MB each at
+// 128x128 (1-2 ms per GroupNorm, a third of the pixel-space step).  Here a workgroup owns a CHUNK of 8*PL positions of
+// the slice, held in registers:
+//   pass 1 (gn_chunk_stats_kernel): exact two-pass (mean, M2) of the chunk per group -> part[n][g][s] = (mean_s, M2_s)
+//   pass 2 (gn_chunk_apply_kernel): every workgroup combines the S partials of its 8 groups in a fixed order
+//     mean = sum n_s mean_s / n,  M2 = sum (M2_s + n_s (mean_s - mean)^2)      (Chan et al.; as exact as the two-pass)
+//   and applies the affine (+FiLM)(+activation) to its chunk, whose loads were issued before the combination.
+// Deterministic; x is read twice and written once by thousands of workgroups.
+// -------------------------------------------------------------------------------------
+constexpr int GN_KEEP = 8;
+
+struct GnChunkGeom { int C0, C1, P, S, PL; };
+
+__device__ __forceinline__ void gn_chunk_load(const float* s0, const float* s1, const GnChunkGeom& g, size_t pos0, int p_first,
+                                              int pl, int c, f32x4 (&keep)[GN_KEEP]) {
+#pragma unroll
+    for (int i = 0; i < GN_KEEP; ++i) {
+        const int p = p_first + pl + i * g.PL;
+        keep[i] = ld_cat(s0, s1, g.C0, g.C1, pos0 + min(p, g.P - 1), c);
+    }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_chunk_stats_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                                    GnChunkGeom g, float* __restrict__ part_out) {
+    const int C = g.C0 + g.C1, cg = C / 32, CW = GN_GPW * cg, Q = CW / 4, PL = g.PL;
+    const int sidx = blockIdx.x, n = blockIdx.z, cbase = blockIdx.y * CW;
+    const int tid = threadIdx.x;
+    const bool active = tid < PL * Q;
+    const int q = active ? tid % Q : 0, pl = active ? tid / Q : 0;
+    const int c = cbase + q * 4;
+    const int p_first = sidx * (GN_KEEP * PL);
+    const int npos = min(GN_KEEP * PL, g.P - p_first);
+    __shared__ float part[GN_THREADS * 4];
+    __shared__ float chs[GN_MAXCW];
+    __shared__ float gmean[GN_GPW];
+    f32x4 keep[GN_KEEP];
+    gn_chunk_load(s0, s1, g, (size_t)n * g.P, p_first, pl, c, keep);
+    for (int pass = 0; pass < 2; ++pass) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            f32x4 mu = {0.f, 0.f, 0.f, 0.f};
+            if (pass) {
+                mu.x = gmean[(q * 4 + 0) / cg]; mu.y = gmean[(q * 4 + 1) / cg];
+                mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg];
+            }
+#pragma unroll
+            for (int i = 0; i < GN_KEEP; ++i) {
+                if (pl + i * PL < npos) {
+                    if (pass == 0) { s += keep[i]; } else { const f32x4 v = keep[i] - mu; s += v * v; }
+                }
+            }
+            st4(part + (pl * Q + q) * 4, s);
+        }
+        __syncthreads();
+        for (int cc = tid; cc < CW; cc += GN_THREADS) {
+            float t = 0.f;
+            for (int i = 0; i < PL; ++i) t += part[i * CW + cc];
+            chs[cc] = t;
+        }
+        __syncthreads();
+        if (tid < GN_GPW) {
+            float t = 0.f;
+            for (int i = 0; i < cg; ++i) t += chs[tid * cg + i];
+            float* o = part_out + (((size_t)n * 32 + blockIdx.y * GN_GPW + tid) * g.S + sidx) * 2;
+            if (pass == 0) { gmean[tid] = t / (float)(cg * npos); o[0] = gmean[tid]; }
+            else o[1] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_chunk_apply_kernel(
+    const float* __restrict__ s0, const float* __restrict__ s1, GnChunkGeom g, const float* __restrict__ part_in,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
+    int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats,
+    float* __restrict__ act_out, int act_mode) {
+    const int C = g.C0 + g.C1, cg = C / 32, CW = GN_GPW * cg, Q = CW / 4, PL = g.PL;
+    const int sidx = blockIdx.x, n = blockIdx.z, cbase = blockIdx.y * CW;
+    const int tid = threadIdx.x;
+    const bool active = tid < PL * Q;
+    const int q = active ? tid % Q : 0, pl = active ? tid / Q : 0;
+    const int c = cbase + q * 4;
+    const int PC = GN_KEEP * PL;
+    const int p_first = sidx * PC;
+    const int npos = min(PC, g.P - p_first);
+    __shared__ float gmean[GN_GPW], grstd[GN_GPW];
+    __shared__ __attribute__((aligned(16))) float shA[GN_MAXCW], shB[GN_MAXCW];
+    f32x4 keep[GN_KEEP];
+    gn_chunk_load(s0, s1, g, (size_t)n * g.P, p_first, pl, c, keep);       // in flight during the combination
+    {   // 32 lanes per group, fixed summation order
+        const int grp = tid >> 5, j = tid & 31;
+        const float* pp = part_in + ((size_t)n * 32 + blockIdx.y * GN_GPW + grp) * g.S * 2;
+        float sm = 0.f;
+        for (int s = j; s < g.S; s += 32) sm += (float)(cg * min(PC, g.P - s * PC)) * pp[2 * s];
+        for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        const float ntot = (float)cg * (float)g.P;
+        const float mean = sm / ntot;
+        float m2 = 0.f;
+        for (int s = j; s < g.S; s += 32) {
+            const float d = pp[2 * s] - mean;
+            m2 += pp[2 * s + 1] + (float)(cg * min(PC, g.P - s * PC)) * d * d;
+        }
+        for (int o = 16; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+        if (j == 0) {
+            gmean[grp] = mean;
+            grstd[grp] = 1.0f / sqrtf(m2 / ntot + eps);
+        }
+    }
+    __syncthreads();
+    if (stats && sidx == 0 && tid < GN_GPW) {
+        stats[((size_t)n * 32 + blockIdx.y * GN_GPW + tid) * 2 + 0] = gmean[tid];
+        stats[((size_t)n * 32 + blockIdx.y * GN_GPW + tid) * 2 + 1] = grstd[tid];
+    }
+    for (int cc = tid; cc < CW; cc += GN_THREADS) {
+        const int ch = cbase + cc;
+        const int gi = cc / cg;
+        float A = grstd[gi] * gamma[ch];
+        float B = beta[ch] - gmean[gi] * A;
+        if (film) {
+            const float* f = film + (size_t)(n / film_div) * film_ld;
+            const float sc = 1.0f + f[ch];
+            A *= sc;
+            B = B * sc + f[C + ch];
+        }
+        if (coefA && sidx == 0) {
+            coefA[(size_t)n * C + ch] = A;
+            coefB[(size_t)n * C + ch] = B;
+        }
+        shA[cc] = A;
+        shB[cc] = B;
+    }
+    if (act_out == nullptr) return;
+    __syncthreads();
+    if (active) {
+        const f32x4 a4 = ld4(shA + q * 4), b4 = ld4(shB + q * 4);
+        const size_t pos0 = (size_t)n * g.P + p_first;
+#pragma unroll
+        for (int i = 0; i < GN_KEEP; ++i) {
+            const int p = pl + i * PL;
+            if (p < npos) {
+                f32x4 v = keep[i] * a4 + b4;
+                if (act_mode == LFVDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                st4(act_out + (pos0 + p) * C + c, v);
+            }
+        }
+    }
+}
+
+// chunked decomposition for (C, P): chunks per slice (0 = the single-launch kernel holds the slice in registers)
+inline int gn_chunks(int C, int P, int* pl_out) {
+    const int Q = GN_GPW * (C / 32) / 4;
+    const int PL = GN_THREADS / Q;
+    if (pl_out) *pl_out = PL;
+    if (P <= GN_KEEP * PL) return 0;
+    return (P + GN_KEEP * PL - 1) / (GN_KEEP * PL);
+}
+
+// -------------------------------------------------------------------------------------
 // gn_temporal: one wave per (b, pixel); the sample is [T][C] with row stride P*C.
 // Writes the normalised rows (they are also the residual of the attention block).
 // -------------------------------------------------------------------------------------
@@ -553,6 +712,37 @@ extern "C" int lfvdm_gn_apply(const float* src0, const float* src1, int C0, int 
     if ((coefA == nullptr) != (coefB == nullptr)) return LFVDM_E_SHAPE;
     hipLaunchKernelGGL(gn_coef_kernel, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0, C1,
                        P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, out, act);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" long lfvdm_gn_apply_ws_floats(int C, int N, int P) {
+    if (C <= 0 || C % 32 || C > 1024 || N <= 0 || P <= 0) return 0;
+    const int S = gn_chunks(C, P, nullptr);
+    return (long)N * 32 * S * 2;
+}
+
+extern "C" int lfvdm_gn_apply_ws(const float* src0, const float* src1, int C0, int C1, int N, int P, const float* gamma,
+                                 const float* beta, const float* film, int film_div, int film_ld, float eps, int act,
+                                 float* out, float* coefA, float* coefB, float* stats, float* ws, long ws_floats,
+                                 void* stream) {
+    const int C = C0 + C1;
+    if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024 || !out) return LFVDM_E_SHAPE;
+    if (C1 > 0 && !src1) return LFVDM_E_SHAPE;
+    if (film && film_div <= 0) return LFVDM_E_SHAPE;
+    if ((coefA == nullptr) != (coefB == nullptr)) return LFVDM_E_SHAPE;
+    int PL = 0;
+    const int S = gn_chunks(C, P, &PL);
+    if (S == 0)
+        return lfvdm_gn_apply(src0, src1, C0, C1, N, P, gamma, beta, film, film_div, film_ld, eps, act, out, coefA, coefB, stats,
+                              stream);
+    if (!ws || ws_floats < (long)N * 32 * S * 2 || N > 65535) return LFVDM_E_SHAPE;
+    const GnChunkGeom g = {C0, C1, P, S, PL};
+    const dim3 grid(S, 32 / GN_GPW, N);
+    hipLaunchKernelGGL(gn_chunk_stats_kernel, grid, dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, g, ws);
+    LFVDM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_chunk_apply_kernel, grid, dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, g, (const float*)ws,
+                       gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, out, act);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

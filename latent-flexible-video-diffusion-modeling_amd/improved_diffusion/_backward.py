@@ -346,10 +346,13 @@ def _gn_apply(a, b, C0, C1, N, P, gamma, beta, film, T, act):
     C = C0 + C1
     out = _new(N * P, C, like=a)
     cA, cB, stats = _new(N, C, like=a), _new(N, C, like=a), _new(N, 32, 2, like=a)
-    nat.check(nat.lib().lfvdm_gn_apply(
+    L = nat.lib()
+    need = int(L.lfvdm_gn_apply_ws_floats(C, N, P))        # > 0: large map, chunked two-launch form
+    ws = _new(need, like=a) if need else None
+    nat.check(L.lfvdm_gn_apply_ws(
         nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(gamma), nat.ptr(beta), film.data_ptr() if film is not None else None,
         T if film is not None else 1, film.stride(0) if film is not None else 0, _EPS, act, nat.ptr(out), nat.ptr(cA),
-        nat.ptr(cB), nat.ptr(stats), nat.stream()), "lfvdm_gn_apply")
+        nat.ptr(cB), nat.ptr(stats), nat.ptr(ws), need, nat.stream()), "lfvdm_gn_apply_ws")
     return out, cA, cB, stats
 
 

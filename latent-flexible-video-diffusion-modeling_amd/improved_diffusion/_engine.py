@@ -74,9 +74,16 @@ class Plan:
 
     def gn_apply(self, a, b, C0, C1, N, P, gn, film, act, key):
         out = self.scratch(key, N * P, C0 + C1)
-        self.add(nat.lib().lfvdm_gn_apply, _p(a), _p(b) if b is not None else None, C0, C1, N, P, _p(gn.weight), _p(gn.bias),
-                 _p(film) if film is not None else None, self.T if film is not None else 1,
-                 self.rows_ld if film is not None else 0, gn.eps, act, _p(out), None, None, None)
+        L = nat.lib()
+        args = (_p(a), _p(b) if b is not None else None, C0, C1, N, P, _p(gn.weight), _p(gn.bias),
+                _p(film) if film is not None else None, self.T if film is not None else 1,
+                self.rows_ld if film is not None else 0, gn.eps, act, _p(out), None, None, None)
+        need = int(L.lfvdm_gn_apply_ws_floats(C0 + C1, N, P))
+        if need:        # large map: chunk statistics + apply over thousands of workgroups (see lfvdm_gn_apply_ws)
+            ws = self.scratch("gn_ws", 1, need)
+            self.add(L.lfvdm_gn_apply_ws, *args, _p(ws), need)
+        else:
+            self.add(L.lfvdm_gn_apply, *args)
         return out
 
     def packed(self, weight):
@@ -609,7 +616,7 @@ class Plan:
     @staticmethod
     def _reads_film(fn, args, film_ptrs):
         L = nat.lib()
-        if fn is L.lfvdm_gn_apply or fn is L.lfvdm_gn_coef:
+        if fn is L.lfvdm_gn_apply or fn is L.lfvdm_gn_apply_ws or fn is L.lfvdm_gn_coef:
             return args[8] in film_ptrs
         if fn is L.lfvdm_conv_igemm:
             return (args[0]._obj.gn_film or 0) in film_ptrs

@@ -497,6 +497,51 @@ def test_gn_apply(nat, N, P, C0, C1, film, act):
     close(F.silu(pre) if act else pre, ref.float(), 5e-5)
 
 
+@pytest.mark.parametrize("N,P,C0,C1,film,act", [(2, 2500, 96, 32, True, 1), (4, 1061, 64, 0, False, 1), (2, 4096, 128, 64, True, 1),
+                                                (3, 16384, 128, 0, False, 1), (2, 300, 512, 256, False, 0),
+                                                (4, 256, 64, 0, False, 1)])
+def test_gn_apply_large_maps(nat, N, P, C0, C1, film, act):
+    """lfvdm_gn_apply_ws: the chunked two-launch GroupNorm for maps whose (sample, 8 groups) slice exceeds one workgroup's
+    registers (chunk statistics + fixed-order combination), ragged last chunks and non-power-of-two channel quads included;
+    the last case fits and must take the single-launch kernel (workspace size 0)."""
+    C, T = C0 + C1, 2
+    a = rnd("gl/a", N * P, C0) * 1.3 + 0.7          # a mean well away from zero: a naive sum of squares would show
+    b = rnd("gl/b", N * P, C1) if C1 else None
+    gamma, beta = 1 + 0.1 * rnd("gl/g", C), 0.1 * rnd("gl/be", C)
+    fm = 0.3 * rnd("gl/film", N // T, 2 * C) if film else None
+    x = torch.cat([a] + ([b] if C1 else []), dim=1).double().view(N, P, C).permute(0, 2, 1)
+    ref = F.group_norm(x, 32, gamma.double(), beta.double(), eps=1e-5)
+    if film:
+        f = fm.double().repeat_interleave(T, dim=0)
+        ref = ref * (1 + f[:, :C, None]) + f[:, C:, None]
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(N * P, C)
+    L = nat.lib()
+    need = int(L.lfvdm_gn_apply_ws_floats(C, N, P))
+    assert (need == 0) == (P == 256)
+    ws = torch.full((max(need, 1),), float("nan"), device="cuda")
+    out = torch.full((N * P, C), float("nan"), device="cuda")
+    cA, cB, st = torch.empty(N, C, device="cuda"), torch.empty(N, C, device="cuda"), torch.empty(N, 32, 2, device="cuda")
+    g = [t.cuda() if t is not None else None for t in (a, b, gamma, beta, fm)]
+    args = (nat.ptr(g[0]), nat.ptr(g[1]), C0, C1, N, P, nat.ptr(g[2]), nat.ptr(g[3]), nat.ptr(g[4]), T if film else 1,
+            2 * C if film else 0, 1e-5, act, nat.ptr(out), nat.ptr(cA), nat.ptr(cB), nat.ptr(st))
+    nat.check(L.lfvdm_gn_apply_ws(*args, nat.ptr(ws), need, nat.stream()), "lfvdm_gn_apply_ws")
+    close(out, ref.float(), 3e-5)
+    grp = x.reshape(N, 32, -1)
+    close(st[..., 0], grp.mean(-1).float(), 1e-5)
+    close(st[..., 1], (1.0 / torch.sqrt(grp.var(-1, unbiased=False) + 1e-5)).float(), 1e-5)
+    # same values as the single-launch kernel (which walks the whole slice in one workgroup), and reproducible
+    out1 = torch.empty_like(out)
+    nat.check(L.lfvdm_gn_apply(*args[:13], nat.ptr(out1), None, None, None, nat.stream()), "lfvdm_gn_apply")
+    close(out, out1, 2e-6)
+    out2 = torch.empty_like(out)
+    nat.check(L.lfvdm_gn_apply_ws(*args[:13], nat.ptr(out2), None, None, None, nat.ptr(ws), need, nat.stream()), "lfvdm_gn_apply_ws")
+    assert torch.equal(out, out2)
+    if need:
+        assert L.lfvdm_gn_apply_ws(*args, None, 0, nat.stream()) != 0, "a missing workspace must be refused"
+
+
 @pytest.mark.parametrize("M,K", [(3, 256), (2, 1024), (6, 512)])
 def test_rowdot_backward(nat, M, K):
     """lfvdm_rowdot_bwd (grouped nn.Linear backward) vs autograd: two jobs sharing one input, one with SiLU in front.
