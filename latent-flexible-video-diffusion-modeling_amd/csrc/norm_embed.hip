@@ -557,19 +557,21 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const lfvdm_rowdot_job* __r
 // Backward of the grouped small-M linears: one wave per block of RDB_ROWS output rows of one job.
 //   dW[o][k] += sum_m dout[m][o] * actin(in[m][k]);  db[o] += sum_m dout[m][o];
 //   din[m][k] += sum_o dout[m][o] * W[o][k]        (gradient w.r.t. the ACTIVATED input; float atomics, may be NULL)
-// Every W row is read once.  din is tiny (M x K) and EVERY wave of a job adds to it: done per wave that is ~1250 waves
-// hammering the same 1024 addresses (measured 63 us per launch, all of it atomic contention).  So a workgroup walks
-// RDB_TPW tasks per wave, keeps its din partial in registers across them, sums the partials of its four waves in LDS
-// and issues ONE set of atomics - 16x fewer.  (Workgroups whose tasks span two jobs fall back to per-task atomics.)
+// Every W row is read once.  din is tiny (M x K) and EVERY wave of a job adds to it: done per wave that is ~1700 waves
+// hammering the same 1024 addresses (measured 63 us per launch, most of it atomic contention).  So the four waves of a
+// workgroup sum their din partials in LDS and issue ONE set of atomics: 31.8 us.  (More tasks per wave would cut the
+// atomics further but leaves too few workgroups for the dW read-modify-write stream: 2 tasks 44 us, 4 tasks 79 us.
+// Workgroups whose tasks span two jobs fall back to per-task atomics.)
 constexpr int RDB_ROWS = 8;    // rows per wave and task: the dW read-modify-write chain of a wave is serial, so keep it short
-constexpr int RDB_TPW = 4;     // tasks per wave
+constexpr int RDB_TPW = 4;     // tasks per wave: upper bound of the LFVDM_ROWDOT_TPW tuning aid; the launcher uses 1
 constexpr int RDB_KIT = 4;     // K <= 1024 on the grouped path (256 floats per lane sweep)
-__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_job* __restrict__ jobs, int njobs, int total_tasks) {
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_job* __restrict__ jobs, int njobs, int total_tasks,
+                                                         int tpw) {
     __shared__ f32x4 red[3][4][RDB_KIT][64];         // waves 1..3 -> wave 0: [wave - 1][m][k sweep][lane]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int first = blockIdx.x * (4 * RDB_TPW);
-    const int last = min(first + 4 * RDB_TPW, total_tasks) - 1;
+    const int first = blockIdx.x * (4 * tpw);
+    const int last = min(first + 4 * tpw, total_tasks) - 1;
     int jf = 0, jl = 0;
     while (jf + 1 < njobs && jobs[jf + 1].task0 <= first) ++jf;
     while (jl + 1 < njobs && jobs[jl + 1].task0 <= last) ++jl;
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int it = 0; it < RDB_KIT; ++it) accG[i][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < RDB_TPW; ++r) {
+    for (int r = 0; r < tpw; ++r) {
         const int task = first + wave + 4 * r;
         if (task >= total_tasks) break;
         int j = jf;
@@ -683,8 +685,10 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_
 
 extern "C" int lfvdm_rowdot_bwd(const lfvdm_rowdot_bwd_job* jobs_dev, int njobs, int total_tasks, void* stream) {
     if (!jobs_dev || njobs <= 0 || total_tasks <= 0) return LFVDM_E_SHAPE;
-    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((total_tasks + 4 * RDB_TPW - 1) / (4 * RDB_TPW)), dim3(256), 0, (hipStream_t)stream,
-                       jobs_dev, njobs, total_tasks);
+    static const int tpw_env = getenv("LFVDM_ROWDOT_TPW") ? atoi(getenv("LFVDM_ROWDOT_TPW")) : 0;     // tuning aid
+    const int tpw = tpw_env >= 1 && tpw_env <= RDB_TPW ? tpw_env : 1;
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((total_tasks + 4 * tpw - 1) / (4 * tpw)), dim3(256), 0, (hipStream_t)stream,
+                       jobs_dev, njobs, total_tasks, tpw);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
