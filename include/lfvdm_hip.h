@@ -461,6 +461,13 @@ int lfvdm_adamw_ema(const lfvdm_adamw_args* a, void* stream);
 int lfvdm_prepare_batch(const float* pool, const int32_t* table, float* batch, int64_t* frame_indices, float* obs_mask,
                         float* latent_mask, int B, int F, int Tp, int frame_elems, void* stream);
 
+/* Input compositing of the TRAINING forward (unet.py:441-450) as channels-last rows [N*H*W][ld] for the first 3x3 conv:
+ * channels 0..Cx-1 = x*(1-obs[n]) + x0*obs[n], channel Cx = obs[n] (indicator), zero up to ld (>= Cx+1, multiple of 4).
+ * x, x0: (N, Cx, H, W); obs: [N].  (Inference fuses this into lfvdm_conv_in; training keeps the rows for the weight
+ * gradient of the first conv.) */
+int lfvdm_compose_rows(const float* x, const float* x0, const float* obs, float* rows, int N, int Cx, int H, int W, int ld,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Device-side semaphores between a replayed hipGraph and another stream: host-side plumbing of the bucketed gradient
  * exchange that stands in for DistributedDataParallel's overlapped buckets (train_util.py:116-125,309-313).

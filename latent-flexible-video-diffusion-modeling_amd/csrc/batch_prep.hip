@@ -26,7 +26,49 @@ __global__ __launch_bounds__(256) void prepare_batch_kernel(const float* __restr
     }
 }
 
+// Input compositing of the training forward (reference unet.py:441-450) as channels-last rows for the first 3x3 conv:
+//   rows[(n, pixel)][c] = x[n][c][pixel] * (1 - obs[n]) + x0[n][c][pixel] * obs[n]   (c < Cx)
+//   rows[(n, pixel)][Cx] = obs[n]  (the indicator channel),  zero up to the row width ld (the GEMM's 32-channel chunk).
+// The inference path has this inside lfvdm_conv_in; training keeps the rows (operand of the weight gradient).
+__global__ __launch_bounds__(256) void compose_rows_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+                                                           const float* __restrict__ obs, float* __restrict__ rows, int Cx,
+                                                           int HW, int ld, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // one thread per (n, pixel, 4 channels)
+    if (i >= total) return;
+    const int q = ld >> 2;
+    const long pos = i / q;
+    const int c0 = (int)(i - pos * q) * 4;
+    const long n = pos / HW;
+    const int pix = (int)(pos - n * HW);
+    const float o = obs[n];
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        float t = 0.f;
+        if (c < Cx) {
+            const size_t at = ((size_t)n * Cx + c) * HW + pix;
+            t = x[at] * (1.f - o) + x0[at] * o;
+        } else if (c == Cx) {
+            t = o;
+        }
+        v[k] = t;
+    }
+    st4(rows + pos * ld + c0, (f32x4){v[0], v[1], v[2], v[3]});
+}
+
 }  // namespace
+
+extern "C" int lfvdm_compose_rows(const float* x, const float* x0, const float* obs, float* rows, int N, int Cx, int H, int W,
+                                  int ld, void* stream) {
+    if (!x || !x0 || !obs || !rows || N <= 0 || Cx <= 0 || H <= 0 || W <= 0 || ld < Cx + 1 || (ld & 3)) return LFVDM_E_SHAPE;
+    const long total = (long)N * H * W * (ld >> 2);
+    if (total >= (1L << 31) * 256) return LFVDM_E_UNSUPPORTED;
+    hipLaunchKernelGGL(compose_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x0, obs,
+                       rows, Cx, H * W, ld, total);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
 
 extern "C" int lfvdm_prepare_batch(const float* pool, const int32_t* table, float* batch, int64_t* frame_indices,
                                    float* obs_mask, float* latent_mask, int B, int F, int Tp, int frame_elems, void* stream) {

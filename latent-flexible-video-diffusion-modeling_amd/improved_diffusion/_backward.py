@@ -965,11 +965,19 @@ class UNetFunction:
             semb = F.silu(emb)
         else:
             emb = semb = None
-        feats = _rpe_feats(frame_indices.unsqueeze(-1) - frame_indices.unsqueeze(-2))
-        # --- input compositing + first conv (reference unet.py:441-450): 5 -> 32 zero-padded channels
-        comp = th.cat([x * (1 - obs) + x0 * obs, th.ones_like(x[:, :, :1]) * obs], dim=2)
-        rows = th.zeros(N * H * W, 32, device=x.device, dtype=th.float32)
-        rows[:, :Cx + 1] = comp.reshape(N, Cx + 1, H, W).permute(0, 2, 3, 1).reshape(N * H * W, Cx + 1)
+        # all RPE networks in one grouped launch (reads the frame indices itself); the per-layer path needs the features
+        rpe_grp = _rpe_group.forward(m, views, frame_indices, B, T, x.device) if views is not None else None
+        feats = _rpe_feats(frame_indices.unsqueeze(-1) - frame_indices.unsqueeze(-2)) if rpe_grp is None else None
+        # --- input compositing + first conv (reference unet.py:441-450): 5 -> 32 zero-padded channels, one launch
+        if (x.requires_grad or x0.requires_grad) and th.is_grad_enabled():     # gradients w.r.t. the frames: library ops
+            comp = th.cat([x * (1 - obs) + x0 * obs, th.ones_like(x[:, :, :1]) * obs], dim=2)
+            rows = th.zeros(N * H * W, 32, device=x.device, dtype=th.float32)
+            rows[:, :Cx + 1] = comp.reshape(N, Cx + 1, H, W).permute(0, 2, 3, 1).reshape(N * H * W, Cx + 1)
+        else:
+            rows = th.empty(N * H * W, 32, device=x.device, dtype=th.float32)
+            nat.check(nat.lib().lfvdm_compose_rows(nat.ptr(x.contiguous().float()), nat.ptr(x0.contiguous().float()),
+                                                   nat.ptr(obs.reshape(N).contiguous()), nat.ptr(rows), N, Cx, H, W, 32,
+                                                   nat.stream()), "lfvdm_compose_rows")
         conv0 = m.input_blocks[0][0]
         w0 = F.pad(conv0.weight, (0, 0, 0, 0, 0, 32 - (Cx + 1)))
         h = ConvFn.apply(rows, w0, conv0.bias, N, H, W, 1, False)
@@ -1012,8 +1020,6 @@ class UNetFunction:
                 else:
                     raise NotImplementedError(type(layer))
             return (h, Hc, Wc)
-
-        rpe_grp = _rpe_group.forward(m, views, frame_indices, B, T, x.device) if views is not None else None
 
         # data-parallel training: marker nodes at the inputs of the stages where a gradient bucket starts; their
         # backward tells the exchange that the bucket is complete (_exchange.GradExchange)

@@ -105,6 +105,7 @@ _SIGS = {
     "lfvdm_gn_apply_ws_floats": ([c_i, c_i, c_i], C.c_long),
     "lfvdm_gn_apply_ws": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_i, c_fp, c_fp, c_fp, c_fp, c_fp,
                            C.c_long, c_fp], c_i),
+    "lfvdm_compose_rows": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_bwd_stats": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_apply": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_bwd_apply_params": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i,

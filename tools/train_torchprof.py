@@ -21,8 +21,16 @@ for _ in range(3):
     loop.run_step(); loop.step += 1
 th.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     for _ in range(2):
         loop.run_step(); loop.step += 1
     th.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=40, max_shapes_column_width=70))
+# the library (ATen) launches only, with the Python frames that issued them
+rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=6)
+        if e.key.startswith("aten::") and e.self_device_time_total > 0]
+rows.sort(key=lambda e: -e.self_device_time_total)
+for e in rows[:45]:
+    frames = [f for f in e.stack if "improved_diffusion" in f or "bench.py" in f][:3]
+    print(f"{e.key:28s} n={e.count:3d} cuda={e.self_device_time_total:8.1f}us shapes={str(e.input_shapes)[:60]:60s} | " + " <- ".join(
+        f.split("improved_diffusion/")[-1][:60] for f in frames))
