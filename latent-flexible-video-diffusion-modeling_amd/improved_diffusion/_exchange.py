@@ -134,10 +134,17 @@ class GradExchange:
         return _Mark.apply(h, self, k)
 
     def bucket_ready(self, k):
-        from ._backward import _packed
-        _packed.flush(only=self.bucket_param_ids[k])          # 3x3 weight gradients of this bucket -> arena
+        from ._backward import _packed, _side
+
+        def fold_and_signal():
+            _packed.flush(only=self.bucket_param_ids[k])          # 3x3 weight gradients of this bucket -> arena
+            if self.overlap:
+                self.flags.add(k)             # a kernel node of the graph when the micro-step is being captured
+        # on the weight-gradient stream (behind the bucket's wgrad launches there and behind everything the main
+        # chain has issued so far): the main chain itself never waits for a weight gradient before the end
+        _side.flush_pending()
+        _side.run(fold_and_signal, now=True)
         if self.overlap:
-            self.flags.add(k)             # a kernel node of the graph when the micro-step is being captured
             self.fired[k] = True
 
     # ------------------------------------------------------------------ after the last micro-batch
