@@ -574,7 +574,8 @@ def main():
                                        "us = time per step, gflop = FLOPs per step, algorithmic_bytes / pmc_bytes = per launch "
                                        "(operands + output once / PMC L2 fills + write-backs, separate --pmc passes); "
                                        "traffic = launch-weighted mean of pmc_bytes"}
-            out["breakdown"] = {"eager_sum_ms": round(tot_ms, 4), "launches": len(sampler.plan.steps),
+            two_launch = sum(1 for fn, _ in sampler.plan.steps if getattr(fn, "__name__", "") == "lfvdm_gn_apply_ws")
+            out["breakdown"] = {"eager_sum_ms": round(tot_ms, 4), "launches": len(sampler.plan.steps) + two_launch,
                                 "all_conv_gemm_tflops": round(ach, 2),
                                 "step_flops_g": round(dom["flops"] / 1e9, 2),
                                 "whole_step_frac_of_mfma_peak": round(dom["flops"] * out["value"] / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
