@@ -349,6 +349,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     // per-lane byte offsets without the chunk's (tap, channel) shift; rows / filters that do not exist start at kOOB
     constexpr int XE = SIMPLE ? 1 : AE, XW = SIMPLE ? 1 : WE;
     unsigned aoff[AE], woff[WE], aoff1[XE], soff0[XE], soff1[XE], w2off[XW], amsk[AE];
+    // nearest-2x upsampled / zero-inserted main source (general variant only): the tap is no uniform pixel shift there
+    // - source pixel ((oy + dy) >> 1, (ox + dx) >> 1) - so the per-lane offset is rebuilt per chunk from (image base,
+    // oy, ox); a handful of VALU instructions per piece on the three such launches of a forward pass
+    int upy[XE], upx[XE];
+    unsigned upb[XE], upq[XE];
 #pragma unroll
     for (int j = 0; j < AE; ++j) {
         const int e = gt + j * CF::GT, r = e >> RSH, sl = e & (QPR - 1);
@@ -359,6 +364,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             aoff1[j] = (unsigned)ri[j].pix * p.C1 * 4u + q16;
             soff0[j] = (unsigned)ri[j].m * p.s2C0 * 4u + q16;
             soff1[j] = (unsigned)ri[j].m * p.s2C1 * 4u + q16;
+            upy[j] = ri[j].oy * p.stride;
+            upx[j] = ri[j].ox * p.stride;
+            upb[j] = (unsigned)ri[j].n * p.Hs * p.Ws;
+            upq[j] = q16;
         }
     }
 #pragma unroll
@@ -397,6 +406,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         const int t3 = tap / 3, km = main_seg ? k3 : 0;                // branch-free: no tap offset for 1x1 / skip chunks
         const int dy = (t3 - 1) * km, dx = (tap - t3 * 3 - 1) * km;
         const int ashift = ((dy * pWs + dx) * Csrc + cl) * 4;          // bytes, may be negative
+        const int upm = SIMPLE ? 0 : sel(main_seg, p.up, 0);            // 0 none, 1 nearest x2, 2 zero insertion (wave-uniform)
         const unsigned wshift = live ? (unsigned)(main_seg ? tap * Cin + cc : cc) * 4u : kOOB;
         const unsigned tapbit = live ? (main_seg ? (1u << tap) : 0x80000000u) : 0u;
         const float* abase = SIMPLE ? p.src0 : sel(main_seg, sel(second, p.src1, p.src0), sel(second, p.s2src1, p.s2src0));
@@ -412,7 +422,15 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                 const unsigned o0 = aoff[j], o1 = aoff1[j], o2 = soff0[j], o3 = soff1[j];
                 base = sel(main_seg, sel(second, o1, o0), sel(second, o3, o2));
             }
-            const unsigned off = (amsk[j] & tapbit) ? base + (unsigned)ashift : kOOB;
+            unsigned off = (amsk[j] & tapbit) ? base + (unsigned)ashift : kOOB;
+            if constexpr (!SIMPLE) {
+                if (upm) {                  // scalar branch
+                    const int iy = upy[j] + dy, ix = upx[j] + dx;       // inside the upsampled image iff the tap bit is set
+                    const bool ok = (amsk[j] & tapbit) && (upm == 1 || ((iy | ix) & 1) == 0);
+                    const unsigned px = upb[j] + (unsigned)((iy >> 1) * pWs + (ix >> 1));
+                    off = ok ? px * (unsigned)Csrc * 4u + (unsigned)cl * 4u + upq[j] : kOOB;
+                }
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(As + j * CF::GT * 4), 16,
                                                      (int)off, 0, 0, 0);
         }
@@ -815,7 +833,7 @@ constexpr long glds_lds_bytes(int WM, int WN, int WK, int NT, int kch, int gl) {
 inline bool glds_ok(const lfvdm_conv_args* a) {
     const long Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1, lim = 1L << 30;
     const long Cmax = a->C0 > a->C1 ? a->C0 : a->C1, C2max = a->s2C0 > a->s2C1 ? a->s2C0 : a->s2C1;
-    return !a->coefA && a->up == 0 && (long)a->N * a->Hs * a->Ws * Cmax * 4 < lim &&
+    return !a->coefA && (long)a->N * a->Hs * a->Ws * Cmax * 4 < lim &&
            (long)a->N * a->Ho * a->Wo * C2max * 4 < lim && (long)a->Cout * a->ksize * a->ksize * Cin * 4 < lim &&
            (long)a->Cout * C2 * 4 < lim;
 }
@@ -823,7 +841,7 @@ inline bool glds_ok(const lfvdm_conv_args* a) {
 template <int WM, int WN, int WK, int NT, int KCH>
 int launch_kc(const lfvdm_conv_args* a, hipStream_t s, long M, int kz, int gl) {
     if (gl && glds_ok(a)) {
-        const bool simple = a->C1 == 0 && a->s2C0 + a->s2C1 == 0;
+        const bool simple = a->C1 == 0 && a->s2C0 + a->s2C1 == 0 && a->up == 0;
         if constexpr (glds_lds_bytes(WM, WN, WK, NT, KCH, 3) <= 160 * 1024) {
             if (gl == 3) return simple ? launch_pro<WM, WN, WK, NT, KCH, 0, true, 3>(a, s, M, kz)
                                        : launch_pro<WM, WN, WK, NT, KCH, 0, false, 3>(a, s, M, kz);

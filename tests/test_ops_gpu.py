@@ -703,6 +703,40 @@ def test_conv_every_tune_code(nat, N, Cin, Cout, H, k, stride):
     assert int(cnt.abs().sum()) == 0, "split-K tickets must be left at zero"
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,up", [(3, 64, 64, 8, 1), (2, 128, 96, 5, 1), (40, 128, 128, 2, 1), (3, 64, 64, 7, 2),
+                                             (5, 128, 64, 4, 2)])
+def test_conv_upsampled_source_every_tune_code(nat, N, Cin, Cout, H, up):
+    """3x3 conv over a nearest-2x upsampled source (Upsample, unet.py:60-83) and over a zero-inserted one (the data
+    gradient of a stride-2 conv as a transposed convolution): every launch variant, including the LDS-DMA loop whose
+    per-lane source offsets are rebuilt per tap for these two modes."""
+    import ctypes as C
+    x, w, b = rnd("eu/x", N, Cin, H, H), rnd("eu/w", Cout, Cin, 3, 3, scale=0.05), rnd("eu/b", Cout)
+    if up == 1:
+        xin = F.interpolate(x, scale_factor=2, mode="nearest")
+    else:
+        xin = torch.zeros(N, Cin, 2 * H, 2 * H)
+        xin[:, :, ::2, ::2] = x
+    ref = F.conv2d(xin, w, b, padding=1)
+    Ho = 2 * H
+    out = torch.empty(N * Ho * Ho, Cout, device="cuda")
+    ws = torch.empty(1 << 22, device="cuda")
+    cnt = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    keep = dict(src0=cl(x), W=packed(nat, w), bias=b.cuda())
+    a = nat.fill_conv_args(C0=Cin, N=N, Hs=H, Ws=H, Ho=Ho, Wo=Ho, Cout=Cout, out=out, ldo=Cout, ksize=3, up=up, **keep)
+    a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+    codes = (C.c_int * 256)()
+    n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
+    dma = [codes[i] for i in range(n) if (codes[i] - 1) >> 8]
+    assert n > 0 and dma, "LDS-DMA variants expected for an upsampled source"
+    for code in [0] + [codes[i] for i in range(n)]:
+        a.tune = code
+        out.fill_(float("nan"))
+        nat.conv_igemm_struct(a)
+        err = float((from_cl(out, N, Ho, Ho, Cout).cpu() - ref).abs().max())
+        assert err < 5e-5, f"tune code {code}: max|d| = {err:.3e}"
+    assert int(cnt.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("N,C0,C1,S0,S1,Cout,H", [(5, 64, 32, 64, 32, 64, 8), (3, 128, 0, 96, 32, 96, 5), (40, 64, 64, 0, 0, 128, 4),
                                                   (2, 32, 32, 32, 0, 32, 16)])
 def test_conv_concat_and_skip_segment_every_tune_code(nat, N, C0, C1, S0, S1, Cout, H):
