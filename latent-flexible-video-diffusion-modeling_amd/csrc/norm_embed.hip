@@ -18,6 +18,7 @@ __device__ __forceinline__ f32x4 ld_cat(const float* s0, const float* s1, int C0
     return c < C0 ? ld4(s0 + pos * C0 + c) : ld4(s1 + pos * C1 + (c - C0));
 }
 
+template <int KEEP>      // float4 per thread held in registers between the passes: 8, or 16 for slices of up to 16 pixel lanes' worth
 __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
     const float* __restrict__ s0, const float* __restrict__ s1, int C0, int C1, int P,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
@@ -43,7 +44,6 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
 
     const size_t pos0 = (size_t)n * P;
     const bool pow2q = (Q & (Q - 1)) == 0 && Q <= 64;      // workgroup-uniform
-    constexpr int KEEP = 8;
     const bool cached = P <= KEEP * PL;       // workgroup-uniform
     f32x4 keep[KEEP];
     for (int pass = 0; pass < 2; ++pass) {
@@ -301,12 +301,18 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_apply_kernel(
     }
 }
 
+// does the slice need (and fit) the 16-float4 register budget of the single-launch kernel?
+inline bool gn_keep16(int C, int P) {
+    const int PL = GN_THREADS / (GN_GPW * (C / 32) / 4);
+    return P > 8 * PL && P <= 16 * PL;
+}
+
 // chunked decomposition for (C, P): chunks per slice (0 = the single-launch kernel holds the slice in registers)
 inline int gn_chunks(int C, int P, int* pl_out) {
     const int Q = GN_GPW * (C / 32) / 4;
     const int PL = GN_THREADS / Q;
     if (pl_out) *pl_out = PL;
-    if (P <= GN_KEEP * PL) return 0;
+    if (P <= 2 * GN_KEEP * PL) return 0;       // up to 16 float4 per thread: the single-launch kernel keeps the slice
     return (P + GN_KEEP * PL - 1) / (GN_KEEP * PL);
 }
 
@@ -700,8 +706,12 @@ extern "C" int lfvdm_gn_coef_stats(const float* src0, const float* src1, int C0,
     if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
     if (C1 > 0 && !src1) return LFVDM_E_SHAPE;
     if (film && film_div <= 0) return LFVDM_E_SHAPE;
-    hipLaunchKernelGGL(gn_coef_kernel, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0, C1,
-                       P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, (float*)nullptr, 0);
+    if (gn_keep16(C, P))
+        hipLaunchKernelGGL(gn_coef_kernel<16>, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0,
+                           C1, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, (float*)nullptr, 0);
+    else
+        hipLaunchKernelGGL(gn_coef_kernel<8>, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0,
+                           C1, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, (float*)nullptr, 0);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
@@ -714,8 +724,12 @@ extern "C" int lfvdm_gn_apply(const float* src0, const float* src1, int C0, int 
     if (C1 > 0 && !src1) return LFVDM_E_SHAPE;
     if (film && film_div <= 0) return LFVDM_E_SHAPE;
     if ((coefA == nullptr) != (coefB == nullptr)) return LFVDM_E_SHAPE;
-    hipLaunchKernelGGL(gn_coef_kernel, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0, C1,
-                       P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, out, act);
+    if (gn_keep16(C, P))
+        hipLaunchKernelGGL(gn_coef_kernel<16>, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0,
+                           C1, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, out, act);
+    else
+        hipLaunchKernelGGL(gn_coef_kernel<8>, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0,
+                           C1, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, out, act);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
