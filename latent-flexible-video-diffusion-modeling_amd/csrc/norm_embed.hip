@@ -465,48 +465,89 @@ __global__ __launch_bounds__(256) void gn_temporal_reg_kernel(const float* __res
 
 // -------------------------------------------------------------------------------------
 // conv_in: x*(1-obs)+x0*obs, indicator channel = obs, 3x3 pad-1 conv, channels-last output.
-// Thread = (pixel, quad of 4 output channels); weights [(C+1)*9][Cout] in LDS.
+// Workgroup = 64 consecutive pixels x all filters: lane = pixel (the NCHW input planes are read as contiguous runs of
+// the wave), wave w = filters [w*Cout/4, (w+1)*Cout/4) in quads; weights [(C+1)*9][Cout] in LDS, read as wave-uniform
+// (broadcast) float4.  (The first version gave every thread one pixel and ONE quad: 16 threads re-loaded each input
+// value and four times as many workgroups staged the weight table - 13 us for a 30 MFLOP layer.)
 // -------------------------------------------------------------------------------------
+template <int QW, int CIT>      // QW float4 quads of output channels per thread (Cout = 16 * QW); CIT = C + 1 when it is
+                                // known at compile time (4 / 5: the input gather is then fully unrolled), else 0
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ x0,
                                                       const float* __restrict__ obs, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ out, int N,
-                                                      int C, int H, int W, int Cout) {
+                                                      int C, int H, int W) {
+    constexpr int Cout = 16 * QW;
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [k = ci*9+tap][Cout]
-    const int Ci = C + 1;
+    const int Ci = CIT ? CIT : C + 1;
     const int K = Ci * 9;
     // w is OIHW = [co][k]; consecutive threads take consecutive co, so the LDS writes are bank-conflict free (walking
     // k fastest put every write of a wave into one bank: stride Cout)
-    for (int i = threadIdx.x; i < K * Cout; i += blockDim.x) {
+    for (int i = threadIdx.x; i < K * Cout; i += 256) {
         const int k = i / Cout, co = i - k * Cout;
         wl[i] = w[(size_t)co * K + k];
     }
     __syncthreads();
-    const int QC = Cout / 4;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)N * H * W * QC;
-    if (gid >= total) return;
-    const int cq = (int)(gid % QC);
-    const long pix = gid / QC;
+    const int lane = threadIdx.x & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int HW = H * W;
-    const int n = (int)(pix / HW);
-    const int p = (int)(pix - (long)n * HW);
+    const long total = (long)N * HW;
+    const long pix = (long)blockIdx.x * 64 + lane;
+    const bool live = pix < total;
+    const long pp = live ? pix : total - 1;
+    const int n = (int)(pp / HW);
+    const int p = (int)(pp - (long)n * HW);
     const int oy = p / W, ox = p - oy * W;
     const float ob = obs[n];
-    f32x4 acc = ld4(bias + cq * 4);
+    f32x4 acc[QW];
+#pragma unroll
+    for (int q = 0; q < QW; ++q) acc[q] = ld4(bias + (grp * QW + q) * 4);
     const float* xn = x + (size_t)n * C * HW;
     const float* x0n = x0 + (size_t)n * C * HW;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-        const int ip = iy * W + ix;
-        for (int ci = 0; ci < Ci; ++ci) {
-            float v;
-            if (ci < C) v = xn[ci * HW + ip] * (1.0f - ob) + x0n[ci * HW + ip] * ob;
-            else v = ob;
-            acc += v * ld4(wl + (ci * 9 + tap) * Cout + cq * 4);
+    const float* wg = wl + grp * QW * 4;
+    if constexpr (CIT > 0) {
+        // all 9 * (C + 1) composited inputs first (independent loads: one exposed latency), then the FMAs
+        float v[9][CIT];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            const bool inb = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int ip = inb ? iy * W + ix : p;
+#pragma unroll
+            for (int ci = 0; ci < CIT; ++ci) {
+                float t = ob;
+                if (ci < CIT - 1) t = xn[ci * HW + ip] * (1.0f - ob) + x0n[ci * HW + ip] * ob;
+                v[tap][ci] = inb ? t : 0.f;
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ci = 0; ci < CIT; ++ci) {
+                const float* wk = wg + (ci * 9 + tap) * Cout;
+#pragma unroll
+                for (int q = 0; q < QW; ++q) acc[q] += v[tap][ci] * ld4(wk + q * 4);
+            }
+    } else {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            const bool inb = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int ip = inb ? iy * W + ix : p;
+            for (int ci = 0; ci < Ci; ++ci) {
+                float v = ob;
+                if (ci < C) v = xn[ci * HW + ip] * (1.0f - ob) + x0n[ci * HW + ip] * ob;
+                v = inb ? v : 0.f;
+                const float* wk = wg + (ci * 9 + tap) * Cout;
+#pragma unroll
+                for (int q = 0; q < QW; ++q) acc[q] += v * ld4(wk + q * 4);
+            }
         }
     }
-    st4(out + (size_t)pix * Cout + cq * 4, acc);
+    if (live) {
+        float* o = out + (size_t)pix * Cout + grp * QW * 4;
+#pragma unroll
+        for (int q = 0; q < QW; ++q) st4(o + q * 4, acc[q]);
+    }
 }
 
 // -------------------------------------------------------------------------------------
@@ -804,12 +845,25 @@ extern "C" int lfvdm_gn_temporal(const float* x, const float* gamma, const float
 
 extern "C" int lfvdm_conv_in(const float* x, const float* x0, const float* obs, const float* w, const float* bias,
                              float* out, int N, int C, int H, int W, int Cout, void* stream) {
-    if (N <= 0 || C <= 0 || Cout % 4 || H <= 0 || W <= 0) return LFVDM_E_SHAPE;
+    if (N <= 0 || C <= 0 || Cout % 16 || Cout > 256 || H <= 0 || W <= 0) return LFVDM_E_SHAPE;
     const size_t lds = (size_t)(C + 1) * 9 * Cout * sizeof(float);
     if (lds > 64 * 1024) return LFVDM_E_UNSUPPORTED;
-    const long total = (long)N * H * W * (Cout / 4);
-    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, (hipStream_t)stream, x, x0, obs,
-                       w, bias, out, N, C, H, W, Cout);
+    const long total = (long)N * H * W;
+    const dim3 grid((unsigned)((total + 63) / 64));
+    hipStream_t s = (hipStream_t)stream;
+#define LFVDM_CONV_IN(Q)                                                                                              \
+    case Q:                                                                                                           \
+        if (C == 4) hipLaunchKernelGGL((conv_in_kernel<Q, 5>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W);      \
+        else if (C == 3) hipLaunchKernelGGL((conv_in_kernel<Q, 4>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W); \
+        else hipLaunchKernelGGL((conv_in_kernel<Q, 0>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W);             \
+        break;
+    switch (Cout / 16) {
+        LFVDM_CONV_IN(1) LFVDM_CONV_IN(2) LFVDM_CONV_IN(3) LFVDM_CONV_IN(4) LFVDM_CONV_IN(5) LFVDM_CONV_IN(6) LFVDM_CONV_IN(7)
+        LFVDM_CONV_IN(8) LFVDM_CONV_IN(9) LFVDM_CONV_IN(10) LFVDM_CONV_IN(11) LFVDM_CONV_IN(12) LFVDM_CONV_IN(13)
+        LFVDM_CONV_IN(14) LFVDM_CONV_IN(15) LFVDM_CONV_IN(16)
+        default: return LFVDM_E_SHAPE;
+    }
+#undef LFVDM_CONV_IN
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

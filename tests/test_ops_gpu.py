@@ -146,10 +146,12 @@ def test_resblock_identity_skip(nat):
     close(from_cl(out, N, H, H, Cc), ref, 1e-4)
 
 
-def test_conv_in(nat):
-    B, T, Cc, H, Cout = 2, 3, 4, 16, 64
+@pytest.mark.parametrize("B,T,Cc,H,Cout", [(2, 3, 4, 16, 64), (1, 3, 3, 10, 128), (2, 3, 4, 2, 32), (1, 3, 4, 5, 48), (1, 3, 2, 6, 32)])
+def test_conv_in(nat, B, T, Cc, H, Cout):
+    """lfvdm_conv_in (compositing + indicator channel + first 3x3 conv, unet.py:441-450,310-316): image borders, maps smaller
+    than a 64-pixel workgroup (pixels of several frames in one wave), ragged last workgroup, 2..8 channel quads per thread."""
     x, x0 = rnd("ci/x", B, T, Cc, H, H), rnd("ci/x0", B, T, Cc, H, H)
-    obs = torch.tensor([[1., 0, 1], [0, 0, 1]]).view(B, T, 1, 1, 1)
+    obs = torch.tensor([[1., 0, 1], [0, 0, 1]])[:B].reshape(B, T, 1, 1, 1)
     w, b = rnd("ci/w", Cout, Cc + 1, 3, 3, scale=0.2), rnd("ci/b", Cout)
     comp = torch.cat([x * (1 - obs) + x0 * obs, torch.ones_like(x[:, :, :1]) * obs], 2).reshape(B * T, Cc + 1, H, H)
     ref = F.conv2d(comp, w, b, padding=1)
