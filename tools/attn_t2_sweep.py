@@ -12,6 +12,9 @@ shapes = [(2, 20, 256, 64, 4), (2, 20, 64, 128, 4), (2, 20, 4, 128, 4), (2, 20, 
 cfgs = [(tg, nw) for tg in (2, 3, 4, 5) for nw in (1, 2, 4)]
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     shapes, cfgs = shapes[:3], [(4, 4), (4, 2), (5, 4)]
+if len(sys.argv) > 1 and sys.argv[1] == "train":        # the cfg-C training shapes with 64-channel heads
+    shapes = [(2, 20, 64, 256, 4), (2, 20, 16, 256, 4), (2, 20, 4, 256, 4), (2, 20, 256, 128, 4)]
+    cfgs = [(tg, nw) for tg in (2, 4, 5, 7, 10) for nw in (1, 2, 4)]
 for (B, T, P, C, heads) in shapes:
     M = B * T * P
     qkv = th.randn(M, 3 * C, device=dev)
