@@ -225,3 +225,31 @@ def test_training_step_with_device_batch_preparation_equals_host_path(monkeypatc
     diff = (outs["1"][1] - outs["0"][1]).abs()
     assert float(diff.max()) <= 2 * 1e-3 * 3 + 1e-6
     assert float((diff > 1e-5).float().mean()) < 2e-3, float((diff > 1e-5).float().mean())
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_weight_gradients_on_a_second_stream_give_the_same_gradients(monkeypatch, mode):
+    """LFVDM_WGRAD_SIDE (off by default, _backward._SideStream): the weight-gradient launches beside the data-gradient
+    chain - one fork per launch (1) or per gradient bucket (2), the bucket folds on that stream, one join at the end of
+    the backward pass - must produce the gradients of the single chain, eagerly and as a replayed graph.  The optimizer
+    runs with lr = 0, so the parameters stay put and the gradients of the 4th micro-step (a replay) are comparable."""
+    outs = {}
+    for side in ("0", mode):
+        monkeypatch.setenv("LFVDM_WGRAD_SIDE", side)
+        cfg, sd, _ = load_case("micro")
+        model = build_native(cfg, sd).train()
+        loop = make_loop(model, lr=0.0)
+        torch.manual_seed(21); np.random.seed(21)
+        grads = []
+        for _ in range(4):                  # micro-steps 3 and 4 replay the captured graph
+            loop.forward_backward()
+            torch.cuda.synchronize()
+            grads.append(loop.arena.g.clone())
+            loop.optimize_normal()
+            loop.step += 1
+        assert loop._graph_state.get("graph") is not None
+        outs[side] = grads
+    for k, (a, b) in enumerate(zip(outs["0"], outs[mode])):
+        scale = float(a.abs().max())
+        assert scale > 0 and bool(torch.isfinite(b).all())
+        assert float((a - b).abs().max()) < 2e-5 * scale, (k, float((a - b).abs().max()), scale)
