@@ -152,6 +152,124 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
 }
 
 // -------------------------------------------------------------------------------------
+// gn_wave: the same GroupNorm for maps of <= 256 positions with 2 / 4 / 8 / 16 channels per group (C = 64 ... 512), ONE
+// WAVE per (sample, 16 channels): lane = (pixel lane pl = lane >> 2, channel quad q = lane & 3), the slice
+// [P][16 channels] sits in <= 16 float4 per lane, and both reductions are wave butterflies (over the 16 pixel lanes,
+// then over the 1 / 2 / 4 quad lanes of a group) - no LDS, no barrier.  The workgroup kernel above spends seven
+// barriers and four LDS round trips on 16 KB of data: 5.8 us per launch against ~4 here, 15 launches per denoising step.
+// -------------------------------------------------------------------------------------
+template <int CG>      // channels per group: 2, 4, 8, 16
+__global__ __launch_bounds__(64) void gn_wave_kernel(
+    const float* __restrict__ s0, const float* __restrict__ s1, int C0, int C1, int P,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
+    int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats,
+    float* __restrict__ act_out, int act_mode) {
+    constexpr int KEEP = 16;
+    const int C = C0 + C1;
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int q = lane & 3, pl = lane >> 2;
+    const int c = blockIdx.y * 16 + q * 4;
+    const size_t pos0 = (size_t)n * P;
+    // coefficient operands first: their latency hides behind the statistics
+    const f32x4 gam = ld4(gamma + c), bet = ld4(beta + c);
+    f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fsh = fsc;
+    if (film) {
+        const float* f = film + (size_t)(n / film_div) * film_ld;
+        fsc = ld4(f + c);
+        fsh = ld4(f + C + c);
+    }
+    f32x4 keep[KEEP];
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        const int p = pl + 16 * i;
+        keep[i] = p < P ? ld_cat(s0, s1, C0, C1, pos0 + p, c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // sum over a group: the lane's own channels of the group, the pixel lanes (xor 4 ... 32), the quad lanes of the group
+    auto group_sum = [&](f32x4 v) -> f32x4 {
+        if constexpr (CG == 2) { const float a = v.x + v.y, b = v.z + v.w; v = (f32x4){a, a, b, b}; }
+        else { const float a = (v.x + v.y) + (v.z + v.w); v = (f32x4){a, a, a, a}; }
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) {
+            v.x += __shfl_xor(v.x, off, 64);
+            if constexpr (CG == 2) v.z += __shfl_xor(v.z, off, 64);
+        }
+        if constexpr (CG >= 8) v.x += __shfl_xor(v.x, 1, 64);
+        if constexpr (CG >= 16) v.x += __shfl_xor(v.x, 2, 64);
+        if constexpr (CG == 2) return (f32x4){v.x, v.x, v.z, v.z};
+        else return (f32x4){v.x, v.x, v.x, v.x};
+    };
+    const float inv = 1.0f / (float)(CG * P);
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) sum += keep[i];
+    const f32x4 mean = group_sum(sum) * inv;
+    f32x4 sq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        if (pl + 16 * i < P) {
+            const f32x4 d = keep[i] - mean;
+            sq += d * d;
+        }
+    }
+    const f32x4 var = group_sum(sq) * inv;
+    f32x4 rstd;
+    rstd.x = 1.0f / sqrtf(var.x + eps); rstd.y = 1.0f / sqrtf(var.y + eps);
+    rstd.z = 1.0f / sqrtf(var.z + eps); rstd.w = 1.0f / sqrtf(var.w + eps);
+    f32x4 A = rstd * gam;
+    f32x4 B = bet - mean * A;
+    if (film) {
+        const f32x4 sc = fsc + (f32x4){1.f, 1.f, 1.f, 1.f};
+        A = A * sc;
+        B = B * sc + fsh;
+    }
+    if (pl == 0) {
+        if (coefA) {
+            st4(coefA + (size_t)n * C + c, A);
+            st4(coefB + (size_t)n * C + c, B);
+        }
+        if (stats) {       // (mean, rstd) per (sample, group): the first channel of a group reports
+            float* st = stats + (size_t)n * 64;
+            if constexpr (CG == 2) {
+                st[2 * (c / 2)] = mean.x; st[2 * (c / 2) + 1] = rstd.x;
+                st[2 * (c / 2 + 1)] = mean.z; st[2 * (c / 2 + 1) + 1] = rstd.z;
+            } else if (c % CG == 0) {
+                st[2 * (c / CG)] = mean.x; st[2 * (c / CG) + 1] = rstd.x;
+            }
+        }
+    }
+    if (act_out == nullptr) return;
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        const int p = pl + 16 * i;
+        if (p < P) {
+            f32x4 v = keep[i] * A + B;
+            if (act_mode == LFVDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            st4(act_out + (pos0 + p) * C + c, v);
+        }
+    }
+}
+
+// one wave per (sample, 16 channels) when the map and the group width allow it; false = use the workgroup kernels
+inline bool gn_wave_launch(const float* src0, const float* src1, int C0, int C1, int N, int P, const float* gamma,
+                           const float* beta, const float* film, int film_div, int film_ld, float eps, float* coefA,
+                           float* coefB, float* stats, float* out, int act, hipStream_t s) {
+    static const bool off = getenv("LFVDM_GN_NO_WAVE") != nullptr;          // A/B aid
+    const int C = C0 + C1, cg = C / 32;
+    if (off || P > 256 || C0 % 16 || (cg != 2 && cg != 4 && cg != 8 && cg != 16) || N > 65535) return false;
+    const dim3 grid(N, C / 16);
+#define LFVDM_GNW(G)                                                                                                   \
+    hipLaunchKernelGGL(gn_wave_kernel<G>, grid, dim3(64), 0, s, src0, src1, C0, C1, P, gamma, beta, film, film_div, film_ld, \
+                       eps, coefA, coefB, stats, out, act)
+    if (cg == 2) LFVDM_GNW(2);
+    else if (cg == 4) LFVDM_GNW(4);
+    else if (cg == 8) LFVDM_GNW(8);
+    else LFVDM_GNW(16);
+#undef LFVDM_GNW
+    return true;
+}
+
+// -------------------------------------------------------------------------------------
 // Large maps (P > 8 pixel lanes' worth: pixel space, 32x32 latents): the (sample, 8 groups) decomposition above gives
 // N*4 workgroups that each walk their whole slice three times, one load at a time - 80 workgroups streaming 2 MB each at
 // 128x128 (1-2 ms per GroupNorm, a third of the pixel-space step).  Here a workgroup owns a CHUNK of 8*PL positions of
@@ -747,7 +865,9 @@ extern "C" int lfvdm_gn_coef_stats(const float* src0, const float* src1, int C0,
     if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
     if (C1 > 0 && !src1) return LFVDM_E_SHAPE;
     if (film && film_div <= 0) return LFVDM_E_SHAPE;
-    if (gn_keep16(C, P))
+    if (gn_wave_launch(src0, src1, C0, C1, N, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, nullptr, 0,
+                       (hipStream_t)stream)) {
+    } else if (gn_keep16(C, P))
         hipLaunchKernelGGL(gn_coef_kernel<16>, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0,
                            C1, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, (float*)nullptr, 0);
     else
@@ -765,7 +885,9 @@ extern "C" int lfvdm_gn_apply(const float* src0, const float* src1, int C0, int 
     if (C1 > 0 && !src1) return LFVDM_E_SHAPE;
     if (film && film_div <= 0) return LFVDM_E_SHAPE;
     if ((coefA == nullptr) != (coefB == nullptr)) return LFVDM_E_SHAPE;
-    if (gn_keep16(C, P))
+    if (gn_wave_launch(src0, src1, C0, C1, N, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, out, act,
+                       (hipStream_t)stream)) {
+    } else if (gn_keep16(C, P))
         hipLaunchKernelGGL(gn_coef_kernel<16>, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0,
                            C1, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, out, act);
     else
