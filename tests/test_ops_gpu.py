@@ -469,7 +469,8 @@ def test_conv_splitk_is_exact_and_deterministic(nat):
 # ------------------------------------------------------------------------------------------- round-1 additions
 @pytest.mark.parametrize("N,P,C0,C1,film,act", [(4, 256, 64, 0, False, 1), (6, 64, 128, 64, False, 1), (4, 16, 128, 0, True, 1),
                                                 (3, 4, 256, 128, False, 1), (2, 256, 64, 0, False, 0), (2, 2500, 96, 32, True, 1),
-                                                (2, 256, 128, 64, True, 1), (2, 300, 64, 32, False, 1)])
+                                                (2, 256, 128, 64, True, 1), (2, 300, 64, 32, False, 1), (2, 16, 512, 256, True, 1),
+                                                (4, 100, 256, 256, False, 1), (2, 37, 512, 0, True, 0)])
 def test_gn_apply(nat, N, P, C0, C1, film, act):
     """lfvdm_gn_apply: act(GroupNorm32(cat(a, b)) * (1 + scale) + shift) materialised (nn.py:17-19, unet.py:199-203)
     plus the coefficient / statistics side outputs, vs torch group_norm in fp64."""
