@@ -575,7 +575,8 @@ def main():
                                        "(operands + output once / PMC L2 fills + write-backs, separate --pmc passes); "
                                        "traffic = launch-weighted mean of pmc_bytes"}
             two_launch = sum(1 for fn, _ in sampler.plan.steps if getattr(fn, "__name__", "") == "lfvdm_gn_apply_ws")
-            out["breakdown"] = {"eager_sum_ms": round(tot_ms, 4), "launches": len(sampler.plan.steps) + two_launch,
+            out["breakdown"] = {"eager_sum_ms": round(tot_ms, 4),
+                                "launches": len(sampler.plan.steps) + two_launch + int(getattr(sampler, "extra_launches", 3)),
                                 "all_conv_gemm_tflops": round(ach, 2),
                                 "step_flops_g": round(dom["flops"] / 1e9, 2),
                                 "whole_step_frac_of_mfma_peak": round(dom["flops"] * out["value"] / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),

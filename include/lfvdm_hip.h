@@ -189,6 +189,11 @@ int lfvdm_unpack_conv_grads(const lfvdm_unpack_job* jobs_dev, int njobs, int tot
  * ------------------------------------------------------------------------------------- */
 int lfvdm_conv_in(const float* x, const float* x0, const float* obs, const float* w, const float* bias,
                   float* out, int N, int C, int H, int W, int Cout, void* stream);
+/* lfvdm_conv_in with the sampler's clock riding in the same launch (one extra workgroup; nothing in the first conv reads
+ * the timestep): exactly lfvdm_sampler_tick_fetch's effect on (t, model_t, rows) - see there for the arguments. */
+int lfvdm_conv_in_tick(const float* x, const float* x0, const float* obs, const float* w, const float* bias, float* out,
+                       int N, int C, int H, int W, int Cout, int64_t* t, const float* model_timestep_table, float* model_t,
+                       int B, const float* rows_all, int rows_ld, float* rows, int row_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * GroupNorm(32) statistics -> per-(sample, channel) affine coefficients, optionally folded
@@ -411,6 +416,14 @@ int lfvdm_p_sample(const float* x, const float* eps, const float* noise, const i
                    const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* coef1,
                    const float* coef2, const float* log_var, int clip, float* sample, float* pred_xstart,
                    float* mean_out, int B, int inner, void* stream);
+/* The same update with the noise drawn INSIDE the kernel (the sampler's replayed step: one launch less than
+ * th.randn + lfvdm_p_sample): Philox4x32-10 keyed by seed[0] (device int64, one value per chain), counter = (element quad,
+ * batch row, timestep t[b]) -> Box-Muller; a (seed, timestep, element) triple always gives the same value.  noise_out
+ * (optional) receives the standard normal values that were used. */
+int lfvdm_p_sample_rng(const float* x, const float* eps, float* noise_out, const int64_t* t, const float* sqrt_recip_acp,
+                       const float* sqrt_recipm1_acp, const float* coef1, const float* coef2, const float* log_var,
+                       int clip, float* sample, float* pred_xstart, float* mean_out, int B, int inner,
+                       const int64_t* seed, void* stream);
 /* Sampler clock of the captured denoising step (the loop `for i in indices: t = th.tensor([i]*B)` of
  * gaussian_diffusion.py:509-512 and _WrappedModel's timestep map, respace.py:117-122, kept on the device):
  * t[b] <- max(t[b] - 1, 0);  model_t[b] <- model_timestep_table[t[b]]. */

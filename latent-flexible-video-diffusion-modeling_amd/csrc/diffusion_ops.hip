@@ -46,6 +46,69 @@ __global__ __launch_bounds__(256) void p_sample_kernel(const float* x, const flo
     }
 }
 
+// ---- the same update with the Gaussian noise drawn in the kernel (one launch less per sampling step).
+// Counter-based: Philox4x32-10 (Salmon et al., SC'11) keyed by the chain's 64-bit seed, counter = (quad index within the
+// row, batch row, timestep, 0) -> four uniform words -> two Box-Muller pairs = the noise of four consecutive elements.
+// A given (seed, timestep, element) always gets the same value, whatever the launch geometry.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ f32x4 normal4(unsigned quad, unsigned row, unsigned step, unsigned k0, unsigned k1) {
+    unsigned r[4];
+    philox4x32_10(quad, row, step, 0u, k0, k1, r);
+    const float two_pi = 6.283185307179586f, s32 = 2.3283064365386963e-10f;      // 2^-32
+    const float u0 = ((float)r[0] + 1.0f) * s32, u1 = (float)r[1] * s32;         // u0 in (0, 1]
+    const float u2 = ((float)r[2] + 1.0f) * s32, u3 = (float)r[3] * s32;
+    const float m0 = sqrtf(-2.0f * logf(u0)), m1 = sqrtf(-2.0f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(two_pi * u1, &s0, &c0);
+    sincosf(two_pi * u3, &s1, &c1);
+    return (f32x4){m0 * c0, m0 * s0, m1 * c1, m1 * s1};
+}
+
+__global__ __launch_bounds__(256) void p_sample_rng_kernel(const float* x, const float* __restrict__ eps,
+                                                           float* __restrict__ noise_out, const int64_t* __restrict__ t,
+                                                           const float* __restrict__ t_recip, const float* __restrict__ t_recipm1,
+                                                           const float* __restrict__ t_c1, const float* __restrict__ t_c2,
+                                                           const float* __restrict__ t_logvar, int clip, float* sample,
+                                                           float* __restrict__ pred, float* __restrict__ mean_out, int inner,
+                                                           const int64_t* __restrict__ seed) {
+    const int b = blockIdx.y;
+    const int64_t tb = t[b];
+    const float r = t_recip[tb], rm1 = t_recipm1[tb], c1 = t_c1[tb], c2 = t_c2[tb];
+    const float sigma = tb != 0 ? expf(0.5f * t_logvar[tb]) : 0.f;
+    const unsigned long long key = (unsigned long long)seed[0];
+    const unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+    const size_t base = (size_t)b * inner;
+    const int nq = (inner + 3) >> 2;
+    for (int qd = blockIdx.x * blockDim.x + threadIdx.x; qd < nq; qd += gridDim.x * blockDim.x) {
+        const f32x4 z = normal4((unsigned)qd, (unsigned)b, (unsigned)tb, k0, k1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * qd + e;
+            if (i < inner) {
+                const float xv = x[base + i];
+                float p0 = r * xv - rm1 * eps[base + i];
+                if (clip) p0 = fminf(fmaxf(p0, -1.f), 1.f);
+                const float mean = c1 * p0 + c2 * xv;
+                sample[base + i] = mean + sigma * z[e];
+                if (noise_out) noise_out[base + i] = z[e];
+                if (pred) pred[base + i] = p0;
+                if (mean_out) mean_out[base + i] = mean;
+            }
+        }
+    }
+}
+
 // out[b] = (1/inner_total) * sum_{t, i} (a - b)^2 * mask[b, t]; one workgroup per batch row
 __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ a, const float* __restrict__ bb,
                                                          const float* __restrict__ mask, float* __restrict__ out, int T,
@@ -145,6 +208,19 @@ extern "C" int lfvdm_p_sample(const float* x, const float* eps, const float* noi
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(p_sample_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, eps, noise, t, sqrt_recip_acp,
                        sqrt_recipm1_acp, coef1, coef2, log_var, clip, sample, pred_xstart, mean_out, inner);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_p_sample_rng(const float* x, const float* eps, float* noise_out, const int64_t* t,
+                                  const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* coef1,
+                                  const float* coef2, const float* log_var, int clip, float* sample, float* pred_xstart,
+                                  float* mean_out, int B, int inner, const int64_t* seed, void* stream) {
+    if (B <= 0 || inner <= 0 || !seed) return LFVDM_E_SHAPE;
+    int gx = ((inner + 3) / 4 + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(p_sample_rng_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, eps, noise_out, t, sqrt_recip_acp,
+                       sqrt_recipm1_acp, coef1, coef2, log_var, clip, sample, pred_xstart, mean_out, inner, seed);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

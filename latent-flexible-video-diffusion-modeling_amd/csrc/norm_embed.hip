@@ -588,14 +588,44 @@ __global__ __launch_bounds__(256) void gn_temporal_reg_kernel(const float* __res
 // (broadcast) float4.  (The first version gave every thread one pixel and ONE quad: 16 threads re-loaded each input
 // value and four times as many workgroups staged the weight table - 13 us for a 30 MFLOP layer.)
 // -------------------------------------------------------------------------------------
+// The sampler's clock rides in this launch (the first of a denoising step, and nothing in it reads the timestep): one
+// extra workgroup does what lfvdm_sampler_tick_fetch does - t <- max(t - 1, 0), model timestep <- table[t], FiLM rows of
+// the new t fetched from the chain's table - one launch less per step.
+struct ConvInTick {
+    int64_t* t;                // [B] or NULL: no clock in this launch
+    const float* table;
+    float* model_t;
+    const float* rows_all;
+    float* rows;
+    int B, rows_ld, row_floats;
+};
+
 template <int QW, int CIT>      // QW float4 quads of output channels per thread (Cout = 16 * QW); CIT = C + 1 when it is
                                 // known at compile time (4 / 5: the input gather is then fully unrolled), else 0
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ x0,
                                                       const float* __restrict__ obs, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ out, int N,
-                                                      int C, int H, int W) {
+                                                      int C, int H, int W, ConvInTick tk) {
     constexpr int Cout = 16 * QW;
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [k = ci*9+tap][Cout]
+    if (tk.t != nullptr && blockIdx.x == gridDim.x - 1) {        // the clock's workgroup (workgroup-uniform branch)
+        int64_t* tnew = reinterpret_cast<int64_t*>(wl);
+        if ((int)threadIdx.x < tk.B) {
+            int64_t v = tk.t[threadIdx.x] - 1;
+            v = v < 0 ? 0 : v;
+            tk.t[threadIdx.x] = v;
+            tk.model_t[threadIdx.x] = tk.table[v];
+            tnew[threadIdx.x] = v;
+        }
+        __syncthreads();
+        const int q4 = tk.row_floats >> 2;
+        for (int e = threadIdx.x; e < tk.B * q4; e += 256) {
+            const int b = e / q4, i = e - b * q4;
+            const float* src = tk.rows_all + ((size_t)tnew[b] * tk.B + b) * tk.rows_ld;
+            st4(tk.rows + (size_t)b * tk.rows_ld + 4 * i, ld4(src + 4 * i));
+        }
+        return;
+    }
     const int Ci = CIT ? CIT : C + 1;
     const int K = Ci * 9;
     // w is OIHW = [co][k]; consecutive threads take consecutive co, so the LDS writes are bank-conflict free (walking
@@ -965,19 +995,19 @@ extern "C" int lfvdm_gn_temporal(const float* x, const float* gamma, const float
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_conv_in(const float* x, const float* x0, const float* obs, const float* w, const float* bias,
-                             float* out, int N, int C, int H, int W, int Cout, void* stream) {
+static int conv_in_launch(const float* x, const float* x0, const float* obs, const float* w, const float* bias, float* out,
+                          int N, int C, int H, int W, int Cout, const ConvInTick& tk, hipStream_t s) {
     if (N <= 0 || C <= 0 || Cout % 16 || Cout > 256 || H <= 0 || W <= 0) return LFVDM_E_SHAPE;
-    const size_t lds = (size_t)(C + 1) * 9 * Cout * sizeof(float);
+    size_t lds = (size_t)(C + 1) * 9 * Cout * sizeof(float);
     if (lds > 64 * 1024) return LFVDM_E_UNSUPPORTED;
+    if (lds < 64 * sizeof(int64_t)) lds = 64 * sizeof(int64_t);
     const long total = (long)N * H * W;
-    const dim3 grid((unsigned)((total + 63) / 64));
-    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((total + 63) / 64) + (tk.t ? 1u : 0u));
 #define LFVDM_CONV_IN(Q)                                                                                              \
     case Q:                                                                                                           \
-        if (C == 4) hipLaunchKernelGGL((conv_in_kernel<Q, 5>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W);      \
-        else if (C == 3) hipLaunchKernelGGL((conv_in_kernel<Q, 4>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W); \
-        else hipLaunchKernelGGL((conv_in_kernel<Q, 0>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W);             \
+        if (C == 4) hipLaunchKernelGGL((conv_in_kernel<Q, 5>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W, tk);      \
+        else if (C == 3) hipLaunchKernelGGL((conv_in_kernel<Q, 4>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W, tk); \
+        else hipLaunchKernelGGL((conv_in_kernel<Q, 0>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W, tk);             \
         break;
     switch (Cout / 16) {
         LFVDM_CONV_IN(1) LFVDM_CONV_IN(2) LFVDM_CONV_IN(3) LFVDM_CONV_IN(4) LFVDM_CONV_IN(5) LFVDM_CONV_IN(6) LFVDM_CONV_IN(7)
@@ -988,6 +1018,22 @@ extern "C" int lfvdm_conv_in(const float* x, const float* x0, const float* obs, 
 #undef LFVDM_CONV_IN
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
+}
+
+extern "C" int lfvdm_conv_in(const float* x, const float* x0, const float* obs, const float* w, const float* bias,
+                             float* out, int N, int C, int H, int W, int Cout, void* stream) {
+    const ConvInTick none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    return conv_in_launch(x, x0, obs, w, bias, out, N, C, H, W, Cout, none, (hipStream_t)stream);
+}
+
+extern "C" int lfvdm_conv_in_tick(const float* x, const float* x0, const float* obs, const float* w, const float* bias,
+                                  float* out, int N, int C, int H, int W, int Cout, int64_t* t,
+                                  const float* model_timestep_table, float* model_t, int B, const float* rows_all, int rows_ld,
+                                  float* rows, int row_floats, void* stream) {
+    if (B <= 0 || B > 64 || !t || !model_timestep_table || !model_t || !rows_all || !rows) return LFVDM_E_SHAPE;
+    if (row_floats <= 0 || (row_floats & 3) || (rows_ld & 3) || rows_ld < row_floats) return LFVDM_E_SHAPE;
+    const ConvInTick tk = {t, model_timestep_table, model_t, rows_all, rows, B, rows_ld, row_floats};
+    return conv_in_launch(x, x0, obs, w, bias, out, N, C, H, W, Cout, tk, (hipStream_t)stream);
 }
 
 namespace {

@@ -559,8 +559,11 @@ class Plan:
             nat.check(L.lfvdm_pack_conv_weight(_p(w), _p(out), w.shape[0], w.shape[1], w.shape[2], s), "pack")
         self._sig = self.weight_signature()
 
-    def launch(self, side=None, side_head=None, side_tail=None):
+    def launch(self, side=None, side_head=None, side_tail=None, tick=None):
         """Enqueue the whole forward (graph-capturable: no sync, no alloc).
+
+        ``tick`` = (t_buf, ts_table), sampler only, timestep tables only: the clock (``Plan.tick``) rides in the first
+        launch of the forward, lfvdm_conv_in_tick - nothing in the first conv reads the timestep.
 
         Default: every launch on the current stream.  With ``side`` (a second stream; used by the captured sampler
         step): the launches that depend on the timestep and frame indices only - the three embedding row-dot
@@ -569,14 +572,20 @@ class Plan:
         consumer and for the R tensors in front of the first temporal attention.  ``side_head`` / ``side_tail``:
         callables enqueued on the side stream before / after those launches (the sampler's clock tick and its
         noise draw); the caller joins the side stream itself after ``side_tail``."""
+        L = nat.lib()
         if side is None:
             s = nat.stream()
             for fn, args in self.steps:
-                rc = fn(*args, s)
+                if tick is not None and fn is L.lfvdm_conv_in:
+                    rc = L.lfvdm_conv_in_tick(*args, _p(tick[0]), _p(tick[1]), _p(self.tin), self.B, _p(self.rows_all),
+                                              self.rows_ld, _p(self.rows), self.film_floats, s)
+                    tick = None
+                else:
+                    rc = fn(*args, s)
                 if rc:
                     nat.check(rc, getattr(fn, "__name__", "kernel"))
+            assert tick is None, "the plan has no lfvdm_conv_in launch to carry the clock"
             return
-        L = nat.lib()
         main = th.cuda.current_stream()
         n_time = 0
         while n_time < len(self.steps) and self.steps[n_time][0] in (L.lfvdm_rowdot, L.lfvdm_rpe_nets, L.lfvdm_rpe_nets_maxc):

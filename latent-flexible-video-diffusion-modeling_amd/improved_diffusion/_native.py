@@ -106,6 +106,9 @@ _SIGS = {
     "lfvdm_gn_apply_ws": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_i, c_fp, c_fp, c_fp, c_fp, c_fp,
                            C.c_long, c_fp], c_i),
     "lfvdm_compose_rows": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_conv_in_tick": ([c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i,
+                            c_fp], c_i),
+    "lfvdm_p_sample_rng": ([c_fp] * 9 + [c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_stats": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_apply": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_bwd_apply_params": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i,
@@ -400,6 +403,14 @@ def p_sample(x, eps, noise, t, recip, recipm1, c1, c2, logvar, clip, sample, pre
     check(lib().lfvdm_p_sample(ptr(x), ptr(eps), ptr(noise), ptr(t, torch.int64), ptr(recip), ptr(recipm1), ptr(c1),
                                ptr(c2), ptr(logvar), int(bool(clip)), ptr(sample), ptr(pred), ptr(mean), B,
                                x.numel() // B, stream()), "lfvdm_p_sample")
+
+
+def p_sample_rng(x, eps, noise_out, t, recip, recipm1, c1, c2, logvar, clip, sample, seed, pred=None, mean=None):
+    """p_sample with the noise drawn in the kernel (Philox keyed by the device int64 ``seed``)."""
+    B = x.shape[0]
+    check(lib().lfvdm_p_sample_rng(ptr(x), ptr(eps), ptr(noise_out), ptr(t, torch.int64), ptr(recip), ptr(recipm1), ptr(c1),
+                                   ptr(c2), ptr(logvar), int(bool(clip)), ptr(sample), ptr(pred), ptr(mean), B,
+                                   x.numel() // B, ptr(seed, torch.int64), stream()), "lfvdm_p_sample_rng")
 
 
 def prepare_batch(pool, table, batch, frame_indices, obs_mask, latent_mask):

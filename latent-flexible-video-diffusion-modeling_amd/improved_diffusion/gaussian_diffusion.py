@@ -468,6 +468,10 @@ class GraphSampler:
         self._ts_key = tuple(self.ts_table.tolist())
         self.noise = th.empty(self.shape, device=dev)
         self.pred = th.empty(self.shape, device=dev)
+        # the replayed step draws its noise inside the update kernel (lfvdm_p_sample_rng: Philox keyed by a per-chain seed
+        # that begin() takes from torch's generator, so th.manual_seed still fixes the video); LFVDM_SAMPLER_NOISE=torch
+        # keeps the th.randn launch
+        self.seed = th.zeros(1, dtype=th.int64, device=dev)
         self.graph = None
         self.expected_t = None
         import os
@@ -476,6 +480,7 @@ class GraphSampler:
         self.side = th.cuda.Stream() if os.environ.get("LFVDM_SAMPLER_FORK", "0") == "1" else None
 
     def _step_body(self):
+        import os
         pl, tb = self.plan, self.tb
 
         def tick():     # device-side clock: t <- max(t - 1, 0), model timestep <- table[t]  (t_buf holds "previous t");
@@ -486,9 +491,20 @@ class GraphSampler:
             # noise draw - runs on a second branch of the captured step, beside the head of the U-Net chain
             pl.launch(side=self.side, side_head=tick, side_tail=self.noise.normal_)
             th.cuda.current_stream().wait_stream(self.side)      # join: the update needs t, the noise and eps
+        elif pl.time_steps and os.environ.get("LFVDM_TICK_IN_CONV", "1") != "0":
+            pl.launch(tick=(self.t_buf, self.ts_table))      # the clock rides in the first launch of the forward
+            self.extra_launches = 1                           # (the update; bench.py reports launches per step)
         else:
             tick()
             pl.launch()
+            self.extra_launches = 2
+        if self.side is None and os.environ.get("LFVDM_SAMPLER_NOISE", "kernel") != "torch":
+            nat.p_sample_rng(pl.x_in, pl.out, self.noise, self.t_buf, tb["sqrt_recip_alphas_cumprod"],
+                             tb["sqrt_recipm1_alphas_cumprod"], tb["posterior_mean_coef1"], tb["posterior_mean_coef2"],
+                             tb["model_log_variance"], self.clip, pl.x_in, self.seed, self.pred, None)
+            return
+        self.extra_launches = getattr(self, "extra_launches", 2) + 1
+        if self.side is None:
             self.noise.normal_()
         nat.p_sample(pl.x_in, pl.out, self.noise, self.t_buf, tb["sqrt_recip_alphas_cumprod"],
                      tb["sqrt_recipm1_alphas_cumprod"], tb["posterior_mean_coef1"], tb["posterior_mean_coef2"],
@@ -540,6 +556,7 @@ class GraphSampler:
                 th.cuda.synchronize()
                 th.cuda.set_rng_state(rng_state, pl.dev)
             self.t_buf.fill_(self.diffusion.num_timesteps)     # the step pre-decrements
+            self.seed.random_()                                 # this chain's noise key (torch's generator: seedable)
         self.expected_t = self.diffusion.num_timesteps - 1
 
     def step(self, i):

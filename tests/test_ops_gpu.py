@@ -668,6 +668,44 @@ def test_gn_param_grads(nat):
             close(db, (db0.double() + s1.sum(0)).float(), 2e-5)
 
 
+def test_p_sample_rng_draws_standard_normal_noise(nat):
+    """lfvdm_p_sample_rng: the update of lfvdm_p_sample with the noise drawn in the kernel (Philox4x32-10 + Box-Muller,
+    keyed by a per-chain seed, counter = (element, batch row, timestep)).  The values it reports are the ones it used, they
+    are standard normal, a (seed, t, element) triple is reproducible, other timesteps / seeds / rows are independent, t = 0
+    adds no noise (gaussian_diffusion.py:396-400)."""
+    from scipy import stats
+    B, inner, S = 4, 262144 + 3, 1000
+    x, eps = rnd("pr/x", B, inner).cuda(), rnd("pr/e", B, inner).cuda()
+    tabs = [torch.rand(S, device="cuda") + 0.5 for _ in range(4)] + [torch.randn(S, device="cuda") * 0.3]
+    seed = torch.tensor([0x1234567, ], dtype=torch.int64, device="cuda")
+
+    def run(t, sd, want_noise=True):
+        tt = torch.tensor(t, dtype=torch.int64, device="cuda")
+        out, nz = torch.empty(B, inner, device="cuda"), torch.empty(B, inner, device="cuda") if want_noise else None
+        nat.p_sample_rng(x, eps, nz, tt, *tabs, True, out, sd, None, None)
+        return out, nz, tt
+
+    out, nz, tt = run([7, 7, 500, 0], seed)
+    ref = torch.empty_like(out)
+    nat.p_sample(x, eps, nz, tt, *tabs, True, ref)                        # the plain kernel on the reported noise
+    assert torch.equal(out, ref)
+    z = nz[:3].flatten().double().cpu().numpy()                            # (row 3 is t = 0: its noise is not used)
+    assert abs(z.mean()) < 4e-3 and abs(z.var() - 1) < 6e-3 and abs(stats.kurtosis(z)) < 0.03 and abs(stats.skew(z)) < 0.01
+    assert stats.kstest(z[:200000], "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 4e-3                    # neighbours (Box-Muller pairs included)
+    assert abs(float(torch.corrcoef(torch.stack([nz[0], nz[1]]))[0, 1])) < 6e-3      # same t, different rows
+    assert abs(float(torch.corrcoef(torch.stack([nz[0], nz[2]]))[0, 1])) < 6e-3      # different t
+    out2, nz2, _ = run([7, 7, 500, 0], seed)
+    assert torch.equal(out, out2) and torch.equal(nz, nz2)                 # reproducible
+    _, nz3, _ = run([7, 7, 500, 0], seed + 1)
+    assert abs(float(torch.corrcoef(torch.stack([nz[0], nz3[0]]))[0, 1])) < 6e-3     # another chain
+    out0, _, _ = run([7, 7, 500, 0], seed, want_noise=False)
+    assert torch.equal(out0, out)                                          # the noise output is optional
+    mean = torch.empty_like(out)
+    nat.p_sample(x, eps, torch.zeros_like(x), tt, *tabs, True, torch.empty_like(out), None, mean)
+    assert torch.equal(out[3], mean[3])                                    # t = 0: the sample is the posterior mean
+
+
 def test_sampler_tick(nat):
     t = torch.tensor([5, 0, 999], dtype=torch.int64, device="cuda")
     table = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.25
