@@ -122,13 +122,16 @@ class TrainLoop:
         self.model_params = list(self.model.parameters())
         self.master_params = self.model_params
         # gradient arena laid out in the buckets of the data-parallel exchange (backward order, _exchange.py)
-        n_buckets = int(os.environ.get("LFVDM_GRAD_BUCKETS", "4")) if self.world > 1 else 1
+        # LFVDM_FORCE_EXCHANGE=1 (testing aid): run the bucketed exchange at world size 1 too - every collective is then a
+        # SUM over one rank (the identity), which exercises the whole mechanism on the real backend with a single GPU
+        exchanging = self.world > 1 or os.environ.get("LFVDM_FORCE_EXCHANGE") == "1"
+        n_buckets = int(os.environ.get("LFVDM_GRAD_BUCKETS", "4")) if exchanging else 1
         groups, marks = plan_buckets(self.model.named_parameters(), max(1, n_buckets))
         self.arena = ParamArena(self.model_params, groups)
-        self.exchange = GradExchange(self.arena, marks, self.world)
+        self.exchange = GradExchange(self.arena, marks, self.world if self.world > 1 else (2 if exchanging else 1))
         if hasattr(self.model, "native_grad_accumulation"):
             self.model.native_grad_accumulation = True      # gradients accumulate in the arena, reduced in optimize_normal
-            self.model._grad_exchange = self.exchange if self.world > 1 else None   # bucket markers in the backward pass
+            self.model._grad_exchange = self.exchange if exchanging else None   # bucket markers in the backward pass
         if hasattr(self.model, "_engine"):
             self.model._engine = None          # parameter storage moved: drop cached device pointers
         dev = self.arena.p.device
@@ -153,7 +156,7 @@ class TrainLoop:
         self.grad_sqsum = th.zeros(1, device=dev)
         self._graph_state = {}
 
-        self.use_ddp = self.world > 1
+        self.use_ddp = exchanging
         self.ddp_model = self.model            # gradient averaging is done on the arena (see optimize_normal)
         self.exchange.broadcast(self.arena.p, *self.ema_flat)   # same initial replica everywhere (DDP: at construction)
         if self.rank == 0:

@@ -136,3 +136,64 @@ def test_trainloop_world2_matches_mean_gradient_step(microbatch):
         print(r)
     assert all(r[1] == "ok" for r in res), [r[2] for r in res if r[1] != "ok"]
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _rccl_worker(port, q):
+    """One rank, REAL backend (nccl = RCCL): the exchange is forced on (world pretended to be 2, so every bucket goes
+    through dist.all_reduce on RCCL's stream behind its device-side counter; LFVDM_FORCE_EXCHANGE) - the mechanics the
+    8-GPU job relies on, minus the wire."""
+    try:
+        for p in (PKG, ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        os.environ.pop("LFVDM_DIST_BACKEND", None)
+        os.environ["LFVDM_FORCE_EXCHANGE"] = "1"       # the bucketed exchange at world size 1: SUM over one rank = identity
+        import torch.distributed as dist
+        from improved_diffusion import dist_util, script_util as su
+        from improved_diffusion.train_util import TrainLoop
+        from test_oracle_golden import load_case
+        from test_forward_gpu import build_native
+        dist_util.setup_dist()
+        assert dist.get_backend() == "nccl"
+        cfg, sd, _ = load_case("micro")
+        model = build_native(cfg, sd).train()
+        diffusion = su.create_gaussian_diffusion(steps=1000, rescale_timesteps=True, rescale_learned_sigmas=True)
+        loop = TrainLoop(model=model, diffusion=diffusion, data=_data(2, 12, 4, 16, 7), batch_size=2, microbatch=-1,
+                         lr=1e-3, ema_rate="0.9", log_interval=1000, save_interval=10 ** 9, resume_checkpoint="", use_fp16=False,
+                         diffusion_space_kwargs={}, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.01,
+                         lr_anneal_steps=0, sample_interval=None, pad_with_random_frames=True, max_frames=4,
+                         enc_dec_chunk_size=20, args=argparse.Namespace(resume_id=""))
+        assert loop.use_ddp and loop.world == 1 and loop.exchange.world == 2 and len(loop.arena.bucket_ranges) >= 2
+        torch.manual_seed(3); np.random.seed(3)
+        for _ in range(6):
+            loop.run_step()
+            loop.step += 1
+        torch.cuda.synchronize()
+        st = dict(loop.exchange.stats)
+        n_b = len(loop.arena.bucket_ranges)
+        ok = (st["exchanges"] == 6 and st["buckets_behind_event"] == (n_b - 1) * 6 and st["buckets_behind_graph_end"] == 6
+              and not loop.exchange.flags.timed_out() and loop._graph_state.get("graph") is not None
+              and bool(torch.isfinite(loop.arena.p).all()))
+        loop.exchange.collect_timing()
+        q.put(("ok" if ok else "bad", st, [round(x, 3) for x in loop.exchange.exposed_ms]))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(("fail", traceback.format_exc(), None))
+        raise
+
+
+def test_exchange_mechanics_on_rccl():
+    """The bucketed exchange with the REAL collective backend on one GPU: graph capture next to RCCL's watchdog thread,
+    collectives on RCCL's own stream ordered behind the counter-polling kernel, the optimizer behind the collectives."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=420)
+    p.join(60)
+    print(res)
+    assert res[0] == "ok", res
+    assert p.exitcode == 0
