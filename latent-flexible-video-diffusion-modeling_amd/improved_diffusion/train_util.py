@@ -125,6 +125,8 @@ class TrainLoop:
         # LFVDM_FORCE_EXCHANGE=1 (testing aid): run the bucketed exchange at world size 1 too - every collective is then a
         # SUM over one rank (the identity), which exercises the whole mechanism on the real backend with a single GPU
         exchanging = self.world > 1 or os.environ.get("LFVDM_FORCE_EXCHANGE") == "1"
+        if exchanging and not dist.is_initialized():
+            dist_util.setup_dist()
         n_buckets = int(os.environ.get("LFVDM_GRAD_BUCKETS", "4")) if exchanging else 1
         groups, marks = plan_buckets(self.model.named_parameters(), max(1, n_buckets))
         self.arena = ParamArena(self.model_params, groups)
