@@ -399,6 +399,128 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
     }
 }
 
+// Register-resident variant for C <= 256 (like gn_temporal_reg_kernel of the forward): x and dy of the (b, pixel) sample -
+// 2 x T x C floats, <= 2 x TIT float4 per lane - are read ONCE; the kernel above reads x four times and dy twice, each
+// pass a dependent round trip through L2 (24 us per launch at the cfg-C shapes, 7 launches per training step).
+template <int TIT>
+__global__ __launch_bounds__(256) void gn_temporal_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  const float* __restrict__ gamma, float eps,
+                                                                  float* __restrict__ dx, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, int B, int T, int P, int C,
+                                                                  int accumulate) {
+    __shared__ float ch_all[4][3][256];
+    __shared__ float gst_all[4][4][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long sample_raw = (long)blockIdx.x * 4 + wave;
+    const bool live = sample_raw < (long)B * P;        // (no early return: the workgroup meets at a barrier below)
+    const long sample = live ? sample_raw : 0;
+    float* chx = ch_all[wave][0];
+    float* chd = ch_all[wave][1];
+    float* chdx = ch_all[wave][2];
+    float* gmean = gst_all[wave][0];
+    float* grstd = gst_all[wave][1];
+    float* gS1 = gst_all[wave][2];
+    float* gS2 = gst_all[wave][3];
+    const int b = (int)(sample / P), p = (int)(sample % P);
+    const int cg = C / 32;
+    const int Q = C / 4;                 // <= 64, divides 64
+    const size_t base = ((size_t)b * T * P + p) * C;
+    const size_t tstride = (size_t)P * C;
+    const int TL = 64 / Q;
+    const int q = lane % Q, tl = lane / Q;
+    f32x4 kx[TIT], kd[TIT];
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+        const int t = tl + i * TL;
+        const bool ok = t < T;
+        kx[i] = ok ? ld4(x + base + t * tstride + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        kd[i] = ok ? ld4(dy + base + t * tstride + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 ga = ld4(gamma + q * 4);
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {         // statistics exactly as in the forward
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TIT; ++i) {
+            if (tl + i * TL < T) {
+                if (pass) { const f32x4 v = kx[i] - mu; s += v * v; } else { s += kx[i]; }
+            }
+        }
+        for (int o = Q; o < 64; o <<= 1) {
+            s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64);
+            s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+        }
+        if (tl == 0) st4(chx + q * 4, s);
+        wave_lds_fence();
+        if (lane < 32) {
+            float t = 0.f;
+            for (int i = 0; i < cg; ++i) t += chx[lane * cg + i];
+            const float inv = 1.0f / (float)(cg * T);
+            if (pass == 0) gmean[lane] = t * inv; else grstd[lane] = 1.0f / sqrtf(t * inv + eps);
+        }
+        wave_lds_fence();
+        if (pass == 0) {
+            mu.x = gmean[(q * 4 + 0) / cg]; mu.y = gmean[(q * 4 + 1) / cg];
+            mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg];
+        } else {
+            rs.x = grstd[(q * 4 + 0) / cg]; rs.y = grstd[(q * 4 + 1) / cg];
+            rs.z = grstd[(q * 4 + 2) / cg]; rs.w = grstd[(q * 4 + 3) / cg];
+        }
+    }
+    // per-channel sums of dy and dy * xhat (xhat replaces x in the registers)
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+        kx[i] = (kx[i] - mu) * rs;
+        if (tl + i * TL < T) {
+            s1 += kd[i];
+            s2 += kd[i] * kx[i];
+        }
+    }
+    for (int o = Q; o < 64; o <<= 1) {
+        s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+        s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+    }
+    if (tl == 0) { st4(chd + q * 4, s1); st4(chdx + q * 4, s2); }
+    wave_lds_fence();
+    if (lane < 32) {
+        float S1 = 0.f, S2 = 0.f;
+        for (int i = 0; i < cg; ++i) { const int ch = lane * cg + i; S1 += gamma[ch] * chd[ch]; S2 += gamma[ch] * chdx[ch]; }
+        const float inv = 1.0f / (float)(cg * T);
+        gS1[lane] = S1 * inv; gS2[lane] = S2 * inv;
+    }
+    // parameter gradients: the four samples of the workgroup are summed first, then one atomic per channel
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        float g = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if ((long)blockIdx.x * 4 + w < (long)B * P) {
+                g += ch_all[w][2][ch];
+                bsum += ch_all[w][1][ch];
+            }
+        }
+        atomicAdd(dgamma + ch, g);
+        atomicAdd(dbeta + ch, bsum);
+    }
+    if (!live) return;
+    f32x4 S1, S2;
+    S1.x = gS1[(q * 4 + 0) / cg]; S1.y = gS1[(q * 4 + 1) / cg]; S1.z = gS1[(q * 4 + 2) / cg]; S1.w = gS1[(q * 4 + 3) / cg];
+    S2.x = gS2[(q * 4 + 0) / cg]; S2.y = gS2[(q * 4 + 1) / cg]; S2.z = gS2[(q * 4 + 2) / cg]; S2.w = gS2[(q * 4 + 3) / cg];
+#pragma unroll
+    for (int i = 0; i < TIT; ++i) {
+        const int t = tl + i * TL;
+        if (t < T) {
+            f32x4 o = rs * (ga * kd[i] - (S1 + kx[i] * S2));
+            float* dst = dx + base + t * tstride + q * 4;
+            if (accumulate) o += ld4(dst);
+            st4(dst, o);
+        }
+    }
+}
+
 // Parameter gradients of a (FiLM-modulated) GroupNorm from the per-(sample, channel) sums of gn_bwd_stats
 // (sums[n][c] = {sum dz, sum dz*xhat}).  Block = 64 channels x 4 sample lanes, fixed summation order (deterministic):
 //   dgamma[c] += sum_n s2 * (1 + scale[n/T][c]);  dbeta[c] += sum_n s1 * (1 + scale);
@@ -529,6 +651,22 @@ extern "C" int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const floa
                                      float* dgamma, float* dbeta, int B, int T, int P, int C, int accumulate, void* stream) {
     if (B <= 0 || T <= 0 || P <= 0 || C % 32 || C > GTB_MAXC) return LFVDM_E_SHAPE;
     const long samples = (long)B * P;
+    const int Q = C / 4;
+    static const bool no_reg = getenv("LFVDM_GNT_BWD_NO_REG") != nullptr;        // A/B aid
+    if (!no_reg && Q <= 64 && 64 % Q == 0) {       // register-resident sample: frames per lane = ceil(T / (64 / Q))
+        const int per_lane = (T + 64 / Q - 1) / (64 / Q);
+        const dim3 grid((unsigned)((samples + 3) / 4));
+        hipStream_t s = (hipStream_t)stream;
+#define LFVDM_GNTB(N)                                                                                                  \
+        if (per_lane <= N) {                                                                                           \
+            hipLaunchKernelGGL(gn_temporal_bwd_reg_kernel<N>, grid, dim3(256), 0, s, x, dy, gamma, eps, dx, dgamma, dbeta, B, T, \
+                               P, C, accumulate);                                                                      \
+            LFVDM_CHECK_LAUNCH();                                                                                      \
+            return LFVDM_OK;                                                                                           \
+        }
+        LFVDM_GNTB(8) LFVDM_GNTB(16) LFVDM_GNTB(32)
+#undef LFVDM_GNTB
+    }
     hipLaunchKernelGGL(gn_temporal_bwd_kernel, dim3((unsigned)((samples + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, dy,
                        gamma, eps, dx, dgamma, dbeta, B, T, P, C, accumulate);
     LFVDM_CHECK_LAUNCH();

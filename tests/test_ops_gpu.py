@@ -668,6 +668,30 @@ def test_gn_param_grads(nat):
             close(db, (db0.double() + s1.sum(0)).float(), 2e-5)
 
 
+@pytest.mark.parametrize("B,T,P,C", [(2, 20, 16, 128), (1, 14, 5, 256), (2, 20, 4, 64), (1, 32, 3, 96), (2, 7, 6, 384)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_gn_temporal_backward(nat, B, T, P, C, accumulate):
+    """lfvdm_gn_temporal_bwd (autograd of the GroupNorm over (C/32, T) per (b, pixel), rpe.py:135-137): dx, dgamma, dbeta vs
+    torch autograd in fp64 - the register-resident kernel (C <= 256) and the general one (96 / 384 channels), ragged
+    workgroups (B*P not a multiple of 4), dx written or accumulated."""
+    x, dy = rnd("gtb/x", B * T * P, C) * 1.2 + 0.3, rnd("gtb/dy", B * T * P, C)
+    gamma, beta = 1 + 0.1 * rnd("gtb/g", C), 0.1 * rnd("gtb/b", C)
+    xr = x.double().view(B, T, P, C).permute(0, 2, 3, 1).reshape(B * P, C, T).requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = F.group_norm(xr, 32, gr, br, eps=1e-5)
+    y.backward(dy.double().view(B, T, P, C).permute(0, 2, 3, 1).reshape(B * P, C, T))
+    want_dx = xr.grad.view(B, P, C, T).permute(0, 3, 1, 2).reshape(B * T * P, C)
+    dx0 = rnd("gtb/dx0", B * T * P, C)
+    dx = dx0.cuda().clone()
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    g = [t.cuda().contiguous() for t in (x, dy, gamma)]
+    nat.check(nat.lib().lfvdm_gn_temporal_bwd(nat.ptr(g[0]), nat.ptr(g[1]), nat.ptr(g[2]), 1e-5, nat.ptr(dx), nat.ptr(dg), nat.ptr(db),
+                                              B, T, P, C, accumulate, nat.stream()), "lfvdm_gn_temporal_bwd")
+    close(dx, (want_dx + (dx0.double() if accumulate else 0)).float(), 5e-5)
+    close(dg, gr.grad.float(), 1e-4 * max(1.0, float(gr.grad.abs().max())))
+    close(db, br.grad.float(), 1e-4 * max(1.0, float(br.grad.abs().max())))
+
+
 def test_p_sample_rng_draws_standard_normal_noise(nat):
     """lfvdm_p_sample_rng: the update of lfvdm_p_sample with the noise drawn in the kernel (Philox4x32-10 + Box-Muller,
     keyed by a per-chain seed, counter = (element, batch row, timestep)).  The values it reports are the ones it used, they

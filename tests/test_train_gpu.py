@@ -198,8 +198,10 @@ def test_device_batch_preparation_matches_host_gather(monkeypatch):
 
 def test_training_step_with_device_batch_preparation_equals_host_path(monkeypatch):
     """Whole training steps, device-prepared vs host-prepared batches (LFVDM_DEVICE_BATCH_PREP=0), same seeds, eager
-    micro-steps (LFVDM_TRAIN_GRAPH=0 makes the noise draws identical): same losses, same parameters (up to the order
-    of the weight-gradient atomics)."""
+    micro-steps (LFVDM_TRAIN_GRAPH=0 makes the noise draws identical): same losses and same gradients.  The optimizer
+    runs with lr = 0: Adam moves every element by ~lr whatever the size of its gradient, so after a few real steps the
+    order of the weight-gradient atomics decides the sign of the update wherever a gradient is rounding noise, and two
+    IDENTICAL runs already differ in ~0.2 % of the parameters - gradients at fixed parameters are the comparable quantity."""
     from improved_diffusion.logger import logger
     monkeypatch.setenv("LFVDM_TRAIN_GRAPH", "0")
     outs = {}
@@ -207,24 +209,24 @@ def test_training_step_with_device_batch_preparation_equals_host_path(monkeypatc
         monkeypatch.setenv("LFVDM_DEVICE_BATCH_PREP", mode)
         cfg, sd, _ = load_case("micro")
         model = build_native(cfg, sd).train()
-        loop = make_loop(model, lr=1e-3)
+        loop = make_loop(model, lr=0.0)
         torch.manual_seed(4); np.random.seed(4)
         logger.dumpkvs()                    # nothing left over from earlier loops in the running means
-        losses = []
+        losses, grads = [], []
         for _ in range(3):
-            loop.run_step()
+            loop.forward_backward()
+            torch.cuda.synchronize()
+            grads.append(loop.arena.g.clone())
+            loop.optimize_normal()
             loop._flush_loss_log()
             losses.append(logger.name2val["loss"])
             logger.dumpkvs()
             loop.step += 1
-        outs[mode] = (losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone())
+        outs[mode] = (losses, grads)
     assert np.allclose(outs["1"][0], outs["0"][0], rtol=1e-4), (outs["1"][0], outs["0"][0])
-    # Adam moves every element by ~lr per step whatever the size of its gradient: where a gradient is pure rounding noise
-    # (analytically zero), the order of the weight-gradient atomics decides its sign, so single elements may differ by up
-    # to 2*lr per step; everything else agrees to fp32 accuracy
-    diff = (outs["1"][1] - outs["0"][1]).abs()
-    assert float(diff.max()) <= 2 * 1e-3 * 3 + 1e-6
-    assert float((diff > 1e-5).float().mean()) < 2e-3, float((diff > 1e-5).float().mean())
+    for a, b in zip(outs["1"][1], outs["0"][1]):
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) < 2e-5 * scale, (float((a - b).abs().max()), scale)
 
 
 @pytest.mark.parametrize("mode", ["1", "2"])
