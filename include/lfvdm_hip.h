@@ -439,6 +439,9 @@ int lfvdm_sampler_tick_fetch(int64_t* t, const float* model_timestep_table, floa
  * mask is (B, T) (broadcast over the per-frame block of `frame_inner` elements) or NULL. */
 int lfvdm_masked_mse(const float* a, const float* b, const float* mask, float* out, int B, int T,
                      int frame_inner, void* stream);
+/* its backward w.r.t. pred: dpred = -2 (target - pred) * mask[b][t] * g[b] / (T * frame_inner); mask may be NULL. */
+int lfvdm_masked_mse_bwd(const float* target, const float* pred, const float* mask, const float* g, float* dpred, int B, int T,
+                         int frame_inner, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused AdamW + EMA + gradient-norm over one flat fp32 arena (train_util.py:346-357, nn.py:55-65).

@@ -109,30 +109,69 @@ __global__ __launch_bounds__(256) void p_sample_rng_kernel(const float* x, const
     }
 }
 
-// out[b] = (1/inner_total) * sum_{t, i} (a - b)^2 * mask[b, t]; one workgroup per batch row
-__global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ a, const float* __restrict__ bb,
-                                                         const float* __restrict__ mask, float* __restrict__ out, int T,
-                                                         int frame_inner) {
+// out[b] = (1/inner_total) * sum_{t, i} (a - b)^2 * mask[b, t]; one workgroup of 1024 threads per batch row, float4 loads
+// (fixed summation order: deterministic).  The first version walked the row with 256 scalar-loading threads: 24 us for
+// 82 k elements, twice per training step.
+__global__ __launch_bounds__(1024) void masked_mse_kernel(const float* __restrict__ a, const float* __restrict__ bb,
+                                                          const float* __restrict__ mask, float* __restrict__ out, int T,
+                                                          int frame_inner) {
     const int b = blockIdx.x;
     const size_t base = (size_t)b * T * frame_inner;
     float acc = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float mk = mask ? mask[b * T + t] : 1.f;
-        float s = 0.f;
-        for (int i = threadIdx.x; i < frame_inner; i += blockDim.x) {
-            const float d = a[base + (size_t)t * frame_inner + i] - bb[base + (size_t)t * frame_inner + i];
-            s += d * d * mk;
+    if ((frame_inner & 3) == 0) {
+        const int q = frame_inner >> 2, total = T * q;
+        for (int e = threadIdx.x; e < total; e += 1024) {
+            const int t = e / q;
+            const float mk = mask ? mask[b * T + t] : 1.f;
+            const f32x4 d = ld4(a + base + (size_t)e * 4) - ld4(bb + base + (size_t)e * 4);
+            acc += ((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * mk;
         }
-        acc += s;
+    } else {
+        for (int t = 0; t < T; ++t) {
+            const float mk = mask ? mask[b * T + t] : 1.f;
+            for (int i = threadIdx.x; i < frame_inner; i += 1024) {
+                const float d = a[base + (size_t)t * frame_inner + i] - bb[base + (size_t)t * frame_inner + i];
+                acc += d * d * mk;
+            }
+        }
     }
-    __shared__ float red[4];
+    __shared__ float red[16];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[b] = (red[0] + red[1] + red[2] + red[3]) / (float)((size_t)T * frame_inner);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[b] = t / (float)((size_t)T * frame_inner);
+    }
+}
+
+// its backward: dpred = -2 (target - pred) * mask[b, t] * g[b] / inner   (closed form, one launch)
+__global__ __launch_bounds__(256) void masked_mse_bwd_kernel(const float* __restrict__ target, const float* __restrict__ pred,
+                                                             const float* __restrict__ mask, const float* __restrict__ g,
+                                                             float* __restrict__ dpred, int T, int frame_inner) {
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * T * frame_inner;
+    const float sc = -2.0f * g[b] / (float)((size_t)T * frame_inner);
+    const long total = (long)T * frame_inner;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float mk = mask ? mask[b * T + (int)(i / frame_inner)] : 1.f;
+        dpred[base + i] = (target[base + i] - pred[base + i]) * (sc * mk);
+    }
 }
 
 }  // namespace
+
+extern "C" int lfvdm_masked_mse_bwd(const float* target, const float* pred, const float* mask, const float* g, float* dpred,
+                                    int B, int T, int frame_inner, void* stream) {
+    if (B <= 0 || T <= 0 || frame_inner <= 0 || !target || !pred || !g || !dpred) return LFVDM_E_SHAPE;
+    long gx = ((long)T * frame_inner + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(masked_mse_bwd_kernel, dim3((unsigned)gx, B), dim3(256), 0, (hipStream_t)stream, target, pred, mask, g, dpred,
+                       T, frame_inner);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
 
 extern "C" int lfvdm_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp,
                               const float* sqrt_1macp, float* out, int B, int inner, void* stream) {
@@ -228,7 +267,7 @@ extern "C" int lfvdm_p_sample_rng(const float* x, const float* eps, float* noise
 extern "C" int lfvdm_masked_mse(const float* a, const float* b, const float* mask, float* out, int B, int T,
                                 int frame_inner, void* stream) {
     if (B <= 0 || T <= 0 || frame_inner <= 0) return LFVDM_E_SHAPE;
-    hipLaunchKernelGGL(masked_mse_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, b, mask, out, T, frame_inner);
+    hipLaunchKernelGGL(masked_mse_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, a, b, mask, out, T, frame_inner);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -24,11 +24,9 @@ class _MaskedMSE(th.autograd.Function):
     def backward(ctx, g):
         target, pred, m = ctx.saved_tensors
         B, T = pred.shape[0], pred.shape[1]
-        inner = pred[0].numel()
-        scale = (g * (-2.0 / inner)).view(B, *([1] * (pred.dim() - 1)))
-        d = (target - pred) * scale
-        if m is not None:
-            d = d * m.view(B, T, *([1] * (pred.dim() - 2)))
+        d = th.empty_like(pred)
+        nat.check(nat.lib().lfvdm_masked_mse_bwd(nat.ptr(target), nat.ptr(pred), nat.ptr(m), nat.ptr(g.contiguous().float()),
+                                                 nat.ptr(d), B, T, pred[0, 0].numel(), nat.stream()), "lfvdm_masked_mse_bwd")
         return None, d, None
 
 

@@ -109,6 +109,7 @@ _SIGS = {
     "lfvdm_conv_in_tick": ([c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i,
                             c_fp], c_i),
     "lfvdm_p_sample_rng": ([c_fp] * 9 + [c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp], c_i),
+    "lfvdm_masked_mse_bwd": ([c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_bwd_stats": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_apply": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_bwd_apply_params": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i,

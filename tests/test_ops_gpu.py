@@ -438,6 +438,27 @@ def test_diffusion_ops(nat):
     close(mo, do.masked_mean_flat((x - eps) ** 2, mask.view(B, T, 1, 1, 1)), 1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(3, 4, 4, 16, 16), (2, 20, 4, 16, 16), (2, 5, 3, 7, 5)])
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_masked_mse_forward_and_backward(nat, shape, with_mask):
+    """_autograd.masked_mse (gaussian_diffusion.py:787-788 mean_flat((target - pred)^2 * mask)): value and gradient w.r.t.
+    the prediction vs torch autograd; frame sizes that are / are not multiples of 4."""
+    from improved_diffusion._autograd import masked_mse
+    B, T = shape[:2]
+    tgt, prd = rnd("mm/t", *shape), rnd("mm/p", *shape)
+    mask = (torch.rand(B, T, 1, 1, 1) < 0.6).float() if with_mask else None
+    pr = prd.double().requires_grad_(True)
+    d2 = (tgt.double() - pr) ** 2
+    ref = (d2 * mask.double() if with_mask else d2).flatten(1).mean(1)
+    w = torch.tensor([0.7, -1.3, 2.1])[:B].double()
+    (ref * w).sum().backward()
+    pg = prd.cuda().requires_grad_(True)
+    out = masked_mse(tgt.cuda(), pg, mask.cuda() if with_mask else None)
+    (out * w.float().cuda()).sum().backward()
+    close(out, ref.float(), 1e-6, rtol=1e-5)
+    close(pg.grad, pr.grad.float(), 1e-7, rtol=1e-5)
+
+
 def test_conv_splitk_is_exact_and_deterministic(nat):
     """Every legal (tile shape, K-chunk, split-K) variant of one small-M launch gives the same conv, and the
     split-K variants (ordered last-arriver reduction) are bitwise reproducible run to run."""
