@@ -112,7 +112,7 @@ class _WeightPacks:
             if th.cuda.is_current_stream_capturing():      # cannot upload a job table now: pack one by one
                 for key, e in self.ent.items():
                     self._pack_one(key, e[1])
-                    e[2] = self._stamp(e[0]())
+                    self._restamp(e)
                 return
             jobs, blk = [], 0
             for (ptr_, (Cout, Cin, k, _k), tr), e in self.ent.items():
@@ -123,7 +123,12 @@ class _WeightPacks:
         nat.check(nat.lib().lfvdm_pack_conv_weights(self.table.data_ptr(), self.njobs, self.blocks, nat.stream()),
                   "lfvdm_pack_conv_weights")
         for e in self.ent.values():
-            e[2] = self._stamp(e[0]())
+            self._restamp(e)
+
+    def _restamp(self, e):
+        base = e[0]()          # (a parameter of a dropped model may be collected while this method runs: pruned next time)
+        if base is not None:
+            e[2] = self._stamp(base)
 
 
 _packs = _WeightPacks()

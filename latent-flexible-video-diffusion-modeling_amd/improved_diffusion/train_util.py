@@ -320,8 +320,10 @@ class TrainLoop:
             self.ddp_model, micro, t,
             model_kwargs={'frame_indices': frame_indices, 'obs_mask': obs_mask, 'latent_mask': latent_mask, 'x0': micro},
             latent_mask=(1 - obs_mask) if self.pad_with_random_frames else latent_mask, eval_mask=latent_mask)
-        loss = (losses["loss"] * weights).mean()
-        loss.backward()          # gradients accumulate in the arena across micro-batches
+        # reference train_util.py:320-328: loss = (losses["loss"] * weights).mean(); loss.backward().  d loss / d loss[b] =
+        # weights[b] / B: the backward pass is seeded with it directly (the scalar's own
+        # forward and backward were five tiny launches); gradients accumulate in the arena across micro-batches
+        losses["loss"].backward(gradient=weights.to(losses["loss"].dtype) / weights.numel())
         return {k: (v * weights).detach() for k, v in losses.items()}, losses["loss"].detach()
 
     def _micro_step_from_pool(self, pool, table, t, weights):
