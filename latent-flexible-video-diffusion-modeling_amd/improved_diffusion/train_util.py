@@ -324,7 +324,12 @@ class TrainLoop:
         # weights[b] / B: the backward pass is seeded with it directly (the scalar's own
         # forward and backward were five tiny launches); gradients accumulate in the arena across micro-batches
         losses["loss"].backward(gradient=weights.to(losses["loss"].dtype) / weights.numel())
-        return {k: (v * weights).detach() for k, v in losses.items()}, losses["loss"].detach()
+        weighted, seen = {}, {}
+        for k, v in losses.items():          # ("loss" is the very tensor of "mse": weight each distinct term once)
+            if id(v) not in seen:
+                seen[id(v)] = (v * weights).detach()
+            weighted[k] = seen[id(v)]
+        return weighted, losses["loss"].detach()
 
     def _micro_step_from_pool(self, pool, table, t, weights):
         """Device-side batch preparation + micro-step: gather the frames named by the index table and write the mask /
