@@ -512,7 +512,9 @@ class Plan:
         jr, n_r, tiles_r = self._rpe_jobs(n_t * B, self.rows_all, self.R)
         nat.check(nat.lib().lfvdm_rpe_nets_maxc(_p(jr), n_r, tiles_r, _p(fi), n_t * B, T, max(r.rpe_net.channels for r in self.R),
                                                 nat.stream()), "lfvdm_rpe_nets")
-        th.cuda.current_stream().synchronize()
+        # no host synchronisation: the job table and the index tensor were allocated on this stream and are released to the
+        # caching allocator in stream order, so the launch above is done with them before anything can reuse the memory -
+        # and a windowed sampler (97 chains per video) keeps the host ahead of the device across windows
 
     def tick(self, t_buf, ts_table):
         """The sampler's clock (t <- max(t-1, 0); model timestep <- table[t]); with timestep tables it also fetches

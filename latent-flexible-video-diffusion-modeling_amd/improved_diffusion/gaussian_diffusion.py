@@ -464,7 +464,7 @@ class GraphSampler:
         self.tb = diffusion.tables(dev)
         self.ts_table = diffusion.model_timestep_table(dev)
         self.t_buf = self.plan.t_sel if self.plan.time_steps else th.zeros(B, dtype=th.int64, device=dev)
-        self.table_build_ms = 0.0      # time spent building the tables in the last begin()
+        self._table_events = None      # (start, end) events around the table build of the last begin()
         self._ts_key = tuple(self.ts_table.tolist())
         self.noise = th.empty(self.shape, device=dev)
         self.pred = th.empty(self.shape, device=dev)
@@ -478,6 +478,15 @@ class GraphSampler:
         # LFVDM_SAMPLER_FORK=1: timestep-only launches on a second branch of the captured step.  Measured SLOWER on MI355X
         # (1.362 vs 1.290 ms per step at cfg B: each cross-branch edge of a hipGraph costs ~20 us), so the step stays one chain
         self.side = th.cuda.Stream() if os.environ.get("LFVDM_SAMPLER_FORK", "0") == "1" else None
+
+    @property
+    def table_build_ms(self):
+        """GPU time of the table build of the last ``begin()`` (synchronises on its end event when read)."""
+        if self._table_events is None:
+            return 0.0
+        e0, e1 = self._table_events
+        e1.synchronize()
+        return e0.elapsed_time(e1)
 
     def _step_body(self):
         import os
@@ -525,8 +534,7 @@ class GraphSampler:
                     pl.build_time_tables(self.ts_table)          # once per set of weights
                 pl.build_R_tables(model_kwargs["frame_indices"])  # once per chain: R depends on this window's frames
                 e1.record()
-                e1.synchronize()
-                self.table_build_ms = e0.elapsed_time(e1)
+                self._table_events = (e0, e1)        # read lazily (table_build_ms): no host stall between windows / chains
                 self.t_buf.fill_(self.diffusion.num_timesteps)
                 pl.tick(self.t_buf, self.ts_table)               # valid FiLM rows for the tuning / warm-up launches
             if self.graph is None:
