@@ -20,11 +20,18 @@
 #include "common_hip.h"
 
 #ifdef LFVDM_STAMP
-// diagnostic build only: shader-clock stamps of workgroup 0 / thread 0 (never compiled into the product)
-__device__ unsigned long long g_stamps[128];
-#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[(i)] = clock64(); } while (0)
+// diagnostic build only (never compiled into the product): per-workgroup phase stamps of thread 0 on the 100 MHz
+// s_memrealtime clock, which is common to all CUs - launch skew, arrival order and the split-K seam become visible
+constexpr int kStampWGs = 2048, kStampN = 16;
+__device__ unsigned long long g_stamps[kStampWGs * kStampN];
+#define STAMP(i) do { const unsigned sb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                  \
+                      if (threadIdx.x == 0 && sb_ < kStampWGs) g_stamps[sb_ * kStampN + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int lfvdm_debug_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 2;
+}
+extern "C" int lfvdm_debug_stamps_clear(void) {
+    static unsigned long long zeros[kStampWGs * kStampN];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : 2;
 }
 #else
 #define STAMP(i) do {} while (0)
@@ -54,6 +61,15 @@ struct Cfg {
     static_assert((BM * QPR) % GT == 0 && (BN * QPR) % GT == 0, "tile must divide over the group");
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (workgroup-scope release of
+// global memory): in the epilogue that makes every wave wait for the acknowledgement of its output stores and for
+// the cold loads of the GroupNorm parameters at each of the three barriers of the fused normalisation.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <class T>
 __device__ __forceinline__ T sel(bool c, T a, T b) {
     return c ? a : b;
@@ -67,14 +83,22 @@ struct RowInfo {
     int m;          // clamped output row index (second-segment / residual addressing)
 };
 
-// exact floor(a / d) for 0 <= a < 2^24 with rd = 1.0f / d (one fix-up step; avoids the ~40-instruction
-// integer division sequence in the kernel prologue)
+// exact floor(a / d) for 0 <= a < 2^24 with rd = 1.0f / d, or with rd = v_rcp_f32(d) (1 ulp) while the QUOTIENT stays
+// below 2^21: the truncated product is then off by at most one and the fix-up step repairs it (avoids the
+// ~40-instruction integer division sequence)
 __device__ __forceinline__ int fast_div(int a, int d, float rd) {
     int q = (int)((float)a * rd);
     const int r = a - q * d;
     q += (r >= d) ? 1 : 0;
     q -= (r < 0) ? 1 : 0;
     return q;
+}
+
+// exact a / d for 0 <= a < 2^21, d >= 1: v_rcp_f32 is accurate to 1 ulp, so the truncated product is off by at most
+// one and fast_div's fix-up step repairs it (a generic 32-bit division is ~25 instructions, a 64-bit one ~150; the
+// kernel prologue is instruction-bound: a lone wave issues one instruction per 4-5 cycles)
+__device__ __forceinline__ int div_small(int a, int d) {
+    return fast_div(a, d, __builtin_amdgcn_rcpf((float)d));
 }
 
 template <int AE, int WE>
@@ -249,11 +273,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         kz = 0;
         if (b >= hyb_nfull) {
             const int r = b - hyb_nfull;
-            tile = hyb_nfull + r / hyb_kz;
-            kz = r - (r / hyb_kz) * hyb_kz;
+            const int q = div_small(r, hyb_kz);
+            tile = hyb_nfull + q;
+            kz = r - q * hyb_kz;
             KZ = hyb_kz;
         }
-        by = tile / MT;
+        by = div_small(tile, MT);
         bx = tile - by * MT;
         tile_id = (size_t)(tile - hyb_nfull);
     }
@@ -261,8 +286,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     const int n0 = by * BN;
     const int Cin = p.C0 + p.C1;
     const int taps = p.ksize * p.ksize;
-    const int NK1 = taps * (Cin / KC);
-    const int NK = NK1 + (p.s2C0 + p.s2C1) / KC;
+    const int NK1 = taps * (int)((unsigned)Cin / (unsigned)KC);
+    const int NK = NK1 + (int)((unsigned)(p.s2C0 + p.s2C1) / (unsigned)KC);
 
     STAMP(0);
     float* gbase = smem + wk * CF::GROUP_LDS;
@@ -272,15 +297,23 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     // release/acquire - sums the slabs in a fixed order: deterministic, no float atomics), then over the
     // k-groups of the workgroup.  Every group runs `iters` iterations (same barrier count); a group that
     // owns fewer chunks replays its last chunk with everything masked to zero.
-    const int zbeg = (int)(((long)NK * kz) / KZ), zend = (int)(((long)NK * (kz + 1)) / KZ);
+    // (all quantities are small - NK * KZ < 2^21 is checked by the launcher - and the divisors WK are powers of two)
+    int zbeg = 0, zend = NK, zmax = NK;                // zmax: chunks of the largest K slice (workgroup-uniform)
+    if (KZ > 1) {
+        zbeg = div_small(NK * kz, KZ);
+        zend = div_small(NK * (kz + 1), KZ);
+        zmax = div_small(NK + KZ - 1, KZ);
+    }
     const int NKz = zend - zbeg;
-    const int kbeg = zbeg + (int)(((long)NKz * wk) / WK);
-    const int kend = zbeg + (int)(((long)NKz * (wk + 1)) / WK);
-    const int iters = (((NK + KZ - 1) / KZ + WK - 1) / WK + 1) & ~1;   // even: the loop is unrolled by two
+    const int kbeg = zbeg + (int)((unsigned)(NKz * wk) / (unsigned)WK);
+    const int kend = zbeg + (int)((unsigned)(NKz * (wk + 1)) / (unsigned)WK);
+    const int iters_g = (int)((unsigned)(zmax + WK - 1) / (unsigned)WK);
+    const int iters = (iters_g + 1) & ~1;              // even: the register-staged loop is unrolled by two
 
     RowInfo ri[CF::AE];
-    {
-        const float rHoWo = 1.0f / (float)HoWo, rWo = 1.0f / (float)p.Wo;
+    auto decode_rows = [&]() {
+        // quotients here are sample / image-row indices (< 2^21): the 1-ulp reciprocal is exact after fast_div's fix-up
+        const float rHoWo = __builtin_amdgcn_rcpf((float)HoWo), rWo = __builtin_amdgcn_rcpf((float)p.Wo);
         const int Hin = p.up ? 2 * p.Hs : p.Hs, Win = p.up ? 2 * p.Ws : p.Ws;
 #pragma unroll
         for (int j = 0; j < CF::AE; ++j) {
@@ -294,19 +327,16 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             ri[j].ox = rem - ri[j].oy * p.Wo;
             const int cy = ri[j].oy * p.stride, cx = ri[j].ox * p.stride;
             ri[j].pix = (ri[j].n * p.Hs + cy) * p.Ws + cx;
-            unsigned tm = 0;
+            // bit t = 3 * (dy + 1) + (dx + 1): tap inside the image.  The centre row / column always is (conv arithmetic
+            // checked by the launcher), so the mask is an outer product of a row and a column triple
+            unsigned tm = 1u;
             if (p.ksize == 3) {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
-                    tm |= ((unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win ? 1u : 0u) << t;
-                }
-            } else {
-                tm = 1u;
+                const unsigned xb = ((unsigned)(cx - 1) < (unsigned)Win ? 1u : 0u) | 2u | ((unsigned)(cx + 1) < (unsigned)Win ? 4u : 0u);
+                tm = ((unsigned)(cy - 1) < (unsigned)Hin ? xb : 0u) | (xb << 3) | ((unsigned)(cy + 1) < (unsigned)Hin ? (xb << 6) : 0u);
             }
             ri[j].taps = ri[j].valid ? tm : 0u;
         }
-    }
+    };
 
     int wrow[CF::WE];       // clamped filter row of this thread's W elements
     unsigned wmask = 0;     // bit j: that filter row exists
@@ -355,22 +385,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     int upy[XE], upx[XE];
     unsigned upb[XE], upq[XE];
 #pragma unroll
-    for (int j = 0; j < AE; ++j) {
-        const int e = gt + j * CF::GT, r = e >> RSH, sl = e & (QPR - 1);
-        const unsigned q16 = (unsigned)(sl ^ (KC == 32 ? ((r >> 1) & 7) : (r & 15))) * 16u;
-        aoff[j] = (unsigned)ri[j].pix * p.C0 * 4u + q16;
-        amsk[j] = ri[j].taps | (ri[j].valid ? 0x80000000u : 0u);     // bit 31: the output row exists (skip segment)
-        if constexpr (!SIMPLE) {
-            aoff1[j] = (unsigned)ri[j].pix * p.C1 * 4u + q16;
-            soff0[j] = (unsigned)ri[j].m * p.s2C0 * 4u + q16;
-            soff1[j] = (unsigned)ri[j].m * p.s2C1 * 4u + q16;
-            upy[j] = ri[j].oy * p.stride;
-            upx[j] = ri[j].ox * p.stride;
-            upb[j] = (unsigned)ri[j].n * p.Hs * p.Ws;
-            upq[j] = q16;
-        }
-    }
-#pragma unroll
     for (int j = 0; j < WE; ++j) {
         const int e = gt + j * CF::GT, r = e >> RSH, sl = e & (QPR - 1);
         const unsigned q16 = (unsigned)(sl ^ (KC == 32 ? ((r >> 1) & 7) : (r & 15))) * 16u;
@@ -378,6 +392,28 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         woff[j] = ok ? (unsigned)wrow[j] * wld * 4u + q16 : kOOB;
         if constexpr (!SIMPLE) w2off[j] = ok ? (unsigned)wrow[j] * w2ld * 4u + q16 : kOOB;
     }
+    // The output-row decode (decode_rows: ~60 instructions per staged row) runs AFTER the filter pieces of the
+    // look-ahead chunks have been issued: filters are cold (last read one denoising step ago), their pieces are the
+    // long pole of the first chunk, and they depend on nothing but the tile position.
+    auto prepare_rows = [&]() {
+        decode_rows();
+#pragma unroll
+        for (int j = 0; j < AE; ++j) {
+            const int e = gt + j * CF::GT, r = e >> RSH, sl = e & (QPR - 1);
+            const unsigned q16 = (unsigned)(sl ^ (KC == 32 ? ((r >> 1) & 7) : (r & 15))) * 16u;
+            aoff[j] = (unsigned)ri[j].pix * p.C0 * 4u + q16;
+            amsk[j] = ri[j].taps | (ri[j].valid ? 0x80000000u : 0u);     // bit 31: the output row exists (skip segment)
+            if constexpr (!SIMPLE) {
+                aoff1[j] = (unsigned)ri[j].pix * p.C1 * 4u + q16;
+                soff0[j] = (unsigned)ri[j].m * p.s2C0 * 4u + q16;
+                soff1[j] = (unsigned)ri[j].m * p.s2C1 * 4u + q16;
+                upy[j] = ri[j].oy * p.stride;
+                upx[j] = ri[j].ox * p.stride;
+                upb[j] = (unsigned)ri[j].n * p.Hs * p.Ws;
+                upq[j] = q16;
+            }
+        }
+    };
     // fragment read offsets (floats, relative to the stage): A row 32*wm + (lane & 31), W row 32*NT*wn + (lane & 31)
     // (+ 32 t: same swizzle), logical slot 2g + (lane >> 5)
     int offA[KC / 8], offW[KC / 8];
@@ -390,15 +426,19 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             offW[g] = (BM + rw) * KC + (((2 * g + h) ^ fw) << 2);
         }
     }
-    const int klast = max(kend - 1, 0);
     const int k3 = p.ksize == 3 ? 1 : 0;
     const int pC0 = p.C0, pC1 = p.C1, pS0 = p.s2C0, pS1 = p.s2C1, pWs = p.Ws;   // by-value copies for the selects below
-    auto issue = [&](int kc_raw, int stage) {       // everything but the per-lane offsets is wave-uniform
+    // (channel chunk, tap) of the next chunk: the chunks of a k-group are issued in order, so the pair is carried as
+    // scalar state and advanced after every issue - one division per kernel instead of one per chunk.  Chunks past the
+    // group's slice (kc_raw >= kend: padding iterations of a group that owns fewer chunks) pass out-of-range offsets
+    // on every lane, whatever the pair says.
+    int nx_ci = div_small(kbeg, taps), nx_tap = kbeg - nx_ci * taps;
+    auto issue = [&](int kc_raw, int stage, bool doA = true, bool doW = true) {   // all but the per-lane offsets is wave-uniform
         const bool live = kc_raw < kend;
-        const int kc = min(kc_raw, klast);
-        const bool main_seg = SIMPLE ? true : kc < NK1;
-        const int kk = main_seg ? kc : kc - NK1;
-        const int ci = main_seg ? kk / taps : kk, tap = main_seg ? kk - ci * taps : 0, cc = ci * KC;
+        const bool main_seg = SIMPLE ? true : kc_raw < NK1;
+        const int ci = main_seg ? nx_ci : kc_raw - NK1, tap = main_seg ? nx_tap : 0, cc = ci * KC;
+        nx_tap += 1;
+        if (nx_tap == taps) { nx_tap = 0; nx_ci += 1; }
         const int c0 = sel(main_seg, pC0, pS0);
         const bool second = SIMPLE ? false : cc >= c0;
         const int cl = second ? cc - c0 : cc;
@@ -417,6 +457,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         float* Wst = As + BM * KC;
 #pragma unroll
         for (int j = 0; j < AE; ++j) {
+            if (!doA) break;
             unsigned base = aoff[j];
             if constexpr (!SIMPLE) {   // by-value selects (a ternary on array elements selects an ADDRESS: arrays go to scratch)
                 const unsigned o0 = aoff[j], o1 = aoff1[j], o2 = soff0[j], o3 = soff1[j];
@@ -436,6 +477,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         }
 #pragma unroll
         for (int j = 0; j < WE; ++j) {
+            if (!doW) break;
             unsigned base = woff[j];
             if constexpr (!SIMPLE) {
                 const unsigned o0 = woff[j], o1 = w2off[j];
@@ -446,7 +488,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                                                      (int)off, 0, 0, 0);
         }
     };
-    const int iters_g = ((NK + KZ - 1) / KZ + WK - 1) / WK;            // chunks of the largest K slice (workgroup-uniform)
 #define LFVDM_GSTEP(S_, IT_)                                                                                    \
     do {                                                                                                       \
         /* RAW: this wave's pieces of the chunk have landed (counted vmcnt) before it arrives at the barrier.  \
@@ -471,8 +512,19 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[t][e], acc[t], 0, 0, 0);           \
         }                                                                                                      \
     } while (0)
+    {   // look-ahead chunks: filter pieces, row decode, activation pieces
+        const int ci0 = nx_ci, tap0 = nx_tap;
 #pragma unroll
-    for (int d = 0; d < GL - 1; ++d) issue(kbeg + d, d);
+        for (int d = 0; d < GL - 1; ++d) issue(kbeg + d, d, false, true);
+        nx_ci = ci0;
+        nx_tap = tap0;
+        prepare_rows();
+#pragma unroll
+        for (int d = 0; d < GL - 1; ++d) issue(kbeg + d, d, true, false);
+        // queue order is W(0) [W(1)] A(0) [A(1)]: chunk 0 is complete once only A(1) is outstanding (the counted wait of
+        // the first step assumes the steady-state order A(k) W(k))
+        if constexpr (GL == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AE) : "memory");
+    }
     STAMP(1);
     int it = 0;
     if constexpr (GL == 2) {
@@ -490,6 +542,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
   } else {
     // Two chunks are kept in flight in registers (R0, R1): the loads of chunk k+2 are issued before the
     // MFMAs of chunk k, so a load has two compute phases (~2 x 1024 MFMA cycles) to come back.
+    decode_rows();
     ChunkRegs<CF::AE, CF::WE> R0, R1;
     f32x4 ca[CF::AE], cb[CF::AE];
 #pragma unroll
@@ -555,7 +608,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
 #undef LFVDM_MFMA
   }
     STAMP(2);
-    __syncthreads();   // all fragment reads done before the stages are reused for the reduction
+    lds_barrier();   // all fragment reads done before the stages are reused for the reduction
 
     // ---- cross-k-group reduction through LDS: group wk writes its partial block tile ----
     float* red = gbase;
@@ -566,7 +619,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             red[row * RED_LD + 32 * NT * wn + t * 32 + (lane & 31)] = acc[t][r];
         }
-    __syncthreads();
+    lds_barrier();
+    STAMP(3);
 
     // ---- split-K over workgroups (KZ > 1): every slice stores its partial tile to a slab of the
     // workspace; the slice that arrives LAST at the tile's counter sums all slabs in FIXED order (slice
@@ -576,8 +630,18 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     // last arriver: acquire fence -> barrier -> plain loads.
     bool do_epilogue = true;
     if (KZ > 1) {
+        // Slabs are published WRITE-THROUGH (16-byte `sc1` stores: the bytes leave the XCD's L2 at once, no dirty
+        // lines for a release fence to write back) and read back with `sc1` loads (served below the reading CU's L1),
+        // which takes the `buffer_wbl2` / `buffer_inv` pair - 1.3 us of the 3.0 us seam in the in-kernel phase table,
+        // DESIGN.md §5 - off the critical path (MI355X guide, "Valid forms": every store of the handed-off bytes `sc1`,
+        // every storing wave drains vmcnt, workgroup barrier, ONE lane's agent-scope counter add; the workgroup whose
+        // add returned last reads after a barrier that lane joins, every load `sc1`).  LFVDM_SEAM_FENCES builds keep
+        // the fenced form (plain stores, release fence; acquire fence, plain loads) for A/B runs.
         constexpr int QNs = BN / 4;
         float* slab = p.splitk_ws + (tile_id * KZ + kz) * (size_t)(BM * BN);
+#ifndef LFVDM_SEAM_FENCES
+        const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, BM * BN * 4, 0x00020000);
+#endif
         for (int e = tid; e < BM * QNs; e += CF::NTHREADS) {
             const int row = e / QNs, c4 = (e - row * QNs) * 4;
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -586,37 +650,65 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                 const float* r = smem + w * CF::GROUP_LDS + row * RED_LD + c4;
                 t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
             }
+#ifdef LFVDM_SEAM_FENCES
             st4(slab + row * BN + c4, t);
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rs_slab, (row * BN + c4) * 4, 0, 16 /* sc1 */);
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        STAMP(4);
         __shared__ int s_last;
         if (tid == 0) {
+#ifdef LFVDM_SEAM_FENCES
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            STAMP(9);
             const int ticket = __hip_atomic_fetch_add(p.splitk_cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (ticket == KZ - 1) ? 1 : 0;
+            STAMP(10);
             if (s_last) {
                 // self-cleaning ticket: nobody else touches it once all KZ slices have arrived, and the next
                 // launch is stream-ordered behind this one - no memset node per launch
                 __hip_atomic_store(p.splitk_cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef LFVDM_SEAM_FENCES
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                STAMP(11);
             }
         }
         __syncthreads();
+        STAMP(5);
         do_epilogue = s_last != 0;
         if (do_epilogue) {
             // ordered sum of the KZ slabs back into the LDS tile of group 0 (the epilogue below reads it)
             const float* base = p.splitk_ws + tile_id * KZ * (size_t)(BM * BN);
+#ifndef LFVDM_SEAM_FENCES
+            const __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, KZ * BM * BN * 4, 0x00020000);
+#endif
             for (int e = tid; e < BM * QNs; e += CF::NTHREADS) {
                 const int row = e / QNs, c4 = (e - row * QNs) * 4;
                 f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#ifdef LFVDM_SEAM_FENCES
                 for (int z = 0; z < KZ; ++z) t += ld4(base + (size_t)z * (BM * BN) + row * BN + c4);
+#else
+                // all slab loads of the element in flight at once (KZ <= 8: cfg_valid), summed in slice order
+                u32x4 sv[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z)
+                    sv[z] = __builtin_amdgcn_raw_buffer_load_b128(rs_all, z < KZ ? (z * (BM * BN) + row * BN + c4) * 4 : -1, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int z = 0; z < 8; ++z)
+                    if (z < KZ) t += __builtin_bit_cast(f32x4, sv[z]);
+#endif
                 float* r = smem + row * RED_LD + c4;
                 r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
             }
-            __syncthreads();
+            lds_barrier();
+            STAMP(6);
         }
     }
     if (!do_epilogue) return;
@@ -669,7 +761,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             const int m = m0 + row;
             if (store_raw && m < M && cok && row0 + i * RSTEP < BM) st4(p.out + ((size_t)m * p.ldo + co), t);
         }
-        STAMP(3);
+        STAMP(7);
         if (gn) {
             // ---- fused GroupNorm(+FiLM)(+activation) of the output tile.  The launcher guarantees whole samples
             // (P = Ho*Wo divides BM) and whole groups (gw = Cout/32 divides BN) per tile.  The finished values go
@@ -677,6 +769,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             // exact two-pass mean / variance per (sample, group) unit, then the affine on the registers.
             // the per-channel / per-sample coefficients are fetched first: their latency hides behind the statistics
             const int P = HoWo, gw = p.Cout >> 5;
+            const float rPF = __builtin_amdgcn_rcpf((float)(P * p.gn_film_div)), rP = __builtin_amdgcn_rcpf((float)P),
+                        rgw = __builtin_amdgcn_rcpf((float)gw);       // fast_div operands here are < 2^21
             f32x4 gam = {0.f, 0.f, 0.f, 0.f}, bet = gam, fsc[EPV], fsh[EPV];
             if (cok) {
                 gam = ld4(p.gn_gamma + cc);
@@ -688,12 +782,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                 fsh[i] = fsc[i];
                 const int m = min(m0 + min(row0 + i * RSTEP, BM - 1), M - 1);
                 if (p.gn_film && cok) {
-                    const float* fl = p.gn_film + (size_t)((m / P) / p.gn_film_div) * p.gn_film_ld + cc;
+                    const float* fl = p.gn_film + (size_t)fast_div(m, P * p.gn_film_div, rPF) * p.gn_film_ld + cc;
                     fsc[i] = ld4(fl);
                     fsh[i] = ld4(fl + p.Cout);
                 }
             }
-            __syncthreads();                 // every partial-tile read above is done before group 0's tile is rewritten
+            lds_barrier();                 // every partial-tile read above is done before group 0's tile is rewritten
 #pragma unroll
             for (int i = 0; i < EPV; ++i) {
                 if (row0 + i * RSTEP < BM) {
@@ -701,26 +795,38 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                     r[0] = tv[i].x; r[1] = tv[i].y; r[2] = tv[i].z; r[3] = tv[i].w;
                 }
             }
-            const int SPT = BM / P, GPT = BN / gw, U = SPT * GPT;          // samples / groups / units per tile
+            const int SPT = div_small(BM, P), GPT = div_small(BN, gw), U = SPT * GPT;   // samples / groups / units per tile
             float* ustat = smem + BM * RED_LD;                               // [U][2] (mean, rstd)
-            __syncthreads();
-            int tpu = CF::NTHREADS / U;                                      // threads per unit: power of two in [1, 64]
+            lds_barrier();
+            int tpu = div_small(CF::NTHREADS, U);                            // threads per unit: power of two in [1, 64]
             tpu = tpu < 1 ? 1 : tpu > 64 ? 64 : tpu;
             tpu = 1 << (31 - __builtin_clz(tpu));
             const int li = tid & (tpu - 1);
             const int ne = P * gw;
             const float inv = 1.0f / (float)ne;
-            for (int u = tid / tpu; u < U; u += CF::NTHREADS / tpu) {        // uniform trip count within a unit's lanes
-                const int sI = u / GPT, g = u - sI * GPT;
+            // lane li of a unit walks elements e = li, li + tpu, ... of its [P][gw] slice; (row, column) advance by
+            // (tpu / gw, tpu % gw) with one carry - no division inside the two passes
+            const int dr = div_small(tpu, gw), dc = tpu - dr * gw;
+            const int r0 = div_small(li, gw), c0 = li - r0 * gw;
+            const int nit = (ne - li + tpu - 1) >> (31 - __builtin_clz(tpu));    // elements of this lane (ne >= li is not required)
+            const int ushift = 31 - __builtin_clz(tpu);
+            for (int u = tid >> ushift; u < U; u += CF::NTHREADS >> ushift) {    // uniform trip count within a unit's lanes
+                const int sI = div_small(u, GPT), g = u - sI * GPT;
                 const float* base = smem + sI * P * RED_LD + g * gw;
                 float s1 = 0.f;
-                for (int e = li; e < ne; e += tpu) s1 += base[(e / gw) * RED_LD + (e % gw)];
+                for (int it = 0, r = r0, c = c0; it < nit; ++it) {
+                    s1 += base[r * RED_LD + c];
+                    c += dc; r += dr;
+                    if (c >= gw) { c -= gw; r += 1; }
+                }
                 for (int o = tpu >> 1; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
                 const float mean = s1 * inv;
                 float s2 = 0.f;
-                for (int e = li; e < ne; e += tpu) {
-                    const float d = base[(e / gw) * RED_LD + (e % gw)] - mean;
+                for (int it = 0, r = r0, c = c0; it < nit; ++it) {
+                    const float d = base[r * RED_LD + c] - mean;
                     s2 += d * d;
+                    c += dc; r += dr;
+                    if (c >= gw) { c -= gw; r += 1; }
                 }
                 for (int o = tpu >> 1; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
                 if (li == 0) {
@@ -728,18 +834,18 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                     ustat[2 * u + 1] = 1.0f / sqrtf(s2 * inv + p.gn_eps);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (cok) {
 #pragma unroll
                 for (int i = 0; i < EPV; ++i) {
                     const int row = row0 + i * RSTEP;
                     const int m = m0 + row;
                     if (row < BM && m < M) {
-                        const int sI = row / P;
+                        const int sI = fast_div(row, P, rP);
                         const float* us = ustat + 2 * (sI * GPT);
                         f32x4 A, B;
 #define LFVDM_GNC(k, f)                                                                        \
-                        { const float* q = us + 2 * ((c4 + k) / gw); A.f = q[1] * gam.f; B.f = bet.f - q[0] * A.f; }
+                        { const float* q = us + 2 * fast_div(c4 + k, gw, rgw); A.f = q[1] * gam.f; B.f = bet.f - q[0] * A.f; }
                         LFVDM_GNC(0, x) LFVDM_GNC(1, y) LFVDM_GNC(2, z) LFVDM_GNC(3, w)
 #undef LFVDM_GNC
                         if (p.gn_film) {
@@ -754,6 +860,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                 }
             }
         }
+        STAMP(8);
     } else {
         // frame layout out[(n*Cout + co)*HoWo + pix]: consecutive threads take consecutive pixels
         for (int e = tid; e < BM * BN; e += CF::NTHREADS) {
@@ -1032,6 +1139,7 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     if ((long)a->N * a->Hs * a->Ws * (a->C0 > a->C1 ? a->C0 : a->C1) >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     if (M * (long)(C2 > a->Cout ? C2 : a->Cout) >= (1L << 31) || (long)a->N * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     if ((long)a->Cout * a->ksize * a->ksize * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
+    if (9L * Cin + C2 >= (1L << 20)) return LFVDM_E_UNSUPPORTED;     // K-slice arithmetic of the kernel: NK * KZ < 2^21
     if (a->gn_out && (!a->gn_gamma || !a->gn_beta || a->gn_film_div <= 0 || (a->gn_film && a->gn_film_ld < 2 * a->Cout)))
         return LFVDM_E_SHAPE;
     const Pick pk = pick_cfg(a, M);

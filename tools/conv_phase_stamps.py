@@ -1,0 +1,116 @@
+"""Developer aid: in-kernel phase table of the implicit-GEMM launches of the cfg-B sampler plan.
+
+Needs the diagnostic build devlib/liblfvdm_stamp.so (conv_igemm.hip compiled with -DLFVDM_STAMP: thread 0 of every
+workgroup stamps the 100 MHz s_memrealtime clock, common to all CUs, at the phase boundaries).  For every distinct
+launch shape whose template instance matches FILTER (default "1141" = <1,1,4,1>) prints, in microseconds:
+  skew   first -> last workgroup entering the kernel
+  pro    kernel entry -> first DMA pieces issued (row decode, descriptors)
+  loop   K loop (DMA wait + MFMA)
+  red    cross-k-group LDS reduction
+  slab   slab stores + vmcnt(0) + barrier           (split-K only)
+  rel    release fence                               (split-K only)
+  tick   ticket atomic round trip                    (split-K only)
+  acq    acquire fence of the last arriver           (split-K only)
+  sum    ordered slab sum                            (split-K only)
+  epi    bias / residual / raw store
+  gn     fused GroupNorm epilogue
+  span   first entry -> last stamp of any workgroup; `event` = HIP-event time per launch of the same launch
+usage: LFVDM_TUNE_CACHE=profiles/tune_cache_mi355x.json python tools/conv_phase_stamps.py [FILTER] [ch]
+"""
+import ctypes as C
+import os
+import statistics as st
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd"))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("LFVDM_LIB_PATH", os.path.join(ROOT, "devlib", "liblfvdm_stamp.so"))
+import torch as th  # noqa: E402
+
+import bench  # noqa: E402
+from improved_diffusion import _native as nat  # noqa: E402
+from improved_diffusion._engine import Plan  # noqa: E402
+
+NS, NW = 16, 2048
+
+
+def main():
+    flt = sys.argv[1] if len(sys.argv) > 1 else "1141"
+    ch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    dev = th.device("cuda")
+    model, diffusion = bench.make_model_and_diffusion(ch, dev)
+    B, T = 2, 20
+    inputs = bench.synthetic_inputs(B, T, 0, dev)
+    pl = Plan(model.native_engine(), B, T, 16, 16, False)
+    pl.refresh_weights()
+    pl.set_inputs(th.randn(B, T, 4, 16, 16, device=dev), inputs["x0"], th.tensor([500.0, 20.0], device=dev),
+                  inputs["frame_indices"], inputs["obs_mask"], inputs["latent_mask"])
+    pl.autotune()
+    L = nat.lib()
+    L.lfvdm_debug_stamps.argtypes = [C.c_void_p]
+    s = nat.stream()
+    pl.launch()
+    th.cuda.synchronize()
+    seen = set()
+    buf = (C.c_ulonglong * (NS * NW))()
+    print("inst    M Cin Cout k s2 gn kz wgs |  skew   pro  loop   red  slab   rel  tick   acq   sum   epi    gn | span event")
+    for i, (fn, args) in enumerate(pl.steps):
+        if fn is not L.lfvdm_conv_igemm:
+            continue
+        a = args[0]._obj
+        nt, nw = C.c_int(), C.c_int()
+        L.lfvdm_conv_igemm_config(C.byref(a), C.byref(nt), C.byref(nw))
+        inst = str(nt.value)
+        if flt != "all" and inst != flt:
+            continue
+        key = nat.tune_key(a) + (a.tune,)
+        if key in seen:
+            continue
+        seen.add(key)
+        t = a.tune - 1
+        kz = 1 << ((t >> 5) & 7) if a.tune > 0 else 1
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            fn(*args, s)
+        e0.record()
+        for _ in range(20):
+            fn(*args, s)
+        e1.record()
+        th.cuda.synchronize()
+        ev_us = e0.elapsed_time(e1) * 1000 / 20
+        L.lfvdm_debug_stamps_clear()
+        # a realistic predecessor (another small kernel) in front, then the launch under test
+        pl.steps[i - 1][0](*pl.steps[i - 1][1], s)
+        fn(*args, s)
+        th.cuda.synchronize()
+        L.lfvdm_debug_stamps(buf)
+        rows = [[buf[w * NS + j] for j in range(NS)] for w in range(NW)]
+        rows = [r for r in rows if r[0]]
+        t0 = min(r[0] for r in rows)
+
+        def med(f, sel=lambda r: True):
+            v = [f(r) for r in rows if sel(r)]
+            return st.median(v) / 100.0 if v else 0.0
+
+        split = any(r[4] for r in rows)
+        last = (lambda r: r[6] > 0) if split else (lambda r: True)
+        skew = (max(r[0] for r in rows) - t0) / 100.0
+        span = (max(max(r) for r in rows) - t0) / 100.0
+        cols = [skew, med(lambda r: r[1] - r[0]), med(lambda r: r[2] - r[1]), med(lambda r: r[3] - r[2])]
+        if split:
+            cols += [med(lambda r: r[4] - r[3]), med(lambda r: r[9] - r[4]), med(lambda r: r[10] - r[9]),
+                     med(lambda r: r[11] - r[10], last), med(lambda r: r[6] - r[5], last),
+                     med(lambda r: r[7] - r[6], last), med(lambda r: r[8] - r[7], last)]
+        else:
+            cols += [0, 0, 0, 0, 0, med(lambda r: r[7] - r[3]), med(lambda r: r[8] - r[7])]
+        M = a.N * a.Ho * a.Wo
+        print(f"{inst} {M:5d} {a.C0 + a.C1:3d} {a.Cout:4d} {a.ksize} {a.s2C0 + a.s2C1:3d} {int(bool(a.gn_out)):2d} {kz:2d} {len(rows):4d} | "
+              + " ".join(f"{c:5.2f}" for c in cols) + f" | {span:5.2f} {ev_us:5.2f}")
+        if os.environ.get("STAMP_DUMP"):
+            for r in sorted(rows, key=lambda r: r[0])[:int(os.environ["STAMP_DUMP"])]:
+                print("   ", [(x - t0) / 100.0 if x else None for x in r[:12]])
+
+
+if __name__ == "__main__":
+    main()
