@@ -213,6 +213,68 @@ def cpu_baseline_train(threads, budget_s):
                        "backward + torch AdamW + EMA, torch CPU fp32")
 
 
+def train_step_flops(model, B, T, H, W):
+    """Algorithmic FLOPs of ONE training step at this shape: 3 x the forward (forward + data gradient + weight gradient
+    of every contraction; SURVEY.md §8d "train step = 3x") with the forward counted in closed form - implicit GEMMs
+    2*M*Cout*K from the forward plan's launch list, temporal attention 10*B*P*T^2*C, spatial attention 4*N*P^2*C."""
+    from improved_diffusion import _native as nat
+    from improved_diffusion._engine import Plan
+    pl = Plan(model.native_engine(), B, T, H, W, False)
+    L = nat.lib()
+    conv = sum(conv_flops(a[0]._obj) for fn, a in pl.steps if fn is L.lfvdm_conv_igemm)
+    att = 0.0
+    for fn, a in pl.steps:
+        if fn is L.lfvdm_attn_temporal:
+            Bv, Tv, P, C = a[7], a[8], a[9], a[10]
+            att += 10.0 * Bv * P * Tv * Tv * C
+        elif fn is L.lfvdm_attn_spatial:
+            N, P, C = a[4], a[5], a[6]
+            att += 4.0 * N * P * P * C
+    return {"forward_conv_gemm": conv, "forward_attention": att, "step": 3.0 * (conv + att)}
+
+
+_TRAIN_FAMILIES = (
+    ("implicit GEMM forward + data gradient", ("conv_igemm_kernel",)),
+    ("weight gradients", ("conv_wgrad", "unpack_conv_grad", "wgrad")),
+    ("attention forward + backward", ("attn_", "rpe_")),
+    ("GroupNorm forward + backward", ("gn_",)),
+    ("optimizer (AdamW + EMA)", ("adamw_ema",)),
+    ("embedding network (row-dot)", ("rowdot", "silu_kernel")),
+)
+
+
+def train_family_split():
+    """Per-family GPU milliseconds of one training step from the newest committed rocprofv3 kernel summary
+    (profiles/rNN_train_kernel_stats.csv: `rocprofv3 --kernel-trace --stats -- python3 tools/train_profile.py`; steps =
+    calls of the fused optimizer kernel).  None when no summary is committed."""
+    import csv
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_kernel_stats.csv")), reverse=True)
+    if not paths:
+        return None
+    rows = []
+    with open(paths[0]) as f:
+        for r in csv.DictReader(f):
+            rows.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"])))
+    steps = sum(c for n, c, _ in rows if "adamw_ema" in n)
+    if steps <= 0:
+        return None
+    fam = {k: 0.0 for k, _ in _TRAIN_FAMILIES}
+    fam["other kernels"] = 0.0
+    launches = 0
+    for n, c, ns in rows:
+        launches += c
+        for k, pats in _TRAIN_FAMILIES:
+            if any(pt in n for pt in pats):
+                fam[k] += ns
+                break
+        else:
+            fam["other kernels"] += ns
+    return {"source": os.path.relpath(paths[0], ROOT), "profiled_steps": steps, "launches_per_step": round(launches / steps, 1),
+            "ms_per_step": {k: round(v / steps / 1e6, 3) for k, v in fam.items()},
+            "gpu_ms_per_step": round(sum(fam.values()) / steps / 1e6, 3)}
+
+
 def synthetic_video_stream(B, T_video, seed):
     g = th.Generator().manual_seed(seed)
     while True:
@@ -266,20 +328,31 @@ def bench_train(rank, world, dev, steps, warmup):
     xch = loop.exchange
     th.cuda.synchronize()
     exposed = xch.collect_timing()[-steps:] if world > 1 else []
+    fl = train_step_flops(model, 2, 20, 16, 16)
+    tfl = fl["step"] / (el / steps) / 1e12
+    roof = {"bound": "mfma", "flops_per_step": fl["step"], "forward_conv_gemm_flops": fl["forward_conv_gemm"],
+            "forward_attention_flops": fl["forward_attention"], "achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
+            "note": "whole optimizer step (wall clock, all launches) against the fp32 MFMA peak; FLOPs = 3 x forward "
+                    "(implicit GEMMs 2*M*Cout*K from the launch list + attention in closed form)",
+            "families": train_family_split()}
     out = {"optimizer_steps_per_s": round(steps / el, 3), "ms_per_step": round(1000.0 * el / steps, 2), "steps": steps,
+           "roofline": roof,
            "host_issue_ms_per_step": round(1000.0 * host / steps, 2),
            "host_wait_ms_per_step": round(1000.0 * host_wait / steps, 2),
            "global_batch": 2 * world, "videos_per_s": round(2 * world * steps / el, 2), "params": P,
            "allreduce_bytes_per_step": 4 * loop.arena.numel if world > 1 else 0, "last_loss": loss,
            "workload": "train: U-Net num_channels=128 num_res_blocks=1 max_frames=20 batch 2/GPU, AdamW+EMA, bucketed "
                        "all-reduce of the fp32 gradient arena overlapped with the backward graph (BASELINE.json configs[2])"}
-    if world > 1:
-        out["exchange"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                           "buckets": len(xch.ranges), "bucket_bytes": [4 * (hi - lo) for lo, hi in xch.ranges],
-                           "overlap_with_backward": bool(xch.overlap),
-                           "exposed_ms_per_step": round(sum(exposed) / max(1, len(exposed)), 3) if exposed else None,
-                           "buckets_started_inside_the_backward": xch.stats["buckets_behind_event"],
-                           "buckets_started_after_the_backward": xch.stats["buckets_behind_graph_end"]}
+    # the same record at every N (N = 1: no collective runs, the layout is what the N > 1 job will exchange)
+    out["exchange"] = {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "backend": dist.get_backend() if (dist.is_initialized() and world > 1) else "none (one rank)",
+                       "buckets": len(xch.ranges), "bucket_bytes": [4 * (hi - lo) for lo, hi in xch.ranges],
+                       "overlap_with_backward": bool(xch.overlap) if world > 1 else None,
+                       "overlap_probe": xch.overlap_probe,
+                       "exposed_ms_per_step": (round(sum(exposed) / max(1, len(exposed)), 3) if exposed else None) if world > 1 else 0.0,
+                       "buckets_started_inside_the_backward": xch.stats["buckets_behind_event"],
+                       "buckets_started_after_the_backward": xch.stats["buckets_behind_graph_end"]}
     return out
 
 
@@ -490,6 +563,7 @@ def main():
     el_steps = sum(times)
     el = el_steps + per_step_s * args.steps * regions
     finite = bool(th.isfinite(sampler.plan.x_in).all().item())
+    tables_info = (sampler.plan.time_table_bytes, sampler.plan.time_table_fallback)   # fallback: why the per-step plan runs
     train = None
     if args.train_steps > 0:
         del sampler
@@ -510,6 +584,7 @@ def main():
         "per_chain_setup": {"table_build_ms": round(table_ms, 3), "first_chain_table_build_ms": round(cold_setup_ms, 3),
                             "chain_steps": diffusion.num_timesteps,
                             "charged_ms_per_step": round(1000.0 * per_step_s, 5),
+                            "timestep_table_bytes": int(tables_info[0]), "fallback": tables_info[1],
                             "note": "value and ms_per_step include this amortised share; timed_seconds is the raw replay time"},
         "region_ms_per_step_min_max": [round(1000.0 * min(times) / args.steps, 4), round(1000.0 * max(times) / args.steps, 4)],
         "config": {"workload": "sample: p_sample loop, latent U-Net num_channels=64 num_res_blocks=1 max_frames=20 "
@@ -518,17 +593,27 @@ def main():
                    "frames_steps_per_s": round(world * total_steps * B * T / el, 1), "finite": finite,
                    "gpus_requested": args.gpus},
     }
-    if world > 1:
-        out["collective_world_size"] = dist.get_world_size()
-        out["collective_backend"] = ("rccl (torch 'nccl')" if backend == "nccl" else
-                                     f"{backend} - REHEARSAL: {world} ranks share {n_dev} GPU(s), not a scaling measurement")
+    # ---- the collective, self-checked: what the launcher asked for is what the process group is
+    rehearsal = world > 1 and backend != "nccl"
+    out["collective_world_size"] = dist.get_world_size() if world > 1 else 1
+    out["collective_backend"] = ("none (one rank)" if world == 1 else "rccl (torch 'nccl')" if backend == "nccl" else
+                                 f"{backend} - REHEARSAL: {world} ranks share {n_dev} GPU(s), not a scaling measurement")
+    checks = {"world_size_matches_launcher": out["collective_world_size"] == world,
+              "backend_is_rccl_or_labelled_rehearsal": world == 1 or backend == "nccl" or (rehearsal and shared_cards) or
+              bool(os.environ.get("LFVDM_BENCH_BACKEND")),
+              "ranks_have_their_own_gpu": not shared_cards or rehearsal}
+    out["self_check"] = checks
+    if not all(checks.values()):
+        raise SystemExit(f"bench.py self-check failed: {checks} (WORLD_SIZE={world}, backend={backend}, devices={n_dev})")
     if train is not None:
         out["train"] = train
-        if world > 1:       # the quantity that shards WITH an exchange, at top level
-            out["train_videos_per_s"] = train["videos_per_s"]
-            out["train_optimizer_steps_per_s"] = train["optimizer_steps_per_s"]
-            out["allreduce_bytes_per_step"] = train["allreduce_bytes_per_step"]
-            out["exposed_allreduce_ms_per_step"] = train["exchange"]["exposed_ms_per_step"]
+        # the quantity that shards WITH an exchange, at top level and in the same schema at every N
+        out["train_videos_per_s"] = train["videos_per_s"]
+        out["train_optimizer_steps_per_s"] = train["optimizer_steps_per_s"]
+        out["allreduce_bytes_per_step"] = train["allreduce_bytes_per_step"]
+        out["exposed_allreduce_ms_per_step"] = train["exchange"]["exposed_ms_per_step"]
+        out["exchange"] = {k: train["exchange"][k] for k in ("bucket_bytes", "exposed_ms_per_step",
+                                                                "buckets_started_inside_the_backward", "overlap_probe")}
     if rank == 0:
         # the single-GPU legs (configs[3], configs[4]) and the CPU baselines belong to the N = 1 line only
         if args.long_video_windows > 0 and world == 1:

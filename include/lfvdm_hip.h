@@ -460,6 +460,8 @@ typedef struct lfvdm_adamw_args {
     float bias_corr1, bias_corr2_sqrt; /* 1 - beta1^t, sqrt(1 - beta2^t) */
     float grad_scale;                  /* applied to g first (1/world_size after a SUM all-reduce) */
     float* grad_sqsum;                 /* optional: += sum (grad_scale*g)^2 */
+    const int32_t* skip_flag;          /* optional: a non-zero word (the `timed_out` word of lfvdm_flag_wait) turns the
+                                          launch into a no-op: nothing is read or written */
 } lfvdm_adamw_args;
 
 int lfvdm_adamw_ema(const lfvdm_adamw_args* a, void* stream);

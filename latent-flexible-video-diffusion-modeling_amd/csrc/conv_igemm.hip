@@ -497,6 +497,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((GL - 2) * (AE + WE)) : "memory");                  \
         __builtin_amdgcn_s_barrier();                                                                          \
         asm volatile("" ::: "memory");                                                                         \
+        if ((IT_) == 0) STAMP(15);                                                                             \
         /* look-ahead pieces first (maximum time to land), then per MFMA group: fragment reads + 4*NT MFMAs.    \
            Measured against hoisting all fragment reads / pinning the order with sched_barriers: this plain     \
            form, which lets the scheduler slide the wait + barrier of the next step above the last MFMA group, \
@@ -798,35 +799,33 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             const int SPT = div_small(BM, P), GPT = div_small(BN, gw), U = SPT * GPT;   // samples / groups / units per tile
             float* ustat = smem + BM * RED_LD;                               // [U][2] (mean, rstd)
             lds_barrier();
-            int tpu = div_small(CF::NTHREADS, U);                            // threads per unit: power of two in [1, 64]
+            STAMP(12);
+            // tpu lanes per unit (a power of two <= 64, no more than the unit has rows); lane li takes whole rows
+            // li, li + tpu, ... of the unit's [P][gw] slice - one address per row, the gw columns at constant offsets
+            int tpu = div_small(CF::NTHREADS, U);
             tpu = tpu < 1 ? 1 : tpu > 64 ? 64 : tpu;
-            tpu = 1 << (31 - __builtin_clz(tpu));
-            const int li = tid & (tpu - 1);
-            const int ne = P * gw;
-            const float inv = 1.0f / (float)ne;
-            // lane li of a unit walks elements e = li, li + tpu, ... of its [P][gw] slice; (row, column) advance by
-            // (tpu / gw, tpu % gw) with one carry - no division inside the two passes
-            const int dr = div_small(tpu, gw), dc = tpu - dr * gw;
-            const int r0 = div_small(li, gw), c0 = li - r0 * gw;
-            const int nit = (ne - li + tpu - 1) >> (31 - __builtin_clz(tpu));    // elements of this lane (ne >= li is not required)
+            tpu = tpu > P ? P : tpu;
             const int ushift = 31 - __builtin_clz(tpu);
+            tpu = 1 << ushift;
+            const int li = tid & (tpu - 1);
+            const float inv = 1.0f / (float)(P * gw);
             for (int u = tid >> ushift; u < U; u += CF::NTHREADS >> ushift) {    // uniform trip count within a unit's lanes
                 const int sI = div_small(u, GPT), g = u - sI * GPT;
-                const float* base = smem + sI * P * RED_LD + g * gw;
+                const float* base = smem + (sI * P + li) * RED_LD + g * gw;
                 float s1 = 0.f;
-                for (int it = 0, r = r0, c = c0; it < nit; ++it) {
-                    s1 += base[r * RED_LD + c];
-                    c += dc; r += dr;
-                    if (c >= gw) { c -= gw; r += 1; }
+                for (int r = li; r < P; r += tpu) {
+                    const float* row = base + (r - li) * RED_LD;
+                    for (int c = 0; c < gw; ++c) s1 += row[c];
                 }
                 for (int o = tpu >> 1; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
                 const float mean = s1 * inv;
                 float s2 = 0.f;
-                for (int it = 0, r = r0, c = c0; it < nit; ++it) {
-                    const float d = base[r * RED_LD + c] - mean;
-                    s2 += d * d;
-                    c += dc; r += dr;
-                    if (c >= gw) { c -= gw; r += 1; }
+                for (int r = li; r < P; r += tpu) {
+                    const float* row = base + (r - li) * RED_LD;
+                    for (int c = 0; c < gw; ++c) {
+                        const float d = row[c] - mean;
+                        s2 += d * d;
+                    }
                 }
                 for (int o = tpu >> 1; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
                 if (li == 0) {
@@ -834,7 +833,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
                     ustat[2 * u + 1] = 1.0f / sqrtf(s2 * inv + p.gn_eps);
                 }
             }
+            STAMP(13);
             lds_barrier();
+            STAMP(14);
             if (cok) {
 #pragma unroll
                 for (int i = 0; i < EPV; ++i) {

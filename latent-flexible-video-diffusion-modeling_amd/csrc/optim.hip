@@ -7,6 +7,9 @@
 namespace {
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(const lfvdm_adamw_args a) {
+    // a gradient bucket was reduced before the backward pass had finished writing it (lfvdm_flag_wait gave up): the
+    // gradients of this step are garbage - touch nothing, the host raises
+    if (a.skip_flag && __hip_atomic_load(a.skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int64_t n4 = a.n / 4;
     float sq = 0.f;
     const float step = a.lr / a.bias_corr1;

@@ -18,10 +18,13 @@ __global__ void flag_add_kernel(int* flag) {
 __global__ void flag_wait_kernel(const int* flag, int target, long long timeout_ticks, int* timed_out) {
     // One lane polls with device-scope loads (served by the memory side, never by this CU's L1) and sleeps between polls:
     // a parked wave, no measurable bandwidth.  The exit condition is always reached: the counter arrives, or the
-    // 100 MHz wall clock passes the deadline (then `timed_out` is raised and the host fails the step loudly).
+    // 100 MHz wall clock passes the deadline.  Then `timed_out` is raised: the optimizer launch of the step reads the
+    // word (lfvdm_adamw_args.skip_flag) and leaves parameters, moments and EMA untouched, and the host fails the step
+    // (TrainLoop polls the word every step through pinned memory, one step late, without stalling).
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {   // wrap-safe
+        // wrap-safe: both sides are plain wrapping 32-bit counters, the difference is taken modulo 2^32 and read as signed
+        while ((int)((unsigned)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)target) < 0) {
             __builtin_amdgcn_s_sleep(64);
             if (wall_clock64() - t0 > timeout_ticks) {
                 atomicExch(timed_out, 1);

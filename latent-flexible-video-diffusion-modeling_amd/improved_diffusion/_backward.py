@@ -180,7 +180,6 @@ class _PackedGrads:
         bucket is complete (_exchange.GradExchange.bucket_ready); the end-of-backward call then folds the rest."""
         if only is None:
             self.queued = False
-            _side.join()             # end of the backward pass: the weight-gradient branch joins the main chain here
         for k in [k for k, (r, _) in self.bufs.items() if r() is None]:     # parameters of freed models
             del self.bufs[k]
             self.tables.clear()
@@ -233,65 +232,6 @@ def _leaf(*ps):
     return _mode.inplace and all(p is None or p.is_leaf for p in ps)
 
 
-class _SideStream:
-    """EXPERIMENT, off by default (``LFVDM_WGRAD_SIDE=1``: every weight-gradient launch forks; ``=2``: the launches of a
-    gradient bucket are batched behind one fork): weight-gradient launches on a second stream / graph branch beside the
-    data-gradient chain.  Nothing reads a weight gradient before the optimizer (or the exchange of its bucket), the data
-    gradients are the dependent chain, so the 1.9 ms of wgrad kernels per step looked hideable.  Measured at cfg C:
-    8.38 ms (=1) and 8.30 ms (=2) per step against 8.27 ms for ONE chain - the wgrad kernels fill the chip (384
-    workgroups of 4 waves) and simply time-share it with the main chain; there is no idle capacity to overlap into.
-    Kept because the ordering rules it needed are easy to get wrong: main -> side edges only, the per-bucket fold +
-    counter bump of the exchange on the side stream, ONE join at the end of the backward pass, ``record_stream`` on every
-    operand."""
-
-    def __init__(self):
-        self.stream = None
-        self.busy = False
-
-    @staticmethod
-    def enabled():
-        return _mode.inplace and os.environ.get("LFVDM_WGRAD_SIDE", "0") != "0" and th.cuda.is_available()
-
-    def run(self, fn, tensors=(), now=False):
-        if not self.enabled():
-            return fn()
-        if os.environ.get("LFVDM_WGRAD_SIDE") == "2" and not now:      # batched: one fork per gradient bucket
-            self.pending = getattr(self, "pending", [])
-            self.pending.append((fn, tensors))
-            self.busy = True
-            return
-        self._issue([(fn, tensors)])
-
-    def flush_pending(self):
-        todo, self.pending = getattr(self, "pending", []), []
-        if todo:
-            self._issue(todo)
-
-    def _issue(self, todo):
-        main = th.cuda.current_stream()
-        if self.stream is None or self.stream.device != main.device:
-            self.stream = th.cuda.Stream(device=main.device)
-        self.stream.wait_stream(main)
-        with th.cuda.stream(self.stream):
-            for fn, _ in todo:
-                fn()
-        for _, tensors in todo:              # their blocks must outlive the side stream's use
-            for t in tensors:
-                if isinstance(t, th.Tensor) and t.is_cuda:
-                    t.record_stream(self.stream)
-        self.busy = True
-
-    def join(self):
-        """Order the current stream behind everything issued on the side stream."""
-        self.flush_pending()
-        if self.busy and self.stream is not None:
-            th.cuda.current_stream().wait_stream(self.stream)
-            self.busy = False
-
-
-_side = _SideStream()
-
-
 def _wgrad_accumulate(w, b, **kw):
     """Weight/bias gradient accumulated by the wgrad kernel without temporaries or AccumulateGrad adds: 1x1 /
     linear weights straight into ``w.grad`` (packed == OIHW), 3x3 weights into their packed accumulator, which
@@ -301,7 +241,7 @@ def _wgrad_accumulate(w, b, **kw):
     gw = _grad_of(w)
     out = _packed.buffer(w) if k == 3 else gw
     gb = _grad_of(b) if b is not None else None
-    _side.run(lambda: nat.conv_wgrad(out=out, bias=gb, Cout=w.shape[0], ksize=k, out_mode=0, **kw), tuple(kw.values()))
+    nat.conv_wgrad(out=out, bias=gb, Cout=w.shape[0], ksize=k, out_mode=0, **kw)
 
 
 def _wgrad_into(grad_w_shape, like, **kw):

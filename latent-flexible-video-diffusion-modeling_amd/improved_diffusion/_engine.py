@@ -16,6 +16,8 @@ Design (MI355X-first, not a translation of the reference's ATen op stream, unet.
 import ctypes as C
 import json
 import os
+import sys
+import weakref
 
 import torch as th
 import torch.nn as nn
@@ -34,6 +36,40 @@ FUSED_GN = os.environ.get("LFVDM_FUSED_GN", "0") == "1"
 GN_EPILOGUE = os.environ.get("LFVDM_GN_EPILOGUE", "1") != "0"
 # LFVDM_NEXT_GN_EPILOGUE=0: never evaluate the NEXT ResBlock's first GroupNorm in a producer's epilogue (A/B aid)
 NEXT_GN_EPILOGUE = os.environ.get("LFVDM_NEXT_GN_EPILOGUE", "1") != "0"
+
+
+class _TableBudget:
+    """Process-wide pool for the samplers' timestep tables (LFVDM_TIME_TABLE_GB, default 12: the headline chain needs
+    6.8 GiB, a 288 GB card has room, but the pool is shared by ALL live sampler plans and released when a plan dies)."""
+
+    def __init__(self):
+        self._held = {}
+        self._logged = set()
+
+    def limit(self):
+        return float(os.environ.get("LFVDM_TIME_TABLE_GB", "12")) * 2 ** 30
+
+    def used(self):
+        return sum(self._held.values())
+
+    def remaining(self):
+        return max(0.0, self.limit() - self.used())
+
+    def reserve(self, plan, nbytes):
+        if nbytes > self.remaining():
+            return False
+        key = id(plan)
+        self._held[key] = nbytes
+        weakref.finalize(plan, self._held.pop, key, None)
+        return True
+
+    def log(self, msg):
+        if os.environ.get("LFVDM_QUIET", "0") != "1" and msg not in self._logged:
+            self._logged.add(msg)
+            print("[lfvdm] " + msg, file=sys.stderr, flush=True)
+
+
+_table_budget = _TableBudget()
 
 
 class Plan:
@@ -243,14 +279,36 @@ class Plan:
             if r.rpe_net.channels > 512:
                 raise RuntimeError("RPE nets support at most 512 channels natively")
 
-        # ---- timestep tables (sampler plans): decide now, the launch sequence differs
+        # every parameter the tables are computed from: their versions are part of the tables' signature (a torch-side
+        # update limited to the embedding / RPE parameters - partial load_state_dict, p.data.copy_ - must rebuild them)
+        self._time_params = [te0.weight, te0.bias, te2.weight, te2.bias] + [t for _, lin, _ in heads for t in (lin.weight, lin.bias)]
+        for r in rpe_mods:
+            net = r.rpe_net
+            self._time_params += [net.embed_distances.weight, net.embed_distances.bias, net.out.weight, net.out.bias]
+
+        # ---- timestep tables (sampler plans): decide now, the launch sequence differs.  The budget is ONE pool per
+        # process shared by every live sampler plan (a long-video schedule keeps a sampler per window shape).
         self.t_sel = None
+        self.time_table_bytes = 0
+        self.time_table_fallback = None          # why the plan runs the per-step embedding / RPE launches instead
         if self.time_steps:
             Bv = self.time_steps * B
             table_bytes = 4 * Bv * (self.rows_ld + T * T * sum(r.rpe_net.channels for r in rpe_mods))
-            budget = float(os.environ.get("LFVDM_TIME_TABLE_GB", "24")) * 2 ** 30
-            if os.environ.get("LFVDM_TIME_TABLES", "1") == "0" or table_bytes > budget or B > 64:
+            if os.environ.get("LFVDM_TIME_TABLES", "1") == "0":
+                self.time_table_fallback = "disabled (LFVDM_TIME_TABLES=0)"
+            elif B > 64:
+                self.time_table_fallback = "batch > 64"
+            elif not _table_budget.reserve(self, table_bytes):
+                self.time_table_fallback = (f"{table_bytes / 2 ** 30:.1f} GiB of tables do not fit the remaining "
+                                            f"{_table_budget.remaining() / 2 ** 30:.1f} GiB of LFVDM_TIME_TABLE_GB")
+            if self.time_table_fallback:
                 self.time_steps = 0
+                _table_budget.log(f"timestep tables off for plan (B={B}, T={T}, {H}x{W}): {self.time_table_fallback}; "
+                                  "+4 launches per step")
+            else:
+                self.time_table_bytes = table_bytes
+                _table_budget.log(f"timestep tables on for plan (B={B}, T={T}, {H}x{W}): {table_bytes / 2 ** 30:.2f} GiB "
+                                  f"({_table_budget.used() / 2 ** 30:.2f} of {_table_budget.limit() / 2 ** 30:.1f} GiB in use)")
         self.R = {}
         if self.time_steps:
             Bv = self.time_steps * B
@@ -500,7 +558,7 @@ class Plan:
         nat.check(L.lfvdm_silu(_p(emb), _p(semb), emb.numel(), s), "lfvdm_silu")
         nat.check(L.lfvdm_rowdot(_p(jg), n_g, rows_g, s), "lfvdm_rowdot")
         th.cuda.current_stream().synchronize()      # the temporaries and job tables above die with this frame
-        self.tables_sig = (self.weight_signature(), tuple(ts_table.tolist()))       # (compared by GraphSampler.begin)
+        self.tables_sig = (self.time_signature(), tuple(ts_table.tolist()))       # (compared by GraphSampler.begin)
 
     def build_R_tables(self, frame_indices):
         """R_q / R_k / R_v of every temporal attention for every timestep of the chain (they depend on the timestep and
@@ -553,6 +611,11 @@ class Plan:
         # epoch is bumped explicitly by code that rewrites parameters through raw pointers (fused AdamW)
         return (self.engine.epoch,) + tuple(w._version for w, _ in self.packs)
 
+    def time_signature(self):
+        """Signature of what the timestep tables were computed from: the conv-weight signature plus the versions of the
+        time-embedding MLP, the FiLM projections and the RPE networks."""
+        return self.weight_signature() + tuple(t._version for t in self._time_params)
+
     def refresh_weights(self):
         """(Re)pack the OIHW conv weights into the [Cout][tap][Cin] layout the kernels read."""
         s = nat.stream()
@@ -561,77 +624,24 @@ class Plan:
             nat.check(L.lfvdm_pack_conv_weight(_p(w), _p(out), w.shape[0], w.shape[1], w.shape[2], s), "pack")
         self._sig = self.weight_signature()
 
-    def launch(self, side=None, side_head=None, side_tail=None, tick=None):
-        """Enqueue the whole forward (graph-capturable: no sync, no alloc).
+    def launch(self, tick=None):
+        """Enqueue the whole forward on the current stream (graph-capturable: no sync, no alloc).
 
         ``tick`` = (t_buf, ts_table), sampler only, timestep tables only: the clock (``Plan.tick``) rides in the first
-        launch of the forward, lfvdm_conv_in_tick - nothing in the first conv reads the timestep.
-
-        Default: every launch on the current stream.  With ``side`` (a second stream; used by the captured sampler
-        step): the launches that depend on the timestep and frame indices only - the three embedding row-dot
-        launches and the grouped RPE networks, ~50 us of dependent latency at the head of the chain - run on ``side``
-        beside the first convolutions of the U-Net; the main chain waits for the FiLM rows in front of their first
-        consumer and for the R tensors in front of the first temporal attention.  ``side_head`` / ``side_tail``:
-        callables enqueued on the side stream before / after those launches (the sampler's clock tick and its
-        noise draw); the caller joins the side stream itself after ``side_tail``."""
+        launch of the forward, lfvdm_conv_in_tick - nothing in the first conv reads the timestep.  (Forking the
+        timestep-only launches onto a second graph branch was measured slower - DESIGN.md §5 - and is gone.)"""
         L = nat.lib()
-        if side is None:
-            s = nat.stream()
-            for fn, args in self.steps:
-                if tick is not None and fn is L.lfvdm_conv_in:
-                    rc = L.lfvdm_conv_in_tick(*args, _p(tick[0]), _p(tick[1]), _p(self.tin), self.B, _p(self.rows_all),
-                                              self.rows_ld, _p(self.rows), self.film_floats, s)
-                    tick = None
-                else:
-                    rc = fn(*args, s)
-                if rc:
-                    nat.check(rc, getattr(fn, "__name__", "kernel"))
-            assert tick is None, "the plan has no lfvdm_conv_in launch to carry the clock"
-            return
-        main = th.cuda.current_stream()
-        n_time = 0
-        while n_time < len(self.steps) and self.steps[n_time][0] in (L.lfvdm_rowdot, L.lfvdm_rpe_nets, L.lfvdm_rpe_nets_maxc):
-            n_time += 1
-        n_emb = sum(1 for fn, _ in self.steps[:n_time] if fn is L.lfvdm_rowdot)
-        ev_film, ev_R = th.cuda.Event(), th.cuda.Event()
-        side.wait_stream(main)                       # fork
-        with th.cuda.stream(side):
-            ss = side.cuda_stream
-            if side_head is not None:
-                side_head()
-            for i, (fn, args) in enumerate(self.steps[:n_time]):
-                nat.check(fn(*args, ss), getattr(fn, "__name__", "kernel"))
-                if i == n_emb - 1:
-                    ev_film.record(side)
-            ev_R.record(side)
-            if side_tail is not None:
-                side_tail()
-        s = main.cuda_stream
-        film_ptrs = {t.data_ptr() for t in self.film.values()}
-        need_film, need_R = True, True
-        for fn, args in self.steps[n_time:]:
-            if need_film and self._reads_film(fn, args, film_ptrs):
-                main.wait_event(ev_film)
-                need_film = False
-            if need_R and fn is L.lfvdm_attn_temporal:
-                main.wait_event(ev_R)
-                need_R = False
-            rc = fn(*args, s)
+        s = nat.stream()
+        for fn, args in self.steps:
+            if tick is not None and fn is L.lfvdm_conv_in:
+                rc = L.lfvdm_conv_in_tick(*args, _p(tick[0]), _p(tick[1]), _p(self.tin), self.B, _p(self.rows_all),
+                                          self.rows_ld, _p(self.rows), self.film_floats, s)
+                tick = None
+            else:
+                rc = fn(*args, s)
             if rc:
                 nat.check(rc, getattr(fn, "__name__", "kernel"))
-        if need_film:
-            main.wait_event(ev_film)
-        if need_R:
-            main.wait_event(ev_R)
-
-    @staticmethod
-    def _reads_film(fn, args, film_ptrs):
-        L = nat.lib()
-        if fn is L.lfvdm_gn_apply or fn is L.lfvdm_gn_apply_ws or fn is L.lfvdm_gn_coef:
-            return args[8] in film_ptrs
-        if fn is L.lfvdm_conv_igemm:
-            return (args[0]._obj.gn_film or 0) in film_ptrs
-        return False
+        assert tick is None, "the plan has no lfvdm_conv_in launch to carry the clock"
 
     def set_inputs(self, x, x0, timesteps, frame_indices, obs_mask, latent_mask):
         B, T = self.B, self.T

@@ -109,14 +109,75 @@ class GradExchange:
         self.flags = None
         self.fired = [False] * self.n_early
         self.micro_steps = 0               # every micro-step (eager or replayed) bumps every early counter once
+        self.wait_timeout_s = float(os.environ.get("LFVDM_FLAG_TIMEOUT_S", "20"))
+        self.overlap_probe = None
+        self._late = []                    # (pinned word, event): the timed-out word of earlier steps, read one step late
         if self.overlap:
             from . import _native as nat
-            self.comm = th.cuda.Stream()
-            self.flags = nat.StreamFlags(self.n_early, arena.g.device)
+            self.comm = th.cuda.Stream(priority=-1)     # a wait parked here must not sit behind bulk work of other streams
+            self.overlap_probe = self._probe_overlap()
+            if self.overlap_probe["ok"]:
+                self.flags = nat.StreamFlags(self.n_early, arena.g.device)
+            else:               # the two streams share a hardware queue (or the wait gave up): exchange behind the graph's end
+                self.overlap = False
         self._works = []
         self._timing = []              # (start, end) event pairs of the exposed waits, read lazily
         self.exposed_ms = []
         self.stats = {"exchanges": 0, "buckets_behind_event": 0, "buckets_behind_graph_end": 0}
+
+    # ------------------------------------------------------------------ overlap: probe and failure handling
+    def _probe_overlap(self):
+        """Can a wait parked on the communication stream finish WHILE the main stream is still busy?  HIP maps user
+        streams onto a few hardware queues; if ``comm`` aliases the queue that replays the backward graph, every early
+        bucket would only start after the graph (no overlap) - or, with a wait dispatched in front of its signal, stall
+        until the timeout.  The probe replays the pattern once with harmless kernels: main = [signal, 5 ms busy kernel],
+        comm = [wait for the signal].  Overlap is enabled only if the wait returns, without its timeout, at least a
+        millisecond before main's busy kernel ends."""
+        from . import _native as nat
+        dev = self.arena.g.device
+        sig, busy = nat.StreamFlags(1, dev), nat.StreamFlags(1, dev)
+        main = th.cuda.current_stream()
+        e_comm, e_main = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        th.cuda.synchronize(dev)
+        with th.cuda.stream(self.comm):
+            sig.wait(0, 1, self.comm, timeout_s=0.5)        # parked BEFORE its signal exists: the bad order on purpose
+            e_comm.record(self.comm)
+        sig.add(0)
+        busy.wait(0, 1, main, timeout_s=0.005)             # never signalled: a 5 ms busy kernel (its timed-out word is private)
+        e_main.record(main)
+        th.cuda.synchronize(dev)
+        lead = e_comm.elapsed_time(e_main)
+        ok = (not sig.timed_out()) and lead > 1.0
+        return {"ok": bool(ok), "wait_returned_ms_before_main_idle": round(float(lead), 3), "wait_timed_out": bool(sig.timed_out())}
+
+    def skip_flag_ptr(self):
+        """Device word the optimizer launch checks (lfvdm_adamw_args.skip_flag): non-zero once a bucket wait gave up."""
+        return self.flags.timed_out_ptr() if self.flags is not None else None
+
+    def poll_timeout(self, sync=False):
+        """Once per optimizer step, after the optimizer launch: raises if a bucket's wait on the backward graph timed out
+        in an EARLIER step (sync=True: in any step so far).  The optimizer launch of such a step has skipped its update,
+        so parameters, moments and EMA are those of the last good step.  No host stall: the word travels through pinned
+        memory behind the step's work and is read when its event has completed - normally one step late."""
+        if self.flags is None:
+            return
+        if sync:
+            bad = self.flags.timed_out()
+        else:
+            host = th.empty(1, dtype=th.int32).pin_memory()
+            host.copy_(self.flags.buf[self.flags.n, :1], non_blocking=True)
+            ev = th.cuda.Event()
+            ev.record()
+            self._late.append((host, ev))
+            bad = False
+            while self._late and (self._late[0][1].query() or len(self._late) > 2):
+                h, e = self._late.pop(0)
+                e.synchronize()
+                bad = bad or bool(h.item())
+        if bad:
+            self.overlap = False            # whoever catches this and carries on gets the exchange behind the graph's end
+            raise RuntimeError("gradient exchange: a bucket's wait on the backward graph timed out (lfvdm_flag_wait); the "
+                               "optimizer skipped that step - parameters are those of the last good step")
 
     # ------------------------------------------------------------------ construction-time sync
     def broadcast(self, *flats):
@@ -134,16 +195,10 @@ class GradExchange:
         return _Mark.apply(h, self, k)
 
     def bucket_ready(self, k):
-        from ._backward import _packed, _side
-
-        def fold_and_signal():
-            _packed.flush(only=self.bucket_param_ids[k])          # 3x3 weight gradients of this bucket -> arena
-            if self.overlap:
-                self.flags.add(k)             # a kernel node of the graph when the micro-step is being captured
-        # on the weight-gradient stream (behind the bucket's wgrad launches there and behind everything the main
-        # chain has issued so far): the main chain itself never waits for a weight gradient before the end
-        _side.flush_pending()
-        _side.run(fold_and_signal, now=True)
+        from ._backward import _packed
+        _packed.flush(only=self.bucket_param_ids[k])          # 3x3 weight gradients of this bucket -> arena
+        if self.overlap:
+            self.flags.add(k)             # a kernel node of the graph when the micro-step is being captured
         if self.overlap:
             self.fired[k] = True
 
@@ -161,7 +216,7 @@ class GradExchange:
                     dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
             return
         if self.comm is None:
-            self.comm = th.cuda.Stream()
+            self.comm = th.cuda.Stream(priority=-1)
         main = th.cuda.current_stream()
         end = th.cuda.Event()
         end.record(main)
@@ -172,7 +227,7 @@ class GradExchange:
                     continue
                 early = k < self.n_early and self.overlap and self.fired[k] and not tail_started
                 if early:
-                    self.flags.wait(k, self.micro_steps, self.comm)
+                    self.flags.wait(k, self.micro_steps, self.comm, timeout_s=self.wait_timeout_s)
                     self.stats["buckets_behind_event"] += 1
                 else:
                     if not tail_started:

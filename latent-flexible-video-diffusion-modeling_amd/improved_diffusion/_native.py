@@ -44,7 +44,7 @@ class AdamWArgs(C.Structure):
     _fields_ = [("p", c_fp), ("g", c_fp), ("m", c_fp), ("v", c_fp), ("ema", c_fp * 4), ("ema_rate", C.c_float * 4),
                 ("n_ema", C.c_int32), ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("weight_decay", C.c_float), ("bias_corr1", C.c_float), ("bias_corr2_sqrt", C.c_float),
-                ("grad_scale", C.c_float), ("grad_sqsum", c_fp)]
+                ("grad_scale", C.c_float), ("grad_sqsum", c_fp), ("skip_flag", c_fp)]
 
 
 class RowdotJob(C.Structure):
@@ -440,8 +440,13 @@ class StreamFlags:
 
     def wait(self, k, target, torch_stream, timeout_s=20.0):
         """``torch_stream`` proceeds once counter k has reached ``target``."""
-        check(lib().lfvdm_flag_wait(self.buf[k].data_ptr(), int(target) & 0x7FFFFFFF, float(timeout_s), self.buf[self.n].data_ptr(),
+        wrapped = ((int(target) + 2 ** 31) % 2 ** 32) - 2 ** 31        # the device counter is a wrapping int32: so is the target
+        check(lib().lfvdm_flag_wait(self.buf[k].data_ptr(), wrapped, float(timeout_s), self.buf[self.n].data_ptr(),
                                     torch_stream.cuda_stream), "lfvdm_flag_wait")
+
+    def timed_out_ptr(self):
+        """Device address of the timed-out word (lfvdm_adamw_args.skip_flag)."""
+        return self.buf[self.n].data_ptr()
 
     def timed_out(self):
         """Host check (synchronises): did any wait give up?"""

@@ -246,6 +246,9 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                       device=None, progress=False, latent_mask=None, return_attn_weights=False, return_decoded=True):
         """Full ancestral sampling chain (reference :403-471) -> (samples, attn-summary dict)."""
+        if return_decoded and not self.can_decode():
+            raise NotImplementedError("p_sample_loop(return_decoded=True) needs the VAE (set_vae() / LFVDM_VAE_PATH); pass "
+                                      "return_decoded=False for latents - refused BEFORE the chain runs")
         final, attns = None, {}
         for neg_t, sample in enumerate(self.p_sample_loop_progressive(
                 model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
@@ -421,21 +424,25 @@ class GaussianDiffusion:
         st = self.pre_encoded_stats_dict
         return video * st["std"].to(video.device, video.dtype) + st["mean"].to(video.device, video.dtype)
 
+    def can_decode(self):
+        """Will ``decode`` return PIXELS?  (pixel space, or a latent space with its autoencoder attached)"""
+        return self.diffusion_space in (None, "pixel") or self.vae is not None
+
     @th.no_grad()
-    def decode(self, video, chunk_size=20):
-        """Latents -> pixels (reference :934-947).  Without an attached VAE, pre-encoded latents come back
-        de-normalised (ready for the decoder) and a warning is printed once; non-pre-encoded latents raise."""
+    def decode(self, video, chunk_size=20, allow_latents=False):
+        """Latents -> pixels (reference :934-947).  The reference always returns decoded pixels here, so without an
+        attached VAE this RAISES: a caller that treats the result as video (evaluation, FVD) must never be handed
+        4-channel latents silently.  ``allow_latents=True`` is the explicit opt-in for pre-encoded data: the
+        de-normalised latents ``z * std + mean`` - what the decoder would be fed - come back instead."""
         if self.diffusion_space in (None, "pixel"):
             return video
         if self.pre_encoded:
             video = self.denormalize_latents(video)
         if self.vae is None:
-            if not self.pre_encoded:
-                raise NotImplementedError("VAE decoding needs the SVD VAE weights: attach them with set_vae() / "
-                                          "LFVDM_VAE_PATH, or call p_sample_loop(..., return_decoded=False)")
-            if not getattr(self, "_warned_no_vae", False):
-                self._warned_no_vae = True
-                print("decode(): no VAE attached - returning de-normalised latents (set_vae() / LFVDM_VAE_PATH for pixels)")
+            if not (self.pre_encoded and allow_latents):
+                raise NotImplementedError("VAE decoding needs the SVD VAE weights: attach them with set_vae() / LFVDM_VAE_PATH, "
+                                          "call p_sample_loop(..., return_decoded=False), or ask for the de-normalised "
+                                          "latents of pre-encoded data explicitly with decode(..., allow_latents=True)")
             return video
         B, T = video.shape[:2]
         out_dtype = self.original_dtype if self.original_dtype is not None else video.dtype
@@ -448,9 +455,12 @@ class GraphSampler:
     """One denoising step (timestep remap -> U-Net forward -> noise -> x_{t-1} update -> t -= 1)
     captured as a hipGraph over the engine's static buffers; ``step`` is a single replay."""
 
-    def __init__(self, diffusion, unet, shape, clip_denoised):
+    def __init__(self, diffusion, unet, shape, clip_denoised, inject_noise=False):
+        # inject_noise (parity tests): the replayed step READS ``self.noise`` - the caller fills it before every
+        # ``step`` - instead of drawing it (the reference's th.randn_like, gaussian_diffusion.py:396)
         self.diffusion, self.unet, self.shape = diffusion, unet, tuple(shape)
         self.clip = bool(clip_denoised)
+        self.inject_noise = bool(inject_noise)
         B, T, Cx, H, W = self.shape
         from ._engine import Plan
         # a private plan: the sampler's state lives in its static buffers, so it must not be shared
@@ -474,10 +484,6 @@ class GraphSampler:
         self.seed = th.zeros(1, dtype=th.int64, device=dev)
         self.graph = None
         self.expected_t = None
-        import os
-        # LFVDM_SAMPLER_FORK=1: timestep-only launches on a second branch of the captured step.  Measured SLOWER on MI355X
-        # (1.362 vs 1.290 ms per step at cfg B: each cross-branch edge of a hipGraph costs ~20 us), so the step stays one chain
-        self.side = th.cuda.Stream() if os.environ.get("LFVDM_SAMPLER_FORK", "0") == "1" else None
 
     @property
     def table_build_ms(self):
@@ -495,25 +501,20 @@ class GraphSampler:
         def tick():     # device-side clock: t <- max(t - 1, 0), model timestep <- table[t]  (t_buf holds "previous t");
             pl.tick(self.t_buf, self.ts_table)      # with timestep tables it also fetches the FiLM rows of the new t
 
-        if self.side is not None:
-            # everything that does not depend on x_t - the clock, the timestep embeddings, the RPE networks and the
-            # noise draw - runs on a second branch of the captured step, beside the head of the U-Net chain
-            pl.launch(side=self.side, side_head=tick, side_tail=self.noise.normal_)
-            th.cuda.current_stream().wait_stream(self.side)      # join: the update needs t, the noise and eps
-        elif pl.time_steps and os.environ.get("LFVDM_TICK_IN_CONV", "1") != "0":
+        if pl.time_steps and os.environ.get("LFVDM_TICK_IN_CONV", "1") != "0":
             pl.launch(tick=(self.t_buf, self.ts_table))      # the clock rides in the first launch of the forward
             self.extra_launches = 1                           # (the update; bench.py reports launches per step)
         else:
             tick()
             pl.launch()
             self.extra_launches = 2
-        if self.side is None and os.environ.get("LFVDM_SAMPLER_NOISE", "kernel") != "torch":
+        if not self.inject_noise and os.environ.get("LFVDM_SAMPLER_NOISE", "kernel") != "torch":
             nat.p_sample_rng(pl.x_in, pl.out, self.noise, self.t_buf, tb["sqrt_recip_alphas_cumprod"],
                              tb["sqrt_recipm1_alphas_cumprod"], tb["posterior_mean_coef1"], tb["posterior_mean_coef2"],
                              tb["model_log_variance"], self.clip, pl.x_in, self.seed, self.pred, None)
             return
-        self.extra_launches = getattr(self, "extra_launches", 2) + 1
-        if self.side is None:
+        if not self.inject_noise:
+            self.extra_launches = getattr(self, "extra_launches", 2) + 1
             self.noise.normal_()
         nat.p_sample(pl.x_in, pl.out, self.noise, self.t_buf, tb["sqrt_recip_alphas_cumprod"],
                      tb["sqrt_recipm1_alphas_cumprod"], tb["posterior_mean_coef1"], tb["posterior_mean_coef2"],
@@ -530,7 +531,7 @@ class GraphSampler:
             if pl.time_steps:
                 e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
                 e0.record()
-                if pl.tables_sig != (pl.weight_signature(), self._ts_key):
+                if pl.tables_sig != (pl.time_signature(), self._ts_key):
                     pl.build_time_tables(self.ts_table)          # once per set of weights
                 pl.build_R_tables(model_kwargs["frame_indices"])  # once per chain: R depends on this window's frames
                 e1.record()

@@ -560,13 +560,14 @@ class TrainLoop:
         a.bias_corr2_sqrt = math.sqrt(1.0 - self.betas[1] ** self.opt_step)
         a.grad_scale = 1.0 / self.world
         a.grad_sqsum = self.grad_sqsum.data_ptr()
+        a.skip_flag = self.exchange.skip_flag_ptr()     # a timed-out bucket wait turns this launch into a no-op
         import ctypes
         nat.check(nat.lib().lfvdm_adamw_ema(ctypes.byref(a), nat.stream()), "lfvdm_adamw_ema")
         self._invalidate_engine()
+        self.exchange.poll_timeout()             # every step, no host stall (the word is read one step late)
         if self.step % self.log_interval == 0:   # the only host sync of the optimizer phase
             logger.logkv_mean("grad_norm", float(np.sqrt(self.grad_sqsum.item())))
-            if self.exchange.flags is not None and self.exchange.flags.timed_out():
-                raise RuntimeError("gradient exchange: a bucket's wait on the backward graph timed out (lfvdm_flag_wait)")
+            self.exchange.poll_timeout(sync=True)
 
     def _invalidate_engine(self):
         nat.param_epoch[0] += 1          # cached packed weights (sampler plans, training path) are stale now

@@ -187,14 +187,17 @@ def gen_ops():
         B, D, C, T = 2, 6, 64, 5
         xa = torch.from_numpy(recipe.gaussianish(f"ops/att_{kind}/x", B * D * C * T).reshape(B, D, C, T).astype(np.float32))
         mask = torch.tensor([[1., 1, 1, 0, 0], [1, 0, 1, 1, 0]]) if use_rpe else None
+        # the time embedding as the network produces it: one row per batch element, repeated over its T frames
+        # (unet.py:440 expands the timesteps over T) - `att_temb` holds these rows
+        temb_att = temb.view(B, T, -1)[:, 0].repeat_interleave(T, 0)
         with torch.no_grad():
-            ya, aa = att._forward(xa, temb, fi if use_rpe else None, mask)
-            yo, ao = uo.rpe_attention({"p." + k: v for k, v in asd.items()}, "p", xa, temb,
+            ya, aa = att._forward(xa, temb_att, fi if use_rpe else None, mask)
+            yo, ao = uo.rpe_attention({"p." + k: v for k, v in asd.items()}, "p", xa, temb_att,
                                       fi if use_rpe else None, mask, 4, use_rpe)
         assert maxdiff(ya, yo) < 1e-5 and maxdiff(aa, ao) < 1e-6
         out[f"att_{kind}_y"] = ya.numpy()
         out[f"att_{kind}_attn"] = aa.numpy()
-    out["att_temb"] = temb.numpy()
+    out["att_temb"] = temb_att.numpy()
     # Down / Up (unet.py:60-114)
     for kind, mod in (("down", runet.Downsample(32, True)), ("up", runet.Upsample(32, True))):
         shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
@@ -338,6 +341,100 @@ def gen_decode():
     print("[decode] ok", dec_pre.shape, enc.shape, calls_dec, calls_enc)
 
 
+def gen_forward_cfgE_T20():
+    """BASELINE.json configs[4] at FULL size (pixel space 128x128x3, 20 frames, batch 1, num_channels=128, the reference's
+    default num_res_blocks=2 / channel_mult (1,1,2,3,4) / attention at 16x16 and 8x8).  The output (3.9 MB) is stored as a
+    4x4-strided subsample plus per-(frame, channel) sums and L2 norms of the FULL output, so the fixture stays < 1 MB."""
+    kw = CONFIGS["cfgE_T2"][0]
+    cfg = uo.make_cfg(**kw)
+    model, sd = build_reference_model(cfg)
+    inp = recipe.make_inputs("cfgE_T20", 1, 20, cfg["in_channels"], 128, 128, n_pad=3)
+    ti = tt(inp)
+    ts = ti["t"].float()
+    with torch.no_grad():
+        ref, _ = model(ti["x"], x0=ti["x0"], timesteps=ts, frame_indices=ti["frame_indices"], obs_mask=ti["obs_mask"],
+                       latent_mask=ti["latent_mask"])
+        mine, _ = uo.unet_forward(sd, cfg, ti["x"], ti["x0"], ts, ti["frame_indices"], ti["obs_mask"], ti["latent_mask"])
+    d = maxdiff(ref, mine)
+    print(f"[forward cfgE_T20] out rms {float(ref.pow(2).mean().sqrt()):.4f}  oracle-vs-ref max|d| {d:.3e}")
+    assert d < 2e-4
+    r64 = ref.double()
+    np.savez_compressed(os.path.join(OUT, "forward_cfgE_T20.npz"), sub=ref[..., ::4, ::4].numpy(),
+                        frame_sum=r64.sum(dim=(-1, -2)).numpy(), frame_norm=r64.pow(2).sum(dim=(-1, -2)).sqrt().numpy(),
+                        absmax=np.float64(ref.abs().max()), frame_indices=inp["frame_indices"],
+                        n_params=np.int64(sum(v.numel() for v in sd.values())))
+
+
+def gen_sampler_cfgB():
+    """Three ancestral steps of the reference's p_sample from the top of the 1000-step chain at BASELINE.json configs[1]
+    (ch64, batch 2, 20 frames, 4x16x16), with the recorded recipe noise: what the replayed cfg-B sampler plan - tune
+    cache, timestep tables, GroupNorm epilogues - is compared with."""
+    kw, B, T, H, n_pad = CONFIGS["cfgB"]
+    cfg = uo.make_cfg(**kw)
+    model, sd = build_reference_model(cfg)
+    inp = tt(recipe.make_inputs("cfgB", B, T, cfg["in_channels"], H, H, n_pad=n_pad))
+    shape = inp["x"].shape
+    pixel = {"diffusion_space": "pixel", "pre_encoded": False, "pre_encoded_stats_dict": None}
+    diff = rsu.create_gaussian_diffusion(steps=1000, timestep_respacing="", rescale_timesteps=True, rescale_learned_sigmas=True,
+                                         diffusion_space_kwargs=dict(pixel))
+    mk = dict(frame_indices=inp["frame_indices"], obs_mask=inp["obs_mask"], latent_mask=inp["latent_mask"], x0=inp["x0"])
+    noise = [torch.from_numpy(recipe.gaussianish(f"samplerB/noise{i}", inp["x"].numel()).reshape(shape).astype(np.float32))
+             for i in range(3)]
+    real_randn_like = torch.randn_like
+    x, traj = inp["x"].clone(), []
+    for j, i in enumerate(range(999, 996, -1)):
+        torch.randn_like = lambda x_, _n=noise[j]: _n
+        try:
+            with torch.no_grad():
+                x = diff.p_sample(model, x, torch.tensor([i] * B), clip_denoised=True, model_kwargs=mk)["sample"]
+        finally:
+            torch.randn_like = real_randn_like
+        traj.append(x.numpy())
+    np.savez_compressed(os.path.join(OUT, "sampler_cfgB.npz"), traj=np.stack(traj))
+    print("[sampler cfgB] ok", np.stack(traj).shape)
+
+
+def gen_train_step_cfgC():
+    """One optimizer step of the reference's TrainLoop arithmetic at BASELINE.json configs[2] (ch128, batch 2, 20 frames):
+    training_losses (MSE branch, gaussian_diffusion.py:722-796) -> (losses["loss"] * weights).mean().backward()
+    (train_util.py:320-328) -> AdamW(lr 1e-4, weight_decay 0) (train_util.py:103,346-351) -> update_ema at 0.9999
+    (nn.py:55-65).  train_util.py itself cannot be imported here (mpi4py / blobfile are absent), so its three lines of
+    arithmetic are driven directly with the reference's own model, diffusion, optimizer class and update_ema.
+    30.5 M parameters: per-tensor summaries are stored (update norm, leading elements of gradient / new value / EMA)."""
+    kw, B, T, H, n_pad = CONFIGS["cfgC"]
+    cfg = uo.make_cfg(**kw)
+    model, sd = build_reference_model(cfg)
+    model.train()
+    inp = tt(recipe.make_inputs("cfgC", B, T, cfg["in_channels"], H, H, n_pad=n_pad))
+    pixel = {"diffusion_space": "pixel", "pre_encoded": False, "pre_encoded_stats_dict": None}
+    diff = rsu.create_gaussian_diffusion(steps=1000, timestep_respacing="", rescale_timesteps=True, rescale_learned_sigmas=True,
+                                         diffusion_space_kwargs=dict(pixel))
+    t = torch.tensor([700, 123])
+    noise = torch.from_numpy(recipe.gaussianish("trainC/noise", inp["x0"].numel()).reshape(inp["x0"].shape).astype(np.float32))
+    mk = dict(frame_indices=inp["frame_indices"], obs_mask=inp["obs_mask"], latent_mask=inp["latent_mask"], x0=inp["x0"])
+    opt = torch.optim.AdamW(list(model.parameters()), lr=1e-4, weight_decay=0.0)
+    ema = [p.detach().clone() for p in model.parameters()]
+    old = [p.detach().clone() for p in model.parameters()]
+    losses = diff.training_losses(model, inp["x0"], t, model_kwargs=mk, noise=noise, latent_mask=1 - inp["obs_mask"],
+                                  eval_mask=inp["latent_mask"])
+    weights = torch.ones(B)
+    (losses["loss"] * weights).mean().backward()
+    grads = [p.grad.detach().clone() for p in model.parameters()]
+    opt.step()
+    rnn.update_ema(ema, list(model.parameters()), rate=0.9999)
+    keys = [n for n, _ in model.named_parameters()]
+    new = [p.detach() for p in model.parameters()]
+    head = lambda ts_: np.stack([np.resize(x.flatten()[:16].numpy(), 16) for x in ts_])
+    np.savez_compressed(
+        os.path.join(OUT, "train_step_cfgC.npz"), keys=np.array(keys), t=t.numpy(),
+        loss=losses["loss"].detach().numpy(), mse=losses["mse"].detach().numpy(),
+        grad_norm=np.array([float(g.double().norm()) for g in grads]), grad_head=head(grads),
+        delta_norm=np.array([float((a - b).double().norm()) for a, b in zip(new, old)]),
+        new_head=head(new), ema_head=head(ema), grad_absmax=np.array([float(g.abs().max()) for g in grads]))
+    print("[train step cfgC] loss", losses["loss"].detach().numpy(), "total grad norm",
+          float(np.sqrt(sum(float(g.double().pow(2).sum()) for g in grads))))
+
+
 SCHEME_CASES = [
     # (scheme, video_length, n_obs, max_frames, step_size)
     ("autoreg", 1000, 36, 20, 10), ("autoreg", 1000, 0, 20, 10), ("autoreg", 47, 3, 8, 3),
@@ -381,10 +478,21 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "decode":
         gen_decode()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ops":
+        gen_ops()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round3":       # the fixtures added in round 3 only
+        gen_sampler_cfgB()
+        gen_train_step_cfgC()
+        gen_forward_cfgE_T20()
+        sys.exit(0)
     gen_ops()
     gen_forward()
     gen_backward()
     gen_diffusion()
     gen_decode()
     gen_schemes()
+    gen_sampler_cfgB()
+    gen_train_step_cfgC()
+    gen_forward_cfgE_T20()
     print("golden vectors written to", OUT)

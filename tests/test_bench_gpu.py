@@ -1,0 +1,56 @@
+"""bench.py as the driver runs it at N > 1: ``python bench.py --gpus 2`` starts two ranks (torch.distributed.run child) which,
+on this one-GPU box, share the card over gloo - the labelled REHEARSAL of the 8-GPU plumbing.  The JSON line must carry the
+driver contract plus the self-checking multi-GPU keys, in the same schema the N = 1 line uses.  GPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config")
+MULTI = ("collective_world_size", "collective_backend", "self_check", "train_videos_per_s", "train_optimizer_steps_per_s",
+         "allreduce_bytes_per_step", "exposed_allreduce_ms_per_step", "exchange")
+
+
+def _run(argv, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_rehearsal_line_is_self_checking():
+    d = _run(["--gpus", "2", "--steps", "20", "--train-steps", "4", "--no-cpu", "--pixel-steps", "0", "--long-video-windows", "0"])
+    for k in CONTRACT + MULTI:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["collective_world_size"] == 2 and d["scaling"] == "weak" and d["steps"] == 20
+    assert all(d["self_check"].values()), d["self_check"]
+    assert "REHEARSAL" in d["collective_backend"] or d["collective_backend"].startswith("rccl")
+    assert d["value"] > 0 and d["config"]["finite"] and d["dtype"] == "f32"
+    tr = d["train"]
+    assert tr["global_batch"] == 4 and tr["allreduce_bytes_per_step"] == 4 * tr["params"] == d["allreduce_bytes_per_step"]
+    ex = tr["exchange"]
+    assert ex["world_size"] == 2 and sum(ex["bucket_bytes"]) == tr["allreduce_bytes_per_step"] and len(ex["bucket_bytes"]) >= 2
+    assert ex["buckets_started_inside_the_backward"] + ex["buckets_started_after_the_backward"] == len(ex["bucket_bytes"]) * (4 + 4)
+    assert d["exchange"]["bucket_bytes"] == ex["bucket_bytes"]
+    assert tr["roofline"]["flops_per_step"] > 2.5e11 and 0 < tr["roofline"]["frac"] < 1
+    assert tr["last_loss"] == tr["last_loss"]          # not NaN
+
+
+def test_one_rank_line_has_the_same_schema():
+    d = _run(["--steps", "50", "--train-steps", "4", "--no-cpu", "--pixel-steps", "0", "--long-video-windows", "0", "--no-breakdown"])
+    for k in CONTRACT + MULTI:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["collective_world_size"] == 1 and d["allreduce_bytes_per_step"] == 0
+    assert d["exposed_allreduce_ms_per_step"] == 0.0 and all(d["self_check"].values())
+    assert d["per_chain_setup"]["fallback"] is None and d["per_chain_setup"]["timestep_table_bytes"] > 0

@@ -197,3 +197,75 @@ def test_exchange_mechanics_on_rccl():
     print(res)
     assert res[0] == "ok", res
     assert p.exitcode == 0
+
+
+def _timeout_worker(port, q):
+    """One rank on RCCL with the exchange forced on; after the micro-step has become a replayed graph, one bucket's wait is
+    made to expect a signal that never comes.  The step must leave parameters, moments and EMA untouched (the optimizer
+    launch reads the timed-out word) and the failure must surface as a RuntimeError no later than the next step."""
+    try:
+        for p in (PKG, ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0", LFVDM_FORCE_EXCHANGE="1", LFVDM_FLAG_TIMEOUT_S="0.3")
+        os.environ.pop("LFVDM_DIST_BACKEND", None)
+        import torch.distributed as dist
+        from improved_diffusion import dist_util, script_util as su
+        from improved_diffusion.train_util import TrainLoop
+        from test_oracle_golden import load_case
+        from test_forward_gpu import build_native
+        dist_util.setup_dist()
+        cfg, sd, _ = load_case("micro")
+        model = build_native(cfg, sd).train()
+        diffusion = su.create_gaussian_diffusion(steps=1000, rescale_timesteps=True, rescale_learned_sigmas=True)
+        loop = TrainLoop(model=model, diffusion=diffusion, data=_data(2, 12, 4, 16, 7), batch_size=2, microbatch=-1,
+                         lr=1e-3, ema_rate="0.9", log_interval=1000, save_interval=10 ** 9, resume_checkpoint="", use_fp16=False,
+                         diffusion_space_kwargs={}, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.01,
+                         lr_anneal_steps=0, sample_interval=None, pad_with_random_frames=True, max_frames=4,
+                         enc_dec_chunk_size=20, args=argparse.Namespace(resume_id=""))
+        ex = loop.exchange
+        assert ex.overlap and ex.overlap_probe["ok"], ex.overlap_probe
+        torch.manual_seed(3); np.random.seed(3)
+        for _ in range(4):
+            loop.run_step()
+            loop.step += 1
+        torch.cuda.synchronize()
+        assert loop._graph_state.get("graph") is not None and not ex.flags.timed_out()
+        before = [loop.arena.p.clone(), loop.exp_avg.clone(), loop.exp_avg_sq.clone(), loop.ema_flat[0].clone()]
+        ex.micro_steps += 1                 # the waits of the next exchange expect one signal more than the graph will send
+        raised_now = False
+        try:
+            loop.run_step()                 # early buckets give up after 0.3 s each; the optimizer launch must skip
+            loop.step += 1
+        except RuntimeError:
+            raised_now = True
+        torch.cuda.synchronize()
+        after = [loop.arena.p, loop.exp_avg, loop.exp_avg_sq, loop.ema_flat[0]]
+        unchanged = all(torch.equal(a, b) for a, b in zip(before, after))
+        raised_next = False
+        if not raised_now:
+            try:
+                loop.run_step()
+            except RuntimeError as e:
+                raised_next = "timed out" in str(e)
+        torch.cuda.synchronize()
+        still = all(torch.equal(a, b) for a, b in zip(before, [loop.arena.p, loop.exp_avg, loop.exp_avg_sq, loop.ema_flat[0]]))
+        q.put(("ok" if (unchanged and still and (raised_now or raised_next) and ex.flags.timed_out() and not ex.overlap) else "bad",
+               dict(unchanged=unchanged, still=still, raised_now=raised_now, raised_next=raised_next, probe=ex.overlap_probe)))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(("fail", traceback.format_exc()))
+        raise
+
+
+def test_timed_out_bucket_wait_skips_the_optimizer_and_raises():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_timeout_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=420)
+    p.join(60)
+    print(res)
+    assert res[0] == "ok", res

@@ -77,3 +77,32 @@ def test_cpu_input_is_rejected():
     with pytest.raises(RuntimeError):
         model(inp["x"], x0=inp["x0"], timesteps=inp["t"].float(), frame_indices=inp["frame_indices"],
               obs_mask=inp["obs_mask"], latent_mask=inp["latent_mask"])
+
+
+def test_full_size_pixel_space_forward_vs_reference():
+    """BASELINE.json configs[4] at FULL size: pixel space 128x128x3, 20 frames (3 of them padding), batch 1,
+    num_channels=128, num_res_blocks=2, channel_mult (1,1,2,3,4), attention at 16x16 and 8x8 (reference
+    scripts/video_train.py:148, unet.py:428-464).  The fixture holds a 4x4-strided subsample of the reference's output
+    plus per-(frame, channel) sums and norms of the whole output (oracle/make_golden.py::gen_forward_cfgE_T20)."""
+    g = np.load(os.path.join(GOLDEN, "forward_cfgE_T20.npz"))
+    kw = CONFIGS["cfgE_T2"][0]
+    cfg = uo.make_cfg(**kw)
+    sd = {k: torch.from_numpy(v) for k, v in recipe.fill_state_dict(uo.param_shapes(cfg)).items()}
+    assert int(g["n_params"]) == sum(v.numel() for v in sd.values())
+    inp = {k: torch.from_numpy(v) for k, v in recipe.make_inputs("cfgE_T20", 1, 20, cfg["in_channels"], 128, 128, n_pad=3).items()}
+    assert np.array_equal(inp["frame_indices"].numpy(), g["frame_indices"])
+    model = build_native(cfg, sd)
+    d = {k: v.cuda() for k, v in inp.items()}
+    with torch.no_grad():
+        out, _ = model(d["x"], x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"],
+                       obs_mask=d["obs_mask"], latent_mask=d["latent_mask"])
+    out = out.cpu()
+    assert out.shape == (1, 20, 3, 128, 128)
+    ref = torch.from_numpy(g["sub"])
+    err = float((out[..., ::4, ::4] - ref).abs().max())
+    print(f"[cfgE T=20] max|hip - reference| on the subsample = {err:.3e} (max|ref| {float(g['absmax']):.3f})")
+    assert torch.allclose(out[..., ::4, ::4], ref, atol=2e-4, rtol=1e-3), err
+    # whole-output checks: per-(frame, channel) L2 norms and sums over the 128x128 map
+    o64 = out.double()
+    np.testing.assert_allclose(o64.pow(2).sum(dim=(-1, -2)).sqrt().numpy(), g["frame_norm"], rtol=2e-5)
+    np.testing.assert_allclose(o64.sum(dim=(-1, -2)).numpy(), g["frame_sum"], atol=2e-4 * 128 * 128 ** 0.5 + 1e-3 * np.abs(g["frame_sum"]).max())

@@ -299,7 +299,10 @@ def test_vae_boundary_matches_reference_golden():
     assert diff.vae is None and diff.pre_encoded_stats_dict["std"].shape == (1, 1, 4, 1, 1)
     # no autoencoder attached: pre-encoded latents come back de-normalised (what the decoder would be fed)
     want = z * st["std"].view(1, 1, 4, 1, 1) + st["mean"].view(1, 1, 4, 1, 1)
-    assert torch.equal(diff.decode(z), want) and torch.equal(diff.denormalize_latents(z), want)
+    with pytest.raises(NotImplementedError):         # the reference always returns pixels: no silent latents
+        diff.decode(z)
+    assert not diff.can_decode()
+    assert torch.equal(diff.decode(z, allow_latents=True), want) and torch.equal(diff.denormalize_latents(z), want)
     assert diff.encode(px) is px
     # with the stand-in attached: the reference's outputs, chunk for chunk
     vae = fake_vae.FakeVAE()
@@ -310,6 +313,8 @@ def test_vae_boundary_matches_reference_golden():
         "diffusion_space": "latent", "pre_encoded": False, "pre_encoded_stats_dict": None})
     with pytest.raises(NotImplementedError):
         raw.decode(z)
+    with pytest.raises(NotImplementedError):
+        raw.decode(z, allow_latents=True)            # not pre-encoded: there is nothing meaningful to hand back
     with pytest.raises(NotImplementedError):
         raw.encode(px)
     vae2 = fake_vae.FakeVAE()

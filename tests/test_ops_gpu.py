@@ -950,3 +950,99 @@ def test_conv_fused_output_groupnorm_every_tune_code(nat, N, Cin, Cout, H, film,
     with pytest.raises(RuntimeError):
         nat.conv_igemm(src0=cl(x2), C0=Cin, N=2, Hs=16, Ws=16, Ho=16, Wo=16, W=keep["W"], bias=keep["bias"], Cout=Cout, out=o2,
                        ldo=Cout, ksize=k, gn_out=torch.empty_like(o2), gn_gamma=keep["gn_gamma"], gn_beta=keep["gn_beta"])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Op-level fixtures generated by the REFERENCE's own modules (tests/golden/ops.npz, oracle/make_golden.py::gen_ops):
+# the attention and resampling ops are pinned to the reference directly, not only through whole-network goldens.
+def _ops_golden():
+    import os
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "ops.npz"))
+
+
+def test_temporal_attention_ops_match_the_reference_fixture(nat):
+    """gn_temporal + qkv GEMM + RPE nets + temporal core + proj GEMM == reference RPEAttention._forward (rpe.py:133-174,
+    temporal instance with rpe_q/k/v, two-clique mask, sparse frame indices): output AND attention probabilities."""
+    g = _ops_golden()
+    B, P, Cc, T, heads, ted = 2, 6, 64, 5, 4, 128
+    shapes = {"qkv.weight": (3 * Cc, Cc), "qkv.bias": (3 * Cc,), "proj_out.weight": (Cc, Cc), "proj_out.bias": (Cc,),
+              "norm.weight": (Cc,), "norm.bias": (Cc,)}
+    for r in ("rpe_q", "rpe_k", "rpe_v"):
+        shapes.update({f"{r}.rpe_net.embed_distances.weight": (Cc, 3), f"{r}.rpe_net.embed_distances.bias": (Cc,),
+                       f"{r}.rpe_net.embed_diffusion_time.weight": (Cc, ted), f"{r}.rpe_net.embed_diffusion_time.bias": (Cc,),
+                       f"{r}.rpe_net.out.weight": (Cc, Cc), f"{r}.rpe_net.out.bias": (Cc,)})
+    sd = {"p." + k: torch.from_numpy(recipe.fill_param("ops/att_temporal." + k, s)) for k, s in shapes.items()}
+    x = rnd("ops/att_temporal/x", B, P, Cc, T)                       # reference layout (B, D = pixels, C, T)
+    temb_b = torch.from_numpy(g["att_temb"]).view(B, T, ted)[:, 0].contiguous()
+    fi = torch.from_numpy(g["rpe_fi"])
+    mask = torch.tensor([[1., 1, 1, 0, 0], [1, 0, 1, 1, 0]])
+    d = {k: v.cuda() for k, v in sd.items()}
+    xc = x.permute(0, 3, 1, 2).reshape(B * T, P, Cc).contiguous().cuda()
+    xn = torch.empty_like(xc)
+    nat.gn_temporal(xc, d["p.norm.weight"], d["p.norm.bias"], 1e-5, xn, B, T, P, Cc)
+    M = B * T * P
+    qkv = torch.empty(M, 3 * Cc, device="cuda")
+    nat.conv_igemm(src0=xn, C0=Cc, N=B * T, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.qkv.weight"], bias=d["p.qkv.bias"],
+                   Cout=3 * Cc, out=qkv, ldo=3 * Cc)
+    jobs, Rs, keep, tile0 = [], {}, [], 0
+    for r in ("rpe_q", "rpe_k", "rpe_v"):
+        pre = f"p.{r}.rpe_net."
+        tproj = F.linear(temb_b, sd[pre + "embed_diffusion_time.weight"], sd[pre + "embed_diffusion_time.bias"]).cuda().contiguous()
+        Rs[r] = torch.empty(B, T, T, Cc, device="cuda")
+        keep.append(tproj)
+        jobs.append(nat.RpeJob(tproj.data_ptr(), d[pre + "embed_distances.weight"].data_ptr(), d[pre + "embed_distances.bias"].data_ptr(),
+                               d[pre + "out.weight"].data_ptr(), d[pre + "out.bias"].data_ptr(), Rs[r].data_ptr(), Cc, tile0, Cc, 0, None))
+        tile0 += (B * T * T + 31) // 32
+    nat.rpe_nets(nat.jobs_to_device(jobs, "cuda"), 3, tile0, fi.cuda(), B, T)
+    o = torch.empty(M, Cc, device="cuda")
+    attn = torch.empty(B * P, heads, T, T, device="cuda")
+    nat.attn_temporal(qkv, Rs["rpe_q"], Rs["rpe_k"], Rs["rpe_v"], mask.cuda(), o, attn, B, T, P, Cc, heads)
+    y = torch.empty(M, Cc, device="cuda")
+    nat.conv_igemm(src0=o, C0=Cc, N=B * T, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.proj_out.weight"], bias=d["p.proj_out.bias"],
+                   Cout=Cc, res=xn.view(M, Cc), ldr=Cc, out=y, ldo=Cc)
+    close(y.view(B, T, P, Cc).permute(0, 2, 3, 1), torch.from_numpy(g["att_temporal_y"]), 1e-4)
+    close(attn.view(B, P, heads, T, T), torch.from_numpy(g["att_temporal_attn"]).view(B, P, heads, T, T), 2e-5)
+
+
+def test_spatial_attention_ops_match_the_reference_fixture(nat):
+    """GroupNorm + qkv GEMM + spatial core + proj GEMM == reference RPEAttention._forward (spatial instance: no RPE, no
+    mask; rpe.py:133-174): output AND attention probabilities."""
+    g = _ops_golden()
+    B, D, Cc, P, heads = 2, 6, 64, 5, 4                    # reference x: (B, D = frames, C, T = tokens)
+    shapes = {"qkv.weight": (3 * Cc, Cc), "qkv.bias": (3 * Cc,), "proj_out.weight": (Cc, Cc), "proj_out.bias": (Cc,),
+              "norm.weight": (Cc,), "norm.bias": (Cc,)}
+    sd = {"p." + k: torch.from_numpy(recipe.fill_param("ops/att_spatial." + k, s)) for k, s in shapes.items()}
+    x = rnd("ops/att_spatial/x", B, D, Cc, P)
+    d = {k: v.cuda() for k, v in sd.items()}
+    N, M = B * D, B * D * P
+    xc = x.reshape(N, Cc, P).permute(0, 2, 1).contiguous().cuda()          # [N][P][C]
+    xn = torch.empty(M, Cc, device="cuda")
+    nat.check(nat.lib().lfvdm_gn_apply(nat.ptr(xc), None, Cc, 0, N, P, nat.ptr(d["p.norm.weight"]), nat.ptr(d["p.norm.bias"]),
+                                       None, 1, 0, 1e-5, nat.ACT_NONE, nat.ptr(xn), None, None, None, nat.stream()), "lfvdm_gn_apply")
+    qkv = torch.empty(M, 3 * Cc, device="cuda")
+    nat.conv_igemm(src0=xn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.qkv.weight"], bias=d["p.qkv.bias"],
+                   Cout=3 * Cc, out=qkv, ldo=3 * Cc)
+    o = torch.empty(M, Cc, device="cuda")
+    attn = torch.empty(N, heads, P, P, device="cuda")
+    nat.attn_spatial(qkv, o, attn, N, P, Cc, heads)
+    y = torch.empty(M, Cc, device="cuda")
+    nat.conv_igemm(src0=o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.proj_out.weight"], bias=d["p.proj_out.bias"],
+                   Cout=Cc, res=xn, ldr=Cc, out=y, ldo=Cc)
+    close(y.view(B, D, P, Cc).permute(0, 1, 3, 2), torch.from_numpy(g["att_spatial_y"]), 1e-4)
+    close(attn.view(B, D, heads, P, P), torch.from_numpy(g["att_spatial_attn"]).view(B, D, heads, P, P), 2e-5)
+
+
+def test_resampling_convs_match_the_reference_fixture(nat):
+    """Downsample (3x3 stride 2) and Upsample (nearest x2 + 3x3) == the reference modules (unet.py:60-114)."""
+    g = _ops_golden()
+    N, Cc, H = 2, 32, 8
+    for kind, key in (("down", "op"), ("up", "conv")):
+        w = torch.from_numpy(recipe.fill_param(f"ops/{kind}.{key}.weight", (Cc, Cc, 3, 3)))
+        b = torch.from_numpy(recipe.fill_param(f"ops/{kind}.{key}.bias", (Cc,)))
+        x = rnd(f"ops/{kind}/x", N, Cc, H, H)
+        Ho = H // 2 if kind == "down" else 2 * H
+        out = torch.empty(N * Ho * Ho, Cc, device="cuda")
+        nat.conv_igemm(src0=cl(x), C0=Cc, N=N, Hs=H, Ws=H, up=0 if kind == "down" else 1, stride=2 if kind == "down" else 1,
+                       Ho=Ho, Wo=Ho, W=packed(nat, w), bias=b.cuda(), Cout=Cc, out=out, ldo=Cc)
+        close(from_cl(out, N, Ho, Ho, Cc), torch.from_numpy(g[f"{kind}_y"]), 2e-5)

@@ -54,7 +54,7 @@ def main():
     th.cuda.synchronize()
     seen = set()
     buf = (C.c_ulonglong * (NS * NW))()
-    print("inst    M Cin Cout k s2 gn kz wgs |  skew   pro  loop   red  slab   rel  tick   acq   sum   epi    gn | span event")
+    print("inst    M Cin Cout k s2 gn kz wgs |  skew   pro  loop   red  slab   rel  tick   acq   sum   epi    gn  1stc gn:wr gn:st gn:ba gn:ap | span event")
     for i, (fn, args) in enumerate(pl.steps):
         if fn is not L.lfvdm_conv_igemm:
             continue
@@ -104,6 +104,9 @@ def main():
                      med(lambda r: r[7] - r[6], last), med(lambda r: r[8] - r[7], last)]
         else:
             cols += [0, 0, 0, 0, 0, med(lambda r: r[7] - r[3]), med(lambda r: r[8] - r[7])]
+        # finer split: first chunk landed (cold filters), GroupNorm: tile rewrite / statistics / last barrier / apply
+        cols += [med(lambda r: r[15] - r[1]), med(lambda r: r[12] - r[7], last), med(lambda r: r[13] - r[12], last),
+                 med(lambda r: r[14] - r[13], last), med(lambda r: r[8] - r[14], last)]
         M = a.N * a.Ho * a.Wo
         print(f"{inst} {M:5d} {a.C0 + a.C1:3d} {a.Cout:4d} {a.ksize} {a.s2C0 + a.s2C1:3d} {int(bool(a.gn_out)):2d} {kz:2d} {len(rows):4d} | "
               + " ".join(f"{c:5.2f}" for c in cols) + f" | {span:5.2f} {ev_us:5.2f}")
