@@ -213,3 +213,43 @@ def test_video_datasets_surface(tmp_path, monkeypatch):
     assert s[3][0].shape == (40, 4, 16, 16) and torch.equal(s[3][0], s[3][0])
     with pytest.raises(Exception):
         vd.get_test_dataset("mazes")
+
+
+def test_reference_schedules_chain_their_windows():
+    """Window-level batching needs windows that neither read nor write each other's frames.  The reference's schedules
+    do not offer that: in every non-adaptive scheme each window conditions on frames the PREVIOUS window generated
+    (autoreg / long-range by construction; hierarchy-N infills left to right, each window observing the last frames of
+    its left neighbour - sampling_schemes.py:69-230).  Checked on the reference's own window lists (schemes.json): with
+    greedy grouping of consecutive same-length windows that touch none of the group's generated frames, cfg D
+    (hierarchy-2, T=1000) is 97 groups of ONE window - a batched chain could not reproduce the sequential video.
+    (hierarchy-5 is the only case with a few independent neighbours.)"""
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "schemes.json")) as f:
+        cases = json.load(f)
+
+    def groups(windows):
+        out, cur = [], []
+        for j, (o, l) in enumerate(windows):
+            ok = bool(cur) and len(o) + len(l) == len(windows[cur[0]][0]) + len(windows[cur[0]][1])
+            for i in cur:
+                ok = ok and not (set(o) & set(windows[i][1]) or set(l) & set(windows[i][1]) or set(l) & set(windows[i][0]))
+            if ok:
+                cur.append(j)
+            else:
+                if cur:
+                    out.append(cur)
+                cur = [j]
+        return out + [cur]
+
+    for c in cases:
+        g = groups(c["windows"])
+        if c["scheme"] in ("autoreg", "long-range", "hierarchy-2", "hierarchy-3", "hierarchy-4"):
+            assert len(g) == len(c["windows"]), (c["scheme"], c["video_length"])
+        # and directly: every window after the first observes at least one frame generated by an earlier window
+        made = set()
+        for j, (o, l) in enumerate(c["windows"]):
+            if j > 0 and c["scheme"] in ("autoreg", "long-range", "hierarchy-2"):
+                assert set(o) & made, (c["scheme"], j)
+            made |= set(l)

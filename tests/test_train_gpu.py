@@ -240,7 +240,7 @@ def test_cfgC_training_step_matches_the_reference_arithmetic():
 
     Bar: losses rtol 1e-4; per-tensor gradient norms and UPDATE norms rtol 2e-3; leading elements of every new parameter
     and EMA tensor |d| <= 1e-4*|ref| + 2e-6, where elements whose reference gradient is below 1e-3 of the tensor's largest
-    are compared at 2.2e-4 absolute instead (Adam's first step is lr * g / (|g| + eps): it moves a parameter by +-lr
+    (or 1e-6 of the model's largest: analytically-zero gradients) are compared at 2.2e-4 absolute instead (Adam's first step is lr * g / (|g| + eps): it moves a parameter by +-lr
     whatever |g| is, so the sign of a rounding-noise gradient decides 2 * lr)."""
     g = np.load(os.path.join(GOLDEN, "train_step_cfgC.npz"))
     cfg, sd, inp = load_case("cfgC")
@@ -276,7 +276,8 @@ def test_cfgC_training_step_matches_the_reference_arithmetic():
         n = min(16, p.numel())
         new_h, ema_h = p.detach().flatten()[:n].cpu().numpy(), e.detach().flatten()[:n].cpu().numpy()
         ref_new, ref_ema, ref_g = g["new_head"][i][:n], g["ema_head"][i][:n], g["grad_head"][i][:n]
-        noisy = np.abs(ref_g) < 1e-3 * float(g["grad_absmax"][i])
+        # (rpe_k's output bias shifts all logits of a query alike: its whole gradient is analytically zero)
+        noisy = np.abs(ref_g) < max(1e-3 * float(g["grad_absmax"][i]), 1e-6 * gmax)
         bound = np.where(noisy, 2.2e-4, 1e-4 * np.abs(ref_new) + 2e-6)
         assert np.all(np.abs(new_h - ref_new) <= bound), (k, np.abs(new_h - ref_new).max())
         assert np.all(np.abs(ema_h - ref_ema) <= np.where(noisy, 2.2e-8, 1e-4 * np.abs(ref_ema) + 2e-6)), k
