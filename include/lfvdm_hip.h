@@ -381,6 +381,16 @@ int lfvdm_rpe_front_bwd(const float* tproj, int tproj_ld, const float* feats, co
 int lfvdm_attn_spatial(const float* qkv, float* o, float* attn_out, float* lse_out, int N, int P, int C, int heads,
                        void* stream);
 
+/* Spatial attention WITH its qkv projection (rpe.py:139 + :143-169, spatial instance): xn = the normalised tokens
+ * [N*P][C] (what qkv's nn.Linear reads), Wqkv [3C][C] / bqkv [3C] = qkv.weight / qkv.bias, o [N*P][C].  One workgroup
+ * per (frame, head) stages the frame and the head's filter rows in LDS, projects on MFMA and runs the flash loop over
+ * resident keys: replaces lfvdm_conv_igemm (qkv) + lfvdm_attn_spatial in the sampler plan.
+ * lfvdm_attn_spatial_fused_ok: LFVDM_OK if the shape is covered (head dim 16 / 32 / 64, C a multiple of 64, frame +
+ * filters + q/k/v tiles within 160 KB of LDS), else LFVDM_E_UNSUPPORTED (use the two-launch form). */
+int lfvdm_attn_spatial_fused_ok(int N, int P, int C, int heads);
+int lfvdm_attn_spatial_fused(const float* xn, const float* Wqkv, const float* bqkv, float* o, int N, int P, int C, int heads,
+                             void* stream);
+
 /* Backward of the spatial core (autograd of rpe.py:143-169 with attn_mask = None, no RPE): from qkv, the
  * forward output o, its gradient d_o and the saved lse, writes dqkv [M][3C] (same layout as qkv).
  * delta_ws: workspace of N*heads*P floats (rowdot(o, d_o)).  S and P are recomputed tile by tile. */

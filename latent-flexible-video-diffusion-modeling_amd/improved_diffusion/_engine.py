@@ -32,6 +32,8 @@ def _p(t):
 
 # LFVDM_FUSED_GN=1 restores the older plan that folds GroupNorm/FiLM/SiLU into the operand load of the consuming GEMM
 FUSED_GN = os.environ.get("LFVDM_FUSED_GN", "0") == "1"
+# LFVDM_SPATIAL_FUSED=0: keep the qkv projection of the spatial attention as its own GEMM launch (A/B aid)
+SPATIAL_FUSED = os.environ.get("LFVDM_SPATIAL_FUSED", "1") != "0"
 # LFVDM_GN_EPILOGUE=0: never evaluate a GroupNorm in the epilogue of the GEMM that produces its input (A/B aid)
 GN_EPILOGUE = os.environ.get("LFVDM_GN_EPILOGUE", "1") != "0"
 # LFVDM_NEXT_GN_EPILOGUE=0: never evaluate the NEXT ResBlock's first GroupNorm in a producer's epilogue (A/B aid)
@@ -501,13 +503,19 @@ class Plan:
         else:
             if ysn is None:
                 ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
-            self.add_conv(src0=ysn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.qkv.weight, bias=sa.qkv.bias,
-                          Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
+            # qkv projection inside the attention launch where a frame, the head's filters and its q / k / v fit the LDS
+            fused_sa = (SPATIAL_FUSED and not self.want_attn and L.lfvdm_attn_spatial_fused_ok(N, P, Cc, heads) == 0)
+            if fused_sa:
+                self.add(L.lfvdm_attn_spatial_fused, _p(ysn), _p(sa.qkv.weight), _p(sa.qkv.bias), _p(self.s_o), N, P, Cc, heads)
+            else:
+                self.add_conv(src0=ysn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.qkv.weight, bias=sa.qkv.bias,
+                              Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
         asp = None
         if self.want_attn:
             asp = self.buf(N, heads, P, P)
             self.attn_s.append(asp)
-        self.add(L.lfvdm_attn_spatial, _p(self.s_qkv), _p(self.s_o), _p(asp) if asp is not None else None, None, N, P, Cc, heads)
+        if FUSED_GN or not fused_sa:
+            self.add(L.lfvdm_attn_spatial, _p(self.s_qkv), _p(self.s_o), _p(asp) if asp is not None else None, None, N, P, Cc, heads)
         ys = self.buf(M, Cc)
         if FUSED_GN:
             self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,

@@ -127,6 +127,8 @@ _SIGS = {
     "lfvdm_rpe_nets_bwd": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_conv_wgrad_grouped": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_attn_spatial": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_attn_spatial_fused_ok": ([c_i, c_i, c_i, c_i], c_i),
+    "lfvdm_attn_spatial_fused": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_front": ([c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_front_bwd": ([c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_sampler_tick": ([c_fp, c_fp, c_fp, c_i, c_fp], c_i),

@@ -39,8 +39,12 @@ def test_forward_vs_reference_golden(name):
                           obs_mask=d["obs_mask"], latent_mask=d["latent_mask"], return_attn_weights=True)
         out2, none = model(d["x"], x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"],
                            obs_mask=d["obs_mask"], latent_mask=d["latent_mask"])
+        out3, _ = model(d["x"], x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"],
+                        obs_mask=d["obs_mask"], latent_mask=d["latent_mask"])
     assert none is None
-    assert torch.equal(out, out2), "forward must be deterministic run to run"
+    assert torch.equal(out2, out3), "forward must be deterministic run to run"
+    # (the plan that also returns attention maps keeps the two-launch spatial attention: same math, other summation order)
+    assert torch.allclose(out, out2, atol=5e-5, rtol=1e-4), float((out - out2).abs().max())
     ref = torch.from_numpy(g["out"])
     err = float((out.cpu() - ref).abs().max())
     print(f"[{name}] max|hip - reference| = {err:.3e} (max|ref| {float(ref.abs().max()):.3f})")

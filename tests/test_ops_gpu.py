@@ -1046,3 +1046,48 @@ def test_resampling_convs_match_the_reference_fixture(nat):
         nat.conv_igemm(src0=cl(x), C0=Cc, N=N, Hs=H, Ws=H, up=0 if kind == "down" else 1, stride=2 if kind == "down" else 1,
                        Ho=Ho, Wo=Ho, W=packed(nat, w), bias=b.cuda(), Cout=Cc, out=out, ldo=Cc)
         close(from_cl(out, N, Ho, Ho, Cc), torch.from_numpy(g[f"{kind}_y"]), 2e-5)
+
+
+@pytest.mark.parametrize("N,P,Cc,heads", [(3, 256, 64, 4), (5, 64, 128, 4), (9, 4, 128, 4), (2, 36, 64, 4), (1, 9, 128, 2), (10, 100, 64, 2),
+                                          (2, 64, 64, 1)])
+def test_spatial_attention_with_fused_projection(nat, N, P, Cc, heads):
+    """lfvdm_attn_spatial_fused (qkv projection + flash attention in one launch) == GroupNorm + qkv Linear + attention +
+    proj of the oracle's spatial RPEAttention (rpe.py:133-174), and == the two-launch form within fp32 re-association."""
+    L = nat.lib()
+    assert L.lfvdm_attn_spatial_fused_ok(N, P, Cc, heads) == 0
+    shapes = {"qkv.weight": (3 * Cc, Cc), "qkv.bias": (3 * Cc,), "proj_out.weight": (Cc, Cc), "proj_out.bias": (Cc,),
+              "norm.weight": (Cc,), "norm.bias": (Cc,)}
+    sd = {"p." + k: torch.from_numpy(recipe.fill_param("saf." + k, s)) for k, s in shapes.items()}
+    x = rnd("saf/x", 1, N, Cc, P)                                    # (B = 1, D = N frames, C, tokens)
+    ref, _ = uo.rpe_attention(sd, "p", x, None, None, None, heads, False)
+    d = {k: v.cuda() for k, v in sd.items()}
+    M = N * P
+    xc = x[0].permute(0, 2, 1).contiguous().cuda()                  # [N][P][C]
+    xn = torch.empty(M, Cc, device="cuda")
+    nat.check(L.lfvdm_gn_apply(nat.ptr(xc), None, Cc, 0, N, P, nat.ptr(d["p.norm.weight"]), nat.ptr(d["p.norm.bias"]),
+                               None, 1, 0, 1e-5, nat.ACT_NONE, nat.ptr(xn), None, None, None, nat.stream()), "lfvdm_gn_apply")
+    o = torch.full((M, Cc), float("nan"), device="cuda")
+    nat.check(L.lfvdm_attn_spatial_fused(nat.ptr(xn), nat.ptr(d["p.qkv.weight"]), nat.ptr(d["p.qkv.bias"]), nat.ptr(o), N, P, Cc, heads,
+                                         nat.stream()), "lfvdm_attn_spatial_fused")
+    # two-launch form on the same operands
+    qkv = torch.empty(M, 3 * Cc, device="cuda")
+    nat.conv_igemm(src0=xn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.qkv.weight"], bias=d["p.qkv.bias"],
+                   Cout=3 * Cc, out=qkv, ldo=3 * Cc)
+    o2 = torch.empty(M, Cc, device="cuda")
+    nat.attn_spatial(qkv, o2, None, N, P, Cc, heads)
+    close(o, o2, 2e-5)
+    o1 = o.clone()
+    nat.check(L.lfvdm_attn_spatial_fused(nat.ptr(xn), nat.ptr(d["p.qkv.weight"]), nat.ptr(d["p.qkv.bias"]), nat.ptr(o), N, P, Cc, heads,
+                                         nat.stream()), "lfvdm_attn_spatial_fused")
+    assert torch.equal(o, o1), "bitwise reproducible"
+    y = torch.empty(M, Cc, device="cuda")
+    nat.conv_igemm(src0=o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.proj_out.weight"], bias=d["p.proj_out.bias"],
+                   Cout=Cc, res=xn, ldr=Cc, out=y, ldo=Cc)
+    close(y.view(N, P, Cc).permute(0, 2, 1), ref[0], 1e-4)
+
+
+def test_spatial_fused_refuses_what_does_not_fit(nat):
+    L = nat.lib()
+    assert L.lfvdm_attn_spatial_fused_ok(40, 256, 128, 4) != 0       # 16x16 frame at 128 channels: 128 KB of tokens alone
+    assert L.lfvdm_attn_spatial_fused_ok(40, 256, 96, 4) != 0        # head dim 24
+    assert L.lfvdm_attn_spatial_fused_ok(40, 64, 128, 4) == 0
