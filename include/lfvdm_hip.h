@@ -157,6 +157,22 @@ int lfvdm_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int C
  *   lfvdm_unpack_conv_grad: packed [Cout][k*k][Cin] -> OIHW gradient (accumulate = 1: +=).
  * ------------------------------------------------------------------------------------- */
 int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Deterministic gradients (LFVDM_DETERMINISTIC=1 on the Python side; reference behaviour: loss.backward() on the CPU
+ * path is run-to-run reproducible, train_util.py:328).  By default the partial sums of different workgroups - weight /
+ * bias gradients over slices of the output pixels, GroupNorm parameter gradients over samples, the input gradient of
+ * the embedding projections over output rows, the RPE hidden-layer gradients over row tiles - are combined with float
+ * atomics: the order, hence the rounding, changes from run to run.  With a workspace the partials are STORED to slabs
+ * (one row per contributor, zero-filled first where a contributor does not cover every element) and added in
+ * contributor order by an extra launch: bitwise reproducible, at the price of the slab traffic.
+ *   lfvdm_conv_wgrad     : a->splitk_ws = slab, a->splitk_ws_floats = its capacity (>= Cout*k*k*Cin + Cout; the number
+ *                          of pixel slices is reduced to what fits)
+ *   lfvdm_*_det          : the entry points below with (det_ws, det_ws_floats) appended
+ *   lfvdm_det_reduce     : dst[i] += slab[0][i] + slab[1][i] + ... + slab[parts-1][i], i < n  (the ordered sum itself)
+ * One workspace per device serves every launch (they are stream-ordered).
+ * ------------------------------------------------------------------------------------- */
+int lfvdm_det_reduce(float* dst, const float* slab, long n, long parts, void* stream);
 int lfvdm_pack_conv_weight_t(const float* w_oihw, float* w_packed_t, int Cout, int Cin, int ksize, void* stream);
 int lfvdm_unpack_conv_grad(const float* g_packed, float* g_oihw, int Cout, int Cin, int ksize, int accumulate, void* stream);
 
@@ -261,6 +277,10 @@ int lfvdm_gn_param_grads(const float* sums, const float* gamma, const float* bet
 /* Temporal GroupNorm backward: dx from dy; dgamma/dbeta [C] are ACCUMULATED with float atomics. */
 int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* dgamma,
                           float* dbeta, int B, int T, int P, int C, int accumulate, void* stream);
+/* deterministic form: det_ws >= 2 * ceil(B*P / 4) * C floats */
+int lfvdm_gn_temporal_bwd_det(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* dgamma,
+                              float* dbeta, int B, int T, int P, int C, int accumulate, float* det_ws, int64_t det_ws_floats,
+                              void* stream);
 
 /* Temporal GroupNorm of rpe.py:135-137: statistics over (C/32 channels x T frames) for each
  * (b, pixel); writes the normalised tensor (it is also the residual of rpe.py:172).
@@ -305,6 +325,10 @@ typedef struct lfvdm_rowdot_bwd_job {
     int32_t K, O, M, ldin, lddout, lddin, in_mode, task0;
 } lfvdm_rowdot_bwd_job;
 int lfvdm_rowdot_bwd(const lfvdm_rowdot_bwd_job* jobs_dev, int njobs, int total_tasks, void* stream);
+/* deterministic form: din_base / din_n = the array every job's `din` rows live in (NULL: no job has a din);
+ * det_ws >= total_tasks * din_n floats */
+int lfvdm_rowdot_bwd_det(const lfvdm_rowdot_bwd_job* jobs_dev, int njobs, int total_tasks, float* din_base, int64_t din_n,
+                         float* det_ws, int64_t det_ws_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * All RPENet output projections of one forward in one launch (rpe.py:20-31):
@@ -357,6 +381,9 @@ typedef struct lfvdm_rpe_bwd_job {
 
 int lfvdm_rpe_nets_bwd(const lfvdm_rpe_bwd_job* jobs_dev, int njobs, int total_tiles, const int64_t* frame_indices_i64,
                        int B, int T, void* stream);
+/* deterministic form: det_ws >= total_tiles * 5 * 512 floats; every job has total_tiles / njobs tiles */
+int lfvdm_rpe_nets_bwd_det(const lfvdm_rpe_bwd_job* jobs_dev, int njobs, int total_tiles, const int64_t* frame_indices_i64,
+                           int B, int T, float* det_ws, int64_t det_ws_floats, void* stream);
 
 /* Hidden layer of one RPENet for the training path (rpe.py:20-31 before the output layer) and its backward:
  *   act[r][c] = silu(tproj[b][c] + Wd[c][0..2] . feats[r][0..2] + bd[c]),  rows r = (b, t, s), rows_per_b = T*T,

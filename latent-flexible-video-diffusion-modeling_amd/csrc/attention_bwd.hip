@@ -517,8 +517,12 @@ __global__ __launch_bounds__(256) void rpe_front_bwd_kernel(const float* __restr
 // ======================================================================================
 constexpr int RPB_LDR = 36;
 
+// det_slab (deterministic mode): tile t stores its five per-channel partial sums to det_slab[t][5][512] instead of adding
+// them with float atomics; rpe_nets_bwd_reduce_kernel then adds the tiles of every network in tile order.
+constexpr int RPB_DET_C = 512, RPB_DET_LD = 5 * RPB_DET_C;
 __global__ __launch_bounds__(256) void rpe_nets_bwd_kernel(const lfvdm_rpe_bwd_job* __restrict__ jobs, int njobs,
-                                                           const int64_t* __restrict__ fi, int B, int T) {
+                                                           const int64_t* __restrict__ fi, int B, int T,
+                                                           float* __restrict__ det_slab) {
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -601,7 +605,10 @@ __global__ __launch_bounds__(256) void rpe_nets_bwd_kernel(const lfvdm_rpe_bwd_j
         }
         s_lo += __shfl_xor(s_lo, 32, 64); s_hi += __shfl_xor(s_hi, 32, 64);
         s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (lane < 32) {
+        if (lane < 32 && det_slab) {
+            float* r = det_slab + (size_t)blockIdx.x * RPB_DET_LD + c;
+            r[0] = s_lo; r[RPB_DET_C] = s_hi; r[2 * RPB_DET_C] = s0; r[3 * RPB_DET_C] = s1; r[4 * RPB_DET_C] = s2;
+        } else if (lane < 32) {
             atomicAdd(J.dtproj + (size_t)b_lo * J.dtproj_ld + c, s_lo);
             if (b_lo + 1 < B && (m0 + 31) / TT != b_lo) atomicAdd(J.dtproj + (size_t)(b_lo + 1) * J.dtproj_ld + c, s_hi);
             atomicAdd(J.dbd + c, s_lo + s_hi);
@@ -610,6 +617,26 @@ __global__ __launch_bounds__(256) void rpe_nets_bwd_kernel(const lfvdm_rpe_bwd_j
             atomicAdd(J.dWd + (size_t)c * 3 + 2, s2);
         }
     }
+}
+
+// one thread per (network, channel): the network's tiles in order; every destination word has ONE writer
+__global__ __launch_bounds__(64) void rpe_nets_bwd_reduce_kernel(const lfvdm_rpe_bwd_job* __restrict__ jobs, const float* __restrict__ slab,
+                                                                int tiles_per_job, int B, int TT) {
+    const lfvdm_rpe_bwd_job J = jobs[blockIdx.x];
+    const int c = blockIdx.y * 64 + threadIdx.x;
+    if (c >= J.C) return;
+    float dbd = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int t = 0; t < tiles_per_job; ++t) {
+        const float* r = slab + (size_t)(J.tile0 + t) * RPB_DET_LD + c;
+        const int m0 = t * 32, b_lo = m0 / TT;
+        const float s_lo = r[0], s_hi = r[RPB_DET_C];
+        J.dtproj[(size_t)b_lo * J.dtproj_ld + c] += s_lo;
+        if (b_lo + 1 < B && (m0 + 31) / TT != b_lo) J.dtproj[(size_t)(b_lo + 1) * J.dtproj_ld + c] += s_hi;
+        dbd += s_lo + s_hi;
+        d0 += r[2 * RPB_DET_C]; d1 += r[3 * RPB_DET_C]; d2 += r[4 * RPB_DET_C];
+    }
+    J.dbd[c] += dbd;
+    J.dWd[(size_t)c * 3 + 0] += d0; J.dWd[(size_t)c * 3 + 1] += d1; J.dWd[(size_t)c * 3 + 2] += d2;
 }
 
 template <int TMAX, int FC>
@@ -688,14 +715,31 @@ extern "C" int lfvdm_rpe_front_bwd(const float* tproj, int tproj_ld, const float
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_rpe_nets_bwd(const lfvdm_rpe_bwd_job* jobs_dev, int njobs, int total_tiles, const int64_t* fi, int B,
-                                  int T, void* stream) {
+static int rpe_nets_bwd_impl(const lfvdm_rpe_bwd_job* jobs_dev, int njobs, int total_tiles, const int64_t* fi, int B, int T,
+                            float* det_ws, long det_ws_floats, hipStream_t s) {
     if (!jobs_dev || !fi || njobs <= 0 || total_tiles <= 0 || B <= 0 || T <= 0 || T * T < 32) return LFVDM_E_SHAPE;
+    if (det_ws && ((long)total_tiles * RPB_DET_LD > det_ws_floats || total_tiles % njobs)) return LFVDM_E_SHAPE;
     const int maxC = 512;    // LDS sized for the largest supported C: dR tile 32*(C+4) + 4 wave-private W chunks
     const size_t lds = (size_t)(32 * (maxC + 4) + 4 * 32 * RPB_LDR) * sizeof(float);
     static DynLdsLimit limit;
     if (int rc = limit.ensure(reinterpret_cast<const void*>(&rpe_nets_bwd_kernel), lds)) return rc;
-    hipLaunchKernelGGL(rpe_nets_bwd_kernel, dim3(total_tiles), dim3(256), lds, (hipStream_t)stream, jobs_dev, njobs, fi, B, T);
+    hipLaunchKernelGGL(rpe_nets_bwd_kernel, dim3(total_tiles), dim3(256), lds, s, jobs_dev, njobs, fi, B, T, det_ws);
     LFVDM_CHECK_LAUNCH();
+    if (det_ws) {
+        hipLaunchKernelGGL(rpe_nets_bwd_reduce_kernel, dim3(njobs, maxC / 64), dim3(64), 0, s, jobs_dev, det_ws, total_tiles / njobs, B,
+                           T * T);
+        LFVDM_CHECK_LAUNCH();
+    }
     return LFVDM_OK;
+}
+
+extern "C" int lfvdm_rpe_nets_bwd(const lfvdm_rpe_bwd_job* jobs_dev, int njobs, int total_tiles, const int64_t* fi, int B,
+                                  int T, void* stream) {
+    return rpe_nets_bwd_impl(jobs_dev, njobs, total_tiles, fi, B, T, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int lfvdm_rpe_nets_bwd_det(const lfvdm_rpe_bwd_job* jobs_dev, int njobs, int total_tiles, const int64_t* fi, int B,
+                                      int T, float* det_ws, int64_t det_ws_floats, void* stream) {
+    if (!det_ws) return LFVDM_E_SHAPE;
+    return rpe_nets_bwd_impl(jobs_dev, njobs, total_tiles, fi, B, T, det_ws, (long)det_ws_floats, (hipStream_t)stream);
 }

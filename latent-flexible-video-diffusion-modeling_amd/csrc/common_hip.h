@@ -68,3 +68,19 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---- Deterministic accumulation (LFVDM_DETERMINISTIC=1, lfvdm_hip.h).  Partial sums of different workgroups are
+// normally combined with float atomics, whose order - hence the rounding - changes from run to run.  With a slab the
+// partials go to slab[part][n] by plain stores (each (part, element) at most once; the slab is zero-filled first
+// where a part does not cover every element) and ONE launch adds the parts in index order: dst[i] += sum_p slab[p][i].
+struct DetSlab {
+    float* slab;           // nullptr: float atomics
+    const float* base;     // first element of the destination array
+    long n;                // elements of the destination array = row length of the slab
+};
+__device__ __forceinline__ void det_add(const DetSlab& d, long part, float* dst, float v) {
+    if (d.slab) d.slab[(size_t)part * d.n + (size_t)(dst - d.base)] = v;
+    else atomicAdd(dst, v);
+}
+// dst[i] += slab[0][i] + slab[1][i] + ... (fixed order), i < n  (det_reduce.hip)
+int lfvdm_det_reduce_launch(float* dst, const float* slab, long n, long parts, hipStream_t s);

@@ -131,16 +131,19 @@ __device__ __forceinline__ void wgrad_wave_task(const lfvdm_conv_args& p, int ms
         wave_lds_fence();
     }
     // ---- accumulate the partial tile: D lane l holds column k = l&31, rows co = (r&3)+8*(r>>2)+4*(l>>5)
+    // (float atomics, or - deterministic mode, splitk_ws = slab - plain stores to this M slice's slab row)
     const int Ktot = taps * Cin;
     float* dW = p.out;
     const bool oihw = p.out_mode == 1;   // accumulate straight into the OIHW parameter gradient
+    const DetSlab dsW = {p.splitk_ws, p.out, (long)p.Cout * Ktot};
+    const DetSlab dsB = {p.splitk_ws ? p.splitk_ws + (size_t)msplit * dsW.n : nullptr, p.bias, (long)p.Cout};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (co < p.Cout) {
             const int ci = cc + (lane & 31);
             float* dst = oihw ? dW + ((size_t)co * Cin + ci) * taps + tap : dW + (size_t)co * Ktot + (size_t)tap * Cin + ci;
-            atomicAdd(dst, acc[r]);
+            det_add(dsW, ms, dst, acc[r]);
         }
     }
     if (kt == 0 && p.bias != nullptr) {
@@ -152,8 +155,8 @@ __device__ __forceinline__ void wgrad_wave_task(const lfvdm_conv_args& p, int ms
             bsum.z += __shfl_xor(bsum.z, o, 64); bsum.w += __shfl_xor(bsum.w, o, 64);
         }
         if (lane < 8 && co0 + col < p.Cout) {
-            atomicAdd(db + co0 + col + 0, bsum.x); atomicAdd(db + co0 + col + 1, bsum.y);
-            atomicAdd(db + co0 + col + 2, bsum.z); atomicAdd(db + co0 + col + 3, bsum.w);
+            det_add(dsB, ms, db + co0 + col + 0, bsum.x); det_add(dsB, ms, db + co0 + col + 1, bsum.y);
+            det_add(dsB, ms, db + co0 + col + 2, bsum.z); det_add(dsB, ms, db + co0 + col + 3, bsum.w);
         }
     }
 }
@@ -327,6 +330,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_coop_kernel(const lfvdm_conv_a
     const int Ktot = taps * Cin;
     float* dW = p.out;
     const bool oihw = p.out_mode == 1;
+    const DetSlab dsW = {p.splitk_ws, p.out, (long)p.Cout * Ktot};      // deterministic mode: slab row ms instead of atomics
+    const DetSlab dsB = {p.splitk_ws ? p.splitk_ws + (size_t)msplit * dsW.n : nullptr, p.bias, (long)p.Cout};
 #pragma unroll
     for (int x = 0; x < TC; ++x)
 #pragma unroll
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_coop_kernel(const lfvdm_conv_a
                 const int co = co0 + (wc * TC + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co < p.Cout) {
                     float* dst = oihw ? dW + ((size_t)co * Cin + ci) * taps + tap : dW + (size_t)co * Ktot + (size_t)tap * Cin + ci;
-                    atomicAdd(dst, acc[x][y][r]);
+                    det_add(dsW, ms, dst, acc[x][y][r]);
                 }
             }
         }
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_coop_kernel(const lfvdm_conv_a
             float t = 0.f;
             const int nr = DRS < 8 ? DRS : 8;
             for (int r = 0; r < nr; ++r) t += bias_red[r][tid];
-            atomicAdd(const_cast<float*>(p.bias) + co0 + tid, t);
+            det_add(dsB, ms, const_cast<float*>(p.bias) + co0 + tid, t);
         }
     }
 }
@@ -498,6 +503,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
     const int Ktot = taps * Cin;
     float* dW = p.out;
     const bool oihw = p.out_mode == 1;
+    const DetSlab dsW = {p.splitk_ws, p.out, (long)p.Cout * Ktot};      // deterministic mode: slab row ms instead of atomics
+    const DetSlab dsB = {p.splitk_ws ? p.splitk_ws + (size_t)msplit * dsW.n : nullptr, p.bias, (long)p.Cout};
 #pragma unroll
     for (int x = 0; x < TC; ++x)
 #pragma unroll
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
                 const int co = co0 + (wc * TC + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co < p.Cout) {
                     float* dst = oihw ? dW + ((size_t)co * Cin + ci) * taps + tap : dW + (size_t)co * Ktot + (size_t)tap * Cin + ci;
-                    atomicAdd(dst, acc[x][y][r]);
+                    det_add(dsW, ms, dst, acc[x][y][r]);
                 }
             }
         }
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
             float t = 0.f;
             const int nr = DRS < 8 ? DRS : 8;
             for (int r = 0; r < nr; ++r) t += bias_red[r * BRL + tid];
-            atomicAdd(const_cast<float*>(p.bias) + co0 + tid, t);
+            det_add(dsB, ms, const_cast<float*>(p.bias) + co0 + tid, t);
         }
     }
 }
@@ -536,6 +543,25 @@ static bool wgrad_dma_ok(const lfvdm_conv_args* a, long M) {
     const bool off = getenv("LFVDM_WGRAD_NO_DMA") != nullptr;             // A/B aid (read per launch: tests toggle it)
     const long Cmax = a->C0 > a->C1 ? a->C0 : a->C1, lim = 1L << 30;
     return !off && !a->coefA && M * a->ldr * 4 < lim && (long)a->N * a->Hs * a->Ws * Cmax * 4 < lim;
+}
+
+// Deterministic mode (lfvdm_conv_args.splitk_ws = slab of splitk_ws_floats floats): every M slice stores its partial
+// dW (and db) to its own slab row - each (slice, element) exactly once: all (tile, slice) workgroups exist - and
+// det_finish adds the rows in slice order.  det_fit shrinks the number of slices to what the slab holds.
+static int det_fit(const lfvdm_conv_args* a, long& msplit) {
+    if (!a->splitk_ws) return LFVDM_OK;
+    const long per = (long)a->Cout * a->ksize * a->ksize * (a->C0 + a->C1) + a->Cout;
+    if (a->splitk_ws_floats < per) return LFVDM_E_SHAPE;
+    if (msplit * per > a->splitk_ws_floats) msplit = a->splitk_ws_floats / per;
+    return LFVDM_OK;
+}
+static int det_finish(const lfvdm_conv_args* a, long msplit, hipStream_t s) {
+    if (!a->splitk_ws) return LFVDM_OK;
+    if (hipGetLastError() != hipSuccess) return LFVDM_E_LAUNCH;
+    const long n = (long)a->Cout * a->ksize * a->ksize * (a->C0 + a->C1);
+    if (int rc = lfvdm_det_reduce_launch(a->out, a->splitk_ws, n, msplit, s)) return rc;
+    if (a->bias) return lfvdm_det_reduce_launch(const_cast<float*>(a->bias), a->splitk_ws + (size_t)msplit * n, a->Cout, msplit, s);
+    return LFVDM_OK;
 }
 
 template <int COT, int KT, int NS>
@@ -551,12 +577,13 @@ static int launch_wgrad_dma(const lfvdm_conv_args* a, hipStream_t s, int nchunks
     constexpr size_t lds = (size_t)(NS * (32 * COT * 32 + 32 * KT * 32) + 8 * COT * 32) * sizeof(float);
     static DynLdsLimit limit;
     if (int rc = limit.ensure(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT, KT, NS>), lds)) return rc;
+    if (int rc = det_fit(a, msplit)) return rc;
     hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT, KT, NS>), dim3((unsigned)(tiles * msplit)), dim3(256), lds, s, *a, (int)msplit);
-    return LFVDM_OK;
+    return det_finish(a, msplit, s);
 }
 
 template <int COT, int KT>
-static void launch_wgrad_coop(const lfvdm_conv_args* a, hipStream_t s, int nchunks) {
+static int launch_wgrad_coop(const lfvdm_conv_args* a, hipStream_t s, int nchunks) {
     const int Cin = a->C0 + a->C1;
     const int NKG = a->ksize * a->ksize * (Cin / (32 * KT));
     const int NCG = (a->Cout + 32 * COT - 1) / (32 * COT);
@@ -565,7 +592,9 @@ static void launch_wgrad_coop(const lfvdm_conv_args* a, hipStream_t s, int nchun
     long msplit = (target + tiles - 1) / tiles;        // 1.5 workgroups per CU measured best (tile traffic vs bytes of atomics)
     if (msplit > nchunks / 2) msplit = nchunks / 2;    // at least two chunks per slice (the prefetch needs a successor)
     if (msplit < 1) msplit = 1;
+    if (int rc = det_fit(a, msplit)) return rc;
     hipLaunchKernelGGL((conv_wgrad_coop_kernel<COT, KT>), dim3((unsigned)(tiles * msplit)), dim3(256), 0, s, *a, (int)msplit);
+    return det_finish(a, msplit, s);
 }
 
 // OIHW -> [Cin][k*k][Cout] with the taps flipped: Wt[ci][t][co] = W[co][ci][k*k-1-t]
@@ -711,10 +740,12 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
                 LFVDM_CHECK_LAUNCH();
                 return LFVDM_OK;
             }
-            if (cot == 4 && kt == 4) launch_wgrad_coop<4, 4>(a, s, nchunks);
-            else if (cot == 4) launch_wgrad_coop<4, 2>(a, s, nchunks);
-            else if (kt == 4) launch_wgrad_coop<2, 4>(a, s, nchunks);
-            else launch_wgrad_coop<2, 2>(a, s, nchunks);
+            int rc;
+            if (cot == 4 && kt == 4) rc = launch_wgrad_coop<4, 4>(a, s, nchunks);
+            else if (cot == 4) rc = launch_wgrad_coop<4, 2>(a, s, nchunks);
+            else if (kt == 4) rc = launch_wgrad_coop<2, 4>(a, s, nchunks);
+            else rc = launch_wgrad_coop<2, 2>(a, s, nchunks);
+            if (rc != LFVDM_OK) return rc;
             LFVDM_CHECK_LAUNCH();
             return LFVDM_OK;
         }
@@ -723,11 +754,12 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
     long msplit = (4096 + tiles - 1) / tiles;          // aim at ~4k wave tasks
     if (msplit > nchunks) msplit = nchunks;
     if (msplit < 1) msplit = 1;
+    if (int rc = det_fit(a, msplit)) return rc;
     const long ntasks = tiles * msplit;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a,
                        (int)msplit);
     LFVDM_CHECK_LAUNCH();
-    return LFVDM_OK;
+    return det_finish(a, msplit, (hipStream_t)stream);
 }
 
 extern "C" int lfvdm_conv_wgrad_grouped(const lfvdm_wgrad_job* jobs_dev, int njobs, int total_tasks, void* stream) {

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
                                                               const float* __restrict__ gamma, float eps,
                                                               float* __restrict__ dx, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int B, int T, int P, int C,
-                                                              int accumulate) {
+                                                              int accumulate, float* __restrict__ det_slab) {
     __shared__ float ch_all[4][3][GTB_MAXC];
     __shared__ float gst_all[4][4][32];
     const int lane = threadIdx.x & 63;
@@ -377,8 +377,11 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
                 bsum += ch_all[w][1][ch];
             }
         }
-        atomicAdd(dgamma + ch, g);
-        atomicAdd(dbeta + ch, bsum);
+        // (deterministic mode: this workgroup's row of the slab instead of atomics; every workgroup writes all C channels)
+        const DetSlab dsG = {det_slab, dgamma, (long)C};
+        const DetSlab dsB = {det_slab ? det_slab + (size_t)gridDim.x * C : nullptr, dbeta, (long)C};
+        det_add(dsG, blockIdx.x, dgamma + ch, g);
+        det_add(dsB, blockIdx.x, dbeta + ch, bsum);
     }
     if (!live) return;
     const int E = T * Q;
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_reg_kernel(const float* _
                                                                   const float* __restrict__ gamma, float eps,
                                                                   float* __restrict__ dx, float* __restrict__ dgamma,
                                                                   float* __restrict__ dbeta, int B, int T, int P, int C,
-                                                                  int accumulate) {
+                                                                  int accumulate, float* __restrict__ det_slab) {
     __shared__ float ch_all[4][3][256];
     __shared__ float gst_all[4][4][32];
     const int lane = threadIdx.x & 63;
@@ -502,8 +505,11 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_reg_kernel(const float* _
                 bsum += ch_all[w][1][ch];
             }
         }
-        atomicAdd(dgamma + ch, g);
-        atomicAdd(dbeta + ch, bsum);
+        // (deterministic mode: this workgroup's row of the slab instead of atomics; every workgroup writes all C channels)
+        const DetSlab dsG = {det_slab, dgamma, (long)C};
+        const DetSlab dsB = {det_slab ? det_slab + (size_t)gridDim.x * C : nullptr, dbeta, (long)C};
+        det_add(dsG, blockIdx.x, dgamma + ch, g);
+        det_add(dsB, blockIdx.x, dbeta + ch, bsum);
     }
     if (!live) return;
     f32x4 S1, S2;
@@ -647,30 +653,50 @@ extern "C" int lfvdm_gn_bwd_fused(const float* da, const float* src0, const floa
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const float* gamma, float eps, float* dx,
-                                     float* dgamma, float* dbeta, int B, int T, int P, int C, int accumulate, void* stream) {
+static int gn_temporal_bwd_impl(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* dgamma,
+                               float* dbeta, int B, int T, int P, int C, int accumulate, float* det_ws, long det_ws_floats,
+                               hipStream_t s) {
     if (B <= 0 || T <= 0 || P <= 0 || C % 32 || C > GTB_MAXC) return LFVDM_E_SHAPE;
     const long samples = (long)B * P;
     const int Q = C / 4;
+    const long nwg = (samples + 3) / 4;
+    if (det_ws && det_ws_floats < 2 * nwg * C) return LFVDM_E_SHAPE;
+    const dim3 grid((unsigned)nwg);
     static const bool no_reg = getenv("LFVDM_GNT_BWD_NO_REG") != nullptr;        // A/B aid
+    bool launched = false;
     if (!no_reg && Q <= 64 && 64 % Q == 0) {       // register-resident sample: frames per lane = ceil(T / (64 / Q))
         const int per_lane = (T + 64 / Q - 1) / (64 / Q);
-        const dim3 grid((unsigned)((samples + 3) / 4));
-        hipStream_t s = (hipStream_t)stream;
 #define LFVDM_GNTB(N)                                                                                                  \
-        if (per_lane <= N) {                                                                                           \
+        if (!launched && per_lane <= N) {                                                                              \
             hipLaunchKernelGGL(gn_temporal_bwd_reg_kernel<N>, grid, dim3(256), 0, s, x, dy, gamma, eps, dx, dgamma, dbeta, B, T, \
-                               P, C, accumulate);                                                                      \
-            LFVDM_CHECK_LAUNCH();                                                                                      \
-            return LFVDM_OK;                                                                                           \
+                               P, C, accumulate, det_ws);                                                              \
+            launched = true;                                                                                           \
         }
         LFVDM_GNTB(8) LFVDM_GNTB(16) LFVDM_GNTB(32)
 #undef LFVDM_GNTB
     }
-    hipLaunchKernelGGL(gn_temporal_bwd_kernel, dim3((unsigned)((samples + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, dy,
-                       gamma, eps, dx, dgamma, dbeta, B, T, P, C, accumulate);
+    if (!launched)
+        hipLaunchKernelGGL(gn_temporal_bwd_kernel, grid, dim3(256), 0, s, x, dy, gamma, eps, dx, dgamma, dbeta, B, T, P, C,
+                           accumulate, det_ws);
     LFVDM_CHECK_LAUNCH();
+    if (det_ws) {       // ordered sum of the workgroups' partial parameter gradients
+        if (int rc = lfvdm_det_reduce_launch(dgamma, det_ws, C, nwg, s)) return rc;
+        return lfvdm_det_reduce_launch(dbeta, det_ws + (size_t)nwg * C, C, nwg, s);
+    }
     return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_temporal_bwd(const float* x, const float* dy, const float* gamma, float eps, float* dx,
+                                     float* dgamma, float* dbeta, int B, int T, int P, int C, int accumulate, void* stream) {
+    return gn_temporal_bwd_impl(x, dy, gamma, eps, dx, dgamma, dbeta, B, T, P, C, accumulate, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int lfvdm_gn_temporal_bwd_det(const float* x, const float* dy, const float* gamma, float eps, float* dx,
+                                         float* dgamma, float* dbeta, int B, int T, int P, int C, int accumulate, float* det_ws,
+                                         int64_t det_ws_floats, void* stream) {
+    if (!det_ws) return LFVDM_E_SHAPE;
+    return gn_temporal_bwd_impl(x, dy, gamma, eps, dx, dgamma, dbeta, B, T, P, C, accumulate, det_ws, (long)det_ws_floats,
+                                (hipStream_t)stream);
 }
 
 extern "C" int lfvdm_gn_param_grads(const float* sums, const float* gamma, const float* beta, const float* film, int film_ld,

@@ -761,7 +761,7 @@ constexpr int RDB_ROWS = 8;    // rows per wave and task: the dW read-modify-wri
 constexpr int RDB_TPW = 4;     // tasks per wave: upper bound of the LFVDM_ROWDOT_TPW tuning aid; the launcher uses 1
 constexpr int RDB_KIT = 4;     // K <= 1024 on the grouped path (256 floats per lane sweep)
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_job* __restrict__ jobs, int njobs, int total_tasks,
-                                                         int tpw) {
+                                                         int tpw, const DetSlab ds) {
     __shared__ f32x4 red[3][4][RDB_KIT][64];         // waves 1..3 -> wave 0: [wave - 1][m][k sweep][lane]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -771,7 +771,8 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_
     while (jf + 1 < njobs && jobs[jf + 1].task0 <= first) ++jf;
     while (jl + 1 < njobs && jobs[jl + 1].task0 <= last) ++jl;
     const lfvdm_rowdot_bwd_job J0 = jobs[jf];
-    const bool grouped = jf == jl && J0.din != nullptr && J0.M <= 4 && J0.K <= 256 * RDB_KIT;   // workgroup-uniform
+    // (deterministic mode: every wave task stores its din partial to ITS row of the zero-filled slab - no grouping)
+    const bool grouped = jf == jl && J0.din != nullptr && J0.M <= 4 && J0.K <= 256 * RDB_KIT && !ds.slab;   // workgroup-uniform
     f32x4 accG[4][RDB_KIT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -836,8 +837,8 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_
                     for (int i = 0; i < 4; ++i) {
                         if (i < mc) {
                             float* dst = J.din + (size_t)(m0 + i) * J.lddin + k;
-                            atomicAdd(dst + 0, accD[i].x); atomicAdd(dst + 1, accD[i].y);
-                            atomicAdd(dst + 2, accD[i].z); atomicAdd(dst + 3, accD[i].w);
+                            det_add(ds, task, dst + 0, accD[i].x); det_add(ds, task, dst + 1, accD[i].y);
+                            det_add(ds, task, dst + 2, accD[i].z); det_add(ds, task, dst + 3, accD[i].w);
                         }
                     }
                 }
@@ -882,9 +883,28 @@ extern "C" int lfvdm_rowdot_bwd(const lfvdm_rowdot_bwd_job* jobs_dev, int njobs,
     if (!jobs_dev || njobs <= 0 || total_tasks <= 0) return LFVDM_E_SHAPE;
     static const int tpw_env = getenv("LFVDM_ROWDOT_TPW") ? atoi(getenv("LFVDM_ROWDOT_TPW")) : 0;     // tuning aid
     const int tpw = tpw_env >= 1 && tpw_env <= RDB_TPW ? tpw_env : 1;
+    const DetSlab none = {nullptr, nullptr, 0};
     hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((total_tasks + 4 * tpw - 1) / (4 * tpw)), dim3(256), 0, (hipStream_t)stream,
-                       jobs_dev, njobs, total_tasks, tpw);
+                       jobs_dev, njobs, total_tasks, tpw, none);
     LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+// Deterministic form: din_base / din_n = the array that holds every job's `din` rows (all jobs of the launch accumulate
+// into it); det_ws holds total_tasks rows of din_n floats.  Zero-fill, partial stores, ordered sum.
+extern "C" int lfvdm_rowdot_bwd_det(const lfvdm_rowdot_bwd_job* jobs_dev, int njobs, int total_tasks, float* din_base,
+                                    int64_t din_n, float* det_ws, int64_t det_ws_floats, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_tasks <= 0) return LFVDM_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    DetSlab ds = {nullptr, nullptr, 0};
+    if (din_base) {
+        if (!det_ws || din_n <= 0 || (int64_t)total_tasks * din_n > det_ws_floats) return LFVDM_E_SHAPE;
+        if (hipMemsetAsync(det_ws, 0, (size_t)total_tasks * din_n * sizeof(float), s) != hipSuccess) return LFVDM_E_LAUNCH;
+        ds = {det_ws, din_base, (long)din_n};
+    }
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((total_tasks + 3) / 4), dim3(256), 0, s, jobs_dev, njobs, total_tasks, 1, ds);
+    LFVDM_CHECK_LAUNCH();
+    if (din_base) return lfvdm_det_reduce_launch(din_base, det_ws, (long)din_n, total_tasks, s);
     return LFVDM_OK;
 }
 

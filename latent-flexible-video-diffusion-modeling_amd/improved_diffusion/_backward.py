@@ -22,6 +22,7 @@ FiLM projections and the 3-feature / time projections inside the RPE networks - 
 block, < 1 % of the FLOPs - plus their elementwise glue (SiLU, log1p features) and GroupNorm parameter-gradient
 reductions.
 """
+import ctypes
 import os
 import weakref
 
@@ -380,6 +381,26 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
     L = nat.lib()
     dxa = _new(N * P, C0, like=da)
     dxb = _new(N * P, C1, like=da) if C1 else None
+    if inplace and nat.deterministic():
+        # fixed summation order: per-(sample, channel) sums (lfvdm_gn_bwd_stats), dx (lfvdm_gn_bwd_apply), then the
+        # parameter / FiLM gradients by lfvdm_gn_param_grads, which walks the samples in order - no float atomics
+        sums = _new(N, C, 2, like=da)
+        nat.check(L.lfvdm_gn_bwd_stats(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
+                                       act, nat.ptr(sums), nat.stream()), "lfvdm_gn_bwd_stats")
+        nat.check(L.lfvdm_gn_bwd_apply(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
+                                       nat.ptr(sums), act, nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.stream()), "lfvdm_gn_bwd_apply")
+        if add is not None:
+            dxa.add_(add[:, :C0])
+            if dxb is not None:
+                dxb.add_(add[:, C0:])
+        dfilm = None
+        if film is not None:
+            dfilm = dfilm_out if dfilm_out is not None else th.zeros(N // T, 2 * C, device=da.device, dtype=th.float32)
+        nat.check(L.lfvdm_gn_param_grads(nat.ptr(sums), nat.ptr(gamma), nat.ptr(beta), film.data_ptr() if film is not None else None,
+                                         film.stride(0) if film is not None else 0, T, nat.ptr(_grad_of(gamma)), nat.ptr(_grad_of(beta)),
+                                         dfilm.data_ptr() if dfilm is not None else None, dfilm.stride(0) if dfilm is not None else 0,
+                                         N, C, nat.stream()), "lfvdm_gn_param_grads")
+        return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
     if inplace:
         # statistics, dx and the parameter gradients in ONE launch (float atomics into .grad / the FiLM gradient slot)
         dfilm = None
@@ -610,8 +631,14 @@ class TemporalAttnFn(th.autograd.Function):
         else:
             dg, db = th.zeros(C, device=x.device), th.zeros(C, device=x.device)
             tg, tb = dg, db
-        nat.check(nat.lib().lfvdm_gn_temporal_bwd(nat.ptr(x), nat.ptr(dxn), nat.ptr(gn_w), _EPS, nat.ptr(dx), nat.ptr(tg),
-                                                  nat.ptr(tb), B, T, P, C, 0, nat.stream()), "lfvdm_gn_temporal_bwd")
+        if nat.deterministic():
+            ws = nat.det_workspace(x.device)
+            nat.check(nat.lib().lfvdm_gn_temporal_bwd_det(nat.ptr(x), nat.ptr(dxn), nat.ptr(gn_w), _EPS, nat.ptr(dx), nat.ptr(tg),
+                                                          nat.ptr(tb), B, T, P, C, 0, ws.data_ptr(), ws.numel(), nat.stream()),
+                      "lfvdm_gn_temporal_bwd_det")
+        else:
+            nat.check(nat.lib().lfvdm_gn_temporal_bwd(nat.ptr(x), nat.ptr(dxn), nat.ptr(gn_w), _EPS, nat.ptr(dx), nat.ptr(tg),
+                                                      nat.ptr(tb), B, T, P, C, 0, nat.stream()), "lfvdm_gn_temporal_bwd")
         if ctx.dR_slots is not None:
             dRq = dRk = dRv = None
         return dx, dg, db, dwq, dbq, dwp, dbp, dRq, dRk, dRv, None, None, None, None, None, None, None
@@ -776,12 +803,22 @@ class _EmbedNet:
         if _rpe_group.pending:          # fills the RPE projections' gradient slots of this buffer
             _rpe_group.backward()
         L, s = nat.lib(), nat.stream()
-        nat.check(L.lfvdm_rowdot_bwd(st["j_bg"].data_ptr(), st["n_g"], st["tasks_g"], s), "lfvdm_rowdot_bwd")
+        if nat.deterministic():
+            # every `din` of these launches lives in the flat gradient buffer st["grads"]: ordered slabs over it
+            ws, g = nat.det_workspace(st["dev"]), st["grads"]
+
+            def rowdot_bwd(jobs, n, tasks, has_din=True):
+                nat.check(L.lfvdm_rowdot_bwd_det(jobs.data_ptr(), n, tasks, g.data_ptr() if has_din else None, g.numel(), ws.data_ptr(),
+                                                 ws.numel(), s), "lfvdm_rowdot_bwd_det")
+        else:
+            def rowdot_bwd(jobs, n, tasks, has_din=True):
+                nat.check(L.lfvdm_rowdot_bwd(jobs.data_ptr(), n, tasks, s), "lfvdm_rowdot_bwd")
+        rowdot_bwd(st["j_bg"], st["n_g"], st["tasks_g"])
         # d emb = (through the RPE projections) + (through silu in front of the FiLM projections)
         th.add(st["demb_raw"], th.ops.aten.silu_backward(st["demb_act"], st["emb"]), out=st["demb"])
-        nat.check(L.lfvdm_rowdot_bwd(st["j_b1"].data_ptr(), 1, st["tasks_t"], s), "lfvdm_rowdot_bwd")
+        rowdot_bwd(st["j_b1"], 1, st["tasks_t"])
         st["dh0"].copy_(th.ops.aten.silu_backward(st["dh0_act"], st["h0"]))
-        nat.check(L.lfvdm_rowdot_bwd(st["j_b0"].data_ptr(), 1, st["tasks_t"], s), "lfvdm_rowdot_bwd")
+        rowdot_bwd(st["j_b0"], 1, st["tasks_t"], has_din=False)
 
 
 _embed = _EmbedNet()
@@ -824,7 +861,7 @@ class _RpeGroup:
         msplit = max(1, min(4, tiles // 2))
         z = lambda *shape: th.zeros(*shape, device=dev, dtype=th.float32)
         st = dict(bufs={}, keep=[])
-        fj, bj, wj, tile0, task0 = [], [], [], 0, 0
+        fj, bj, wj, wargs, tile0, task0 = [], [], [], [], 0, 0
         for net in flat:
             C = net.out.weight.shape[0]
             tproj, dtproj = views[net]
@@ -841,9 +878,10 @@ class _RpeGroup:
             a = nat.fill_conv_args(src0=act, C0=C, N=M, Hs=1, Ws=1, Ho=1, Wo=1, ksize=1, res=dR.view(M, C), ldr=C,
                                    out=_grad_of(net.out.weight), bias=_grad_of(net.out.bias), Cout=C)
             wj.append(nat.WgradJob(a, msplit, task0))
+            wargs.append(a)
             tile0 += tiles
             task0 += (C // 32) * (C // 32) * msplit
-        st.update(nets=nets, flat=flat, params=params, tiles=tile0, tasks=task0, n=len(flat),
+        st.update(nets=nets, flat=flat, params=params, tiles=tile0, tasks=task0, n=len(flat), wargs=wargs,
                   maxC=max(n.out.weight.shape[0] for n in flat),
                   j_f=nat.jobs_to_device(fj, dev), j_b=nat.jobs_to_device(bj, dev), j_w=nat.jobs_to_device(wj, dev),
                   key=self._key(m, views, flat, params, B, T, dev))
@@ -882,6 +920,14 @@ class _RpeGroup:
         st = self.state
         B, T = st["BT"]
         L, s = nat.lib(), nat.stream()
+        if nat.deterministic():
+            ws = nat.det_workspace(st["fi"].device)
+            nat.check(L.lfvdm_rpe_nets_bwd_det(st["j_b"].data_ptr(), st["n"], st["tiles"], nat.ptr(st["fi"], th.int64), B, T,
+                                               ws.data_ptr(), ws.numel(), s), "lfvdm_rpe_nets_bwd_det")
+            for a in st["wargs"]:        # the output layers' weight gradients one by one (each through its ordered slab)
+                a.splitk_ws, a.splitk_ws_floats = ws.data_ptr(), ws.numel()
+                nat.check(L.lfvdm_conv_wgrad(ctypes.byref(a), s), "lfvdm_conv_wgrad")
+            return
         nat.check(L.lfvdm_rpe_nets_bwd(st["j_b"].data_ptr(), st["n"], st["tiles"], nat.ptr(st["fi"], th.int64), B, T, s),
                   "lfvdm_rpe_nets_bwd")
         nat.check(L.lfvdm_conv_wgrad_grouped(st["j_w"].data_ptr(), st["n"], st["tasks"], s), "lfvdm_conv_wgrad_grouped")

@@ -129,6 +129,10 @@ _SIGS = {
     "lfvdm_attn_spatial": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_attn_spatial_fused_ok": ([c_i, c_i, c_i, c_i], c_i),
     "lfvdm_attn_spatial_fused": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_det_reduce": ([c_fp, c_fp, C.c_long, C.c_long, c_fp], c_i),
+    "lfvdm_gn_temporal_bwd_det": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, C.c_int64, c_fp], c_i),
+    "lfvdm_rowdot_bwd_det": ([c_fp, c_i, c_i, c_fp, C.c_int64, c_fp, C.c_int64, c_fp], c_i),
+    "lfvdm_rpe_nets_bwd_det": ([c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp, C.c_int64, c_fp], c_i),
     "lfvdm_rpe_front": ([c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rpe_front_bwd": ([c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_sampler_tick": ([c_fp, c_fp, c_fp, c_i, c_fp], c_i),
@@ -327,9 +331,34 @@ def fill_conv_args(**kw):
     return a
 
 
+# ------------------------------------------------------------------------------------------- deterministic gradients
+def deterministic():
+    """LFVDM_DETERMINISTIC=1: partial gradient sums go through ordered slabs instead of float atomics (include/lfvdm_hip.h,
+    "Deterministic gradients"): bitwise reproducible training steps, at the price of the slab traffic."""
+    return os.environ.get("LFVDM_DETERMINISTIC", "0") == "1"
+
+
+_det_ws = {}
+
+
+def det_workspace(device):
+    """The per-device slab workspace of the deterministic mode (LFVDM_DET_WS_MB, default 1024 MiB; launches are stream-ordered,
+    one workspace serves all of them).  Allocated on first use, outside of stream capture."""
+    ws = _det_ws.get(device)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("deterministic workspace missing under stream capture: run the step eagerly once first")
+        ws = _det_ws[device] = torch.empty(int(os.environ.get("LFVDM_DET_WS_MB", "1024")) * 2 ** 18, device=device, dtype=torch.float32)
+    return ws
+
+
 def conv_wgrad(**kw):
     """Weight/bias gradient launch; kw as conv_igemm plus res=dout rows, out=packed dW, bias=db."""
-    check(lib().lfvdm_conv_wgrad(C.byref(fill_conv_args(**kw)), stream()), "lfvdm_conv_wgrad")
+    a = fill_conv_args(**kw)
+    if deterministic():
+        ws = det_workspace(kw["out"].device)
+        a.splitk_ws, a.splitk_ws_floats = ws.data_ptr(), ws.numel()
+    check(lib().lfvdm_conv_wgrad(C.byref(a), stream()), "lfvdm_conv_wgrad")
 
 
 def pack_conv_weight_t(w, out):

@@ -118,8 +118,11 @@ def _worker(rank, world, port, q, microbatch):
         raise
 
 
-@pytest.mark.parametrize("microbatch", [-1, 1], ids=["one_microbatch", "two_microbatches"])
-def test_trainloop_world2_matches_mean_gradient_step(microbatch):
+@pytest.mark.parametrize("microbatch,deterministic", [(-1, "0"), (1, "0"), (1, "1")],
+                         ids=["one_microbatch", "two_microbatches", "two_microbatches_deterministic"])
+def test_trainloop_world2_matches_mean_gradient_step(microbatch, deterministic, monkeypatch):
+    # deterministic = "1": the same job with LFVDM_DETERMINISTIC=1 (ordered slabs instead of float atomics) in both ranks
+    monkeypatch.setenv("LFVDM_DETERMINISTIC", deterministic)
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
