@@ -49,15 +49,16 @@ int lfvdm_abi_version(void);
 /* ---------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear on fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * Replaces nn.Conv2d 3x3 (unet.py:76,108,155,169,313,402), the 1x1 skip conv (unet.py:180),
- * nn.Linear qkv / proj_out (rpe.py:111-112,139,171) and — fused into the operand load — the
- * preceding GroupNorm32 + SiLU (+FiLM) (nn.py:12-19, unet.py:152-171,199-203), the nearest-2x
- * Upsample (unet.py:85-87), the skip concat (unet.py:460) and the residual add (unet.py:207,
- * rpe.py:172).
+ * nn.Linear qkv / proj_out (rpe.py:111-112,139,171) and - fused into the launch - the nearest-2x
+ * Upsample (unet.py:85-87), the skip concat (unet.py:460), the residual add (unet.py:207,
+ * rpe.py:172) and, in the epilogue, the NEXT GroupNorm32 (+FiLM)(+SiLU) (gn_* fields).
  *
- *   out[m][co] = bias[co] + sum_{tap,ci} f(src[n, iy, ix, ci]) * W[co][tap*Cin + ci]
+ *   out[m][co] = bias[co] + sum_{tap,ci} src[n, iy, ix, ci] * W[co][tap*Cin + ci]     (zero outside the padded image)
  *              (+ bias2[co] + sum_ci src2[m][ci] * W2[co][ci])            second segment
  *              (+ res[m][co] * resA[n][co] + resB[n][co])                 residual
- *   f(v) = act(v * coefA[n][ci] + coefB[n][ci]), zero outside the (padded) image.
+ * Operands are RAW: coefA / coefB / act (the GroupNorm affine + SiLU applied while staging, rounds 1-2) must be
+ * NULL / 0 for lfvdm_conv_igemm (LFVDM_E_UNSUPPORTED otherwise) - normalise with lfvdm_gn_apply or a producer's gn_*
+ * epilogue.  lfvdm_conv_wgrad still honours them (f(v) = act(v * coefA[n][ci] + coefB[n][ci])).
  * ------------------------------------------------------------------------------------- */
 typedef struct lfvdm_conv_args {
     /* main segment: virtual concat of src0 (C0 ch) and src1 (C1 ch, may be 0/NULL) */

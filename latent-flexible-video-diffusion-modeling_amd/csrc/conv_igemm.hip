@@ -1,18 +1,17 @@
 // Implicit-GEMM convolution / linear for gfx950 on fp32 MFMA (v_mfma_f32_32x32x2_f32).
 //
 // Workgroup = WK "k-groups" of WM x WN waves.  A k-group owns a contiguous slice of the K loop
-// (K = taps*Cin in 32-channel chunks, plus the optional fused 1x1 skip segment) and computes the
+// (K = taps*Cin in 32- or 64-channel chunks, plus the optional fused 1x1 skip segment) and computes the
 // whole (32*WM) x (32*NT*WN) block tile for that slice; the k-groups' partial tiles are summed
-// through LDS at the end.  Inside a k-group the A tile (output pixels x 32 channels of one filter
-// tap, gathered from the channels-last activation, GroupNorm/FiLM affine + SiLU applied on the
-// fly, zero outside the image) and the W tile are staged COOPERATIVELY by the group's threads
-// into a double-buffered LDS stage, so every operand byte fetched from L2 feeds WN (A) or WM (W)
-// waves.  Loads of chunk k+1 are issued (unconditionally, clamped + masked) before the MFMAs of
-// chunk k; one s_barrier per chunk.  The K loop runs channel-chunk-major / tap-minor so the
-// per-(sample,channel) GroupNorm coefficients are fetched once per channel chunk, not per tap.
-// LDS rows are padded to 36 floats: the ds_read_b128 fragment reads are conflict-free.
+// through LDS at the end.  Inside a k-group the A tile (output pixels x KC channels of one filter
+// tap, gathered from the channels-last RAW activation - GroupNorm / FiLM / SiLU are materialised by the
+// producer's epilogue or by lfvdm_gn_apply, never applied here) and the W tile are staged by LDS-DMA
+// (buffer_load ... lds) into 2 or 3 unpadded, XOR-swizzled stages: no VGPR staging, no ds_write, zero padding by
+// out-of-range offsets; one s_barrier per chunk.  The K loop runs channel-chunk-major / tap-minor.
+// (The register-staged loop with the GroupNorm prologue folded into the operand load - round 1, LFVDM_FUSED_GN in
+// round 2 - was measured 15-30 % slower and is gone: DESIGN.md section 5.)
 //
-// MFMA operand mapping (cdna guide §3): A lane l holds A[i=l&31][k=l>>5], B lane l holds
+// MFMA operand mapping (cdna guide section 3): A lane l holds A[i=l&31][k=l>>5], B lane l holds
 // B[k=l>>5][j=l&31]; within a group of 8 k the e-th MFMA uses k = 8g + 4h + e on both operands.
 // D: lane l holds column j=l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r=0..15.
 #include <stdlib.h>
@@ -39,24 +38,22 @@ extern "C" int lfvdm_debug_stamps_clear(void) {
 
 namespace {
 
-// KCH = channels per K chunk (32 or 64; 64 halves the barriers / staging overhead per MFMA)
-// GL  = 0: operand tiles staged through registers into a padded, double-buffered LDS image;
-//       2/3: tiles written by LDS-DMA (buffer_load ... lds) into GL unpadded, XOR-swizzled stages (see the kernel)
-template <int WM, int WN, int WK, int NT, int KCH, int GL = 0>
+// KCH = channels per K chunk (32 or 64; 64 halves the barriers per MFMA and the chunks a short K slice needs);
+// GL = number of LDS-DMA stages (2 or 3): tiles are written by buffer_load ... lds into GL unpadded, XOR-swizzled stages
+template <int WM, int WN, int WK, int NT, int KCH, int GL>
 struct Cfg {
     static constexpr int KC = KCH;
-    static constexpr int LDR = GL ? KCH : KCH + 4;       // LDS row (floats); padded rows: conflict-free b128 reads
+    static constexpr int LDR = KCH;                      // LDS row (floats): unpadded, XOR-swizzled 16-byte slots
     static constexpr int QPR = KCH / 4;                  // float4 per row
     static constexpr int RSH = KCH == 64 ? 4 : 3;        // log2(QPR)
     static constexpr int BM = 32 * WM;
     static constexpr int BN = 32 * NT * WN;
     static constexpr int GT = 64 * WM * WN;              // threads per k-group
     static constexpr int NTHREADS = GT * WK;
-    static constexpr int AE = (BM * QPR) / GT;           // float4 A elements per thread per chunk
-    static constexpr int WE = (BN * QPR) / GT;           // float4 W elements per thread per chunk
+    static constexpr int AE = (BM * QPR) / GT;           // 1 KiB pieces of the A tile per wave and chunk
+    static constexpr int WE = (BN * QPR) / GT;           // ... of the W tile
     static constexpr int STAGE = (BM + BN) * LDR;        // floats per LDS stage
-    static constexpr int NSTAGE = GL ? GL : 2;
-    static constexpr int GROUP_LDS = NSTAGE * STAGE;
+    static constexpr int GROUP_LDS = GL * STAGE;
     static constexpr size_t LDS_BYTES = (size_t)WK * GROUP_LDS * sizeof(float);
     static_assert((BM * QPR) % GT == 0 && (BN * QPR) % GT == 0, "tile must divide over the group");
 };
@@ -101,149 +98,11 @@ __device__ __forceinline__ int div_small(int a, int d) {
     return fast_div(a, d, __builtin_amdgcn_rcpf((float)d));
 }
 
-template <int AE, int WE>
-struct ChunkRegs {
-    f32x4 a[AE];
-    f32x4 w[WE];
-    // GroupNorm/FiLM coefficients: loaded WITH the first chunk of a channel chunk so that they sit in front
-    // of younger prefetches in the in-order vmcnt queue.  Only when the thread stages <= 2 A rows (register
-    // budget); otherwise they are fetched when the chunk is written to LDS (once per 9 taps).
-    static constexpr bool COEF_PREFETCH = AE <= 2;
-    f32x4 ca[COEF_PREFETCH ? AE : 1], cb[COEF_PREFETCH ? AE : 1];
-    unsigned amask;
-    int coef_cc;            // >= 0: first chunk of a channel chunk -> (re)load the GroupNorm/FiLM coefficients
-    bool main_seg;
-};
-
-// Issue the global loads of K chunk `kc` (branch-free: every address is clamped to a valid one and
-// the parts that must not contribute are masked when the chunk is written to LDS).  `live` is false
-// for the padding iterations of k-groups that own fewer chunks than the others.  All per-lane
-// address arithmetic is 32-bit (element offsets < 2^31 is checked by the launcher); the chunk
-// parameters are wave-uniform and live in SGPRs.
-// SIMPLE = plain convolution (no fused skip segment, no upsampling, no GroupNorm coefficients): every wave-uniform
-// branch disappears, the whole body is one basic block that the scheduler can interleave with the MFMAs of the
-// chunk in flight (scalar address arithmetic and loads issue in the shadow of the matrix instructions).
-template <class CF, bool SIMPLE = false>
-__device__ __forceinline__ void issue_chunk(const lfvdm_conv_args& p, int kc, bool live, int kfirst, int NK1, int taps,
-                                            int Cin, const RowInfo (&ri)[CF::AE], const int (&wrow)[CF::WE], int col,
-                                            ChunkRegs<CF::AE, CF::WE>& R) {
-    const bool main_seg = SIMPLE ? true : kc < NK1;
-    // ---- wave-uniform chunk parameters (scalar selects, no divergent code) ----
-    // (sel() takes its operands by value: a plain `c ? p.a : p.b` is an lvalue select, i.e. a load from
-    // a selected ADDRESS, which pins the whole argument struct in scratch memory)
-    const int kk = main_seg ? kc : kc - NK1;
-    const int ci = main_seg ? kk / taps : kk;
-    const int tap = main_seg ? kk - ci * taps : 0;
-    const int cc = ci * CF::KC;
-    const int dy = (main_seg && p.ksize == 3) ? tap / 3 - 1 : 0;
-    const int dx = (main_seg && p.ksize == 3) ? tap - (tap / 3) * 3 - 1 : 0;
-    const int c0 = sel(main_seg, p.C0, p.s2C0);
-    const bool second = cc >= c0;
-    const float* src = sel(main_seg, sel(second, p.src1, p.src0), sel(second, p.s2src1, p.s2src0));
-    const int Csrc = sel(main_seg, sel(second, p.C1, p.C0), sel(second, p.s2C1, p.s2C0));
-    const int cl = second ? cc - c0 : cc;
-    const int upmode = SIMPLE ? 0 : sel(main_seg, p.up, 0);   // 0 none, 1 nearest x2, 2 zero-insertion x2 (transposed conv)
-    const int up = upmode ? 1 : 0;
-    const int stride = sel(main_seg, p.stride, 1);
-    const int Hst = sel(main_seg, p.Hs, p.Ho);      // stored source extent
-    const int Wst = sel(main_seg, p.Ws, p.Wo);
-    const int Hin = Hst << up;
-    const int Win = Wst << up;
-    const float* wbase = sel(main_seg, p.W + (tap * Cin + cc), p.W2 + cc);
-    const int wld = sel(main_seg, taps * Cin, p.s2C0 + p.s2C1);
-
-    R.main_seg = main_seg;
-    R.coef_cc = (!SIMPLE && p.coefA && main_seg && live && (tap == 0 || kc == kfirst)) ? cc : -1;
-    if (!SIMPLE && ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH && R.coef_cc >= 0) {   // wave-uniform
-#pragma unroll
-        for (int j = 0; j < CF::AE; ++j) {
-            R.ca[j < (ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH ? CF::AE : 1) ? j : 0] = ld4(p.coefA + (unsigned)(ri[j].n * Cin + cc + col));
-            R.cb[j < (ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH ? CF::AE : 1) ? j : 0] = ld4(p.coefB + (unsigned)(ri[j].n * Cin + cc + col));
-        }
-    }
-    unsigned am = 0;
-    const float* srcc = src + cl + col;
-    if (!SIMPLE && !main_seg) {
-        // fused 1x1 skip segment: row m of a raw source at output resolution
-#pragma unroll
-        for (int j = 0; j < CF::AE; ++j) {
-            am |= ((live && ri[j].valid) ? 1u : 0u) << j;
-            R.a[j] = ld4(srcc + (unsigned)__mul24(ri[j].m, Csrc));
-        }
-    } else if (SIMPLE || !up) {
-        // common case: the tap is a wave-uniform pixel offset from the precomputed centre pixel
-        const int tappix = dy * Wst + dx;
-#pragma unroll
-        for (int j = 0; j < CF::AE; ++j) {
-            const bool inb = live && ((ri[j].taps >> tap) & 1u);
-            am |= (inb ? 1u : 0u) << j;
-            const int px = inb ? ri[j].pix + tappix : ri[j].pix;
-            R.a[j] = ld4(srcc + (unsigned)__mul24(px, Csrc));
-        }
-    } else {
-        // nearest-2x upsampled source (3 launches per forward): general clamp-and-shift addressing
-#pragma unroll
-        for (int j = 0; j < CF::AE; ++j) {
-            const RowInfo& q = ri[j];
-            const int iy = q.oy * stride + dy;
-            const int ix = q.ox * stride + dx;
-            bool inb = live && q.valid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-            if (upmode == 2) inb = inb && (((iy | ix) & 1) == 0);   // only the even grid carries data
-            am |= (inb ? 1u : 0u) << j;
-            const int sy = min(max(iy, 0), Hin - 1) >> 1;
-            const int sx = min(max(ix, 0), Win - 1) >> 1;
-            R.a[j] = ld4(srcc + (unsigned)(((q.n * Hst + sy) * Wst + sx) * Csrc));
-        }
-    }
-    R.amask = am;
-#pragma unroll
-    for (int j = 0; j < CF::WE; ++j) R.w[j] = ld4(wbase + col + (unsigned)__mul24(wrow[j], wld));
-}
-
-// PRO: 0 = raw operand, 1 = affine (GroupNorm coefficients), 2 = affine + SiLU
-template <class CF, int PRO>
-__device__ __forceinline__ void finish_chunk(const lfvdm_conv_args& p, ChunkRegs<CF::AE, CF::WE>& R,
-                                             f32x4 (&ca)[CF::AE], f32x4 (&cb)[CF::AE], unsigned wmask,
-                                             const RowInfo (&ri)[CF::AE], int Cin, float* As, float* Ws, int gt) {
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const int col = (gt & (CF::QPR - 1)) * 4;
-    if (PRO > 0 && R.coef_cc >= 0) {   // once per channel chunk (the 9 taps share it)
-        if constexpr (ChunkRegs<CF::AE, CF::WE>::COEF_PREFETCH) {
-#pragma unroll
-            for (int j = 0; j < CF::AE; ++j) { ca[j] = R.ca[j]; cb[j] = R.cb[j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < CF::AE; ++j) {
-                ca[j] = ld4(p.coefA + (unsigned)(ri[j].n * Cin + R.coef_cc + col));
-                cb[j] = ld4(p.coefB + (unsigned)(ri[j].n * Cin + R.coef_cc + col));
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < CF::WE; ++j)
-        st4(Ws + ((gt + j * CF::GT) >> CF::RSH) * CF::LDR + col, ((wmask >> j) & 1u) ? R.w[j] : zero);
-#pragma unroll
-    for (int j = 0; j < CF::AE; ++j) {
-        f32x4 v = R.a[j];
-        if (PRO > 0) {
-            const f32x4 t = v * ca[j] + cb[j];
-            v = R.main_seg ? t : v;
-        }
-        if (PRO > 1) {
-            f32x4 t;
-            t.x = silu_f(v.x); t.y = silu_f(v.y); t.z = silu_f(v.z); t.w = silu_f(v.w);
-            v = R.main_seg ? t : v;
-        }
-        v = ((R.amask >> j) & 1u) ? v : zero;
-        st4(As + ((gt + j * CF::GT) >> CF::RSH) * CF::LDR + col, v);
-    }
-}
-
-template <int WM, int WN, int WK, int NT, int KCH, int PRO, bool SIMPLE, int GL = 0>
+template <int WM, int WN, int WK, int NT, int KCH, bool SIMPLE, int GL>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfvdm_conv_args p_in, int hyb_nfull, int hyb_kz) {
     const lfvdm_conv_args p = p_in;   // private SSA copy: helpers take it by reference (keeps it out of scratch)
     using CF = Cfg<WM, WN, WK, NT, KCH, GL>;
-    static_assert(GL == 0 || PRO == 0, "LDS-DMA staging carries raw operands only");
+    static_assert(GL == 2 || GL == 3, "two or three LDS-DMA stages");
     constexpr int BM = CF::BM, BN = CF::BN, KC = CF::KC, LDR = CF::LDR;
     constexpr int RED_LD = BN + 1;
     static_assert(BM * RED_LD <= CF::GROUP_LDS, "reduction tile must fit the group's stages");
@@ -308,7 +167,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     const int kbeg = zbeg + (int)((unsigned)(NKz * wk) / (unsigned)WK);
     const int kend = zbeg + (int)((unsigned)(NKz * (wk + 1)) / (unsigned)WK);
     const int iters_g = (int)((unsigned)(zmax + WK - 1) / (unsigned)WK);
-    const int iters = (iters_g + 1) & ~1;              // even: the register-staged loop is unrolled by two
 
     RowInfo ri[CF::AE];
     auto decode_rows = [&]() {
@@ -354,7 +212,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  if constexpr (GL > 0) {
+  {
     // ---- LDS-DMA main loop.  `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 B to ONE contiguous 1 KiB piece
     // of LDS (wave-uniform base + lane * 16) while every lane supplies its own source offset.  The stage image is
     // therefore the plain row-major [rows][KC] tile (a piece = 64 / QPR rows), no VGPR staging, no ds_write, no
@@ -540,73 +398,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     }
 #undef LFVDM_GSTEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the zero-filled look-ahead pieces must land before the stages are reused
-  } else {
-    // Two chunks are kept in flight in registers (R0, R1): the loads of chunk k+2 are issued before the
-    // MFMAs of chunk k, so a load has two compute phases (~2 x 1024 MFMA cycles) to come back.
-    decode_rows();
-    ChunkRegs<CF::AE, CF::WE> R0, R1;
-    f32x4 ca[CF::AE], cb[CF::AE];
-#pragma unroll
-    for (int j = 0; j < CF::AE; ++j) { ca[j] = (f32x4){1.f, 1.f, 1.f, 1.f}; cb[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const int klast = max(kend - 1, 0);
-    issue_chunk<CF, SIMPLE>(p, min(kbeg, klast), kbeg < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R0);
-    issue_chunk<CF, SIMPLE>(p, min(kbeg + 1, klast), kbeg + 1 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R1);
-
-    STAMP(1);
-    const int fra = (32 * wm + (lane & 31)) * LDR + (lane >> 5) * 4;                    // A fragment offset
-    const int frw = (BM + 32 * NT * wn + (lane & 31)) * LDR + (lane >> 5) * 4;          // W fragment offset
-
-#define LFVDM_FINISH(ST_, R_) finish_chunk<CF, PRO>(p, R_, ca, cb, wmask, ri, Cin, (ST_), (ST_) + BM * LDR, gt)
-#define LFVDM_ISSUE(KC_, R_) \
-    issue_chunk<CF, SIMPLE>(p, min((KC_) + 2, klast), (KC_) + 2 < kend, kbeg, NK1, taps, Cin, ri, wrow, col, R_)
-#define LFVDM_MFMA(ST_)                                                                                        \
-    do {                                                                                                       \
-        const float* st_ = (ST_);                                                                              \
-        _Pragma("unroll") for (int g = 0; g < KC / 8; ++g) {                                                   \
-            const f32x4 a4 = ld4(st_ + fra + g * 8);                                                           \
-            f32x4 b4[NT];                                                                                      \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) b4[t] = ld4(st_ + frw + t * 32 * LDR + g * 8);      \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                      \
-                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                 \
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[t][e], acc[t], 0, 0, 0);           \
-        }                                                                                                      \
-    } while (0)
-    // Two barriers per chunk.  In an 8-wave workgroup every SIMD holds one wave of the first half (waves
-    // 0-3) and one of the second half (4-7); the halves run the loop half a period apart ("ping-pong"):
-    // while one half issues its 16*NT*(KC/32) MFMAs the other half does its VALU/LDS staging work, so the
-    // matrix pipe and the vector pipe of a SIMD overlap instead of alternating.  A k-group always lies
-    // inside one half, and its LDS write (finish) and read (MFMA) phases are separated by a barrier.
-    const bool late_half = (CF::NTHREADS == 512) && wave >= 4;
-    if (!late_half) {
-        for (int it = 0; it < iters; it += 2) {
-            LFVDM_FINISH(gbase, R0);
-            __syncthreads();
-            LFVDM_ISSUE(kbeg + it, R0);
-            LFVDM_MFMA(gbase);
-            __syncthreads();
-            LFVDM_FINISH(gbase + CF::STAGE, R1);
-            __syncthreads();
-            LFVDM_ISSUE(kbeg + it + 1, R1);
-            LFVDM_MFMA(gbase + CF::STAGE);
-            __syncthreads();
-        }
-    } else {
-        for (int it = 0; it < iters; it += 2) {
-            __syncthreads();
-            LFVDM_FINISH(gbase, R0);
-            LFVDM_ISSUE(kbeg + it, R0);
-            __syncthreads();
-            LFVDM_MFMA(gbase);
-            __syncthreads();
-            LFVDM_FINISH(gbase + CF::STAGE, R1);
-            LFVDM_ISSUE(kbeg + it + 1, R1);
-            __syncthreads();
-            LFVDM_MFMA(gbase + CF::STAGE);
-        }
-    }
-#undef LFVDM_FINISH
-#undef LFVDM_ISSUE
-#undef LFVDM_MFMA
   }
     STAMP(2);
     lds_barrier();   // all fragment reads done before the stages are reused for the reduction
@@ -909,67 +700,58 @@ inline HybridPlan hybrid_plan(long tiles) {
     return h;
 }
 
-template <int WM, int WN, int WK, int NT, int KCH, int PRO, bool SIMPLE, int GL = 0>
+template <int WM, int WN, int WK, int NT, int KCH, bool SIMPLE, int GL>
 int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
     using CF = Cfg<WM, WN, WK, NT, KCH, GL>;
     if (CF::LDS_BYTES > 160 * 1024) return LFVDM_E_UNSUPPORTED;
     static DynLdsLimit limit;
-    if (int rc = limit.ensure(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE, GL>),
-                              CF::LDS_BYTES))
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), CF::LDS_BYTES))
         return rc;
     const long MT = (M + CF::BM - 1) / CF::BM, NT2 = (a->Cout + CF::BN - 1) / CF::BN;
     if (kz == kHybridKz) {   // tail split (see the kernel): flat grid
         const HybridPlan h = hybrid_plan(MT * NT2);
-        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE, GL>), dim3((unsigned)(h.nfull + h.tail * h.kz)),
+        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), dim3((unsigned)(h.nfull + h.tail * h.kz)),
                            dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, (int)h.nfull, h.kz);
         LFVDM_CHECK_LAUNCH();
         return LFVDM_OK;
     }
     const dim3 grid((unsigned)MT, (unsigned)NT2, (unsigned)kz);
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, PRO, SIMPLE, GL>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
 
-// LDS bytes of the LDS-DMA variant with `gl` unpadded stages
+// LDS bytes of a configuration with `gl` stages
 constexpr long glds_lds_bytes(int WM, int WN, int WK, int NT, int kch, int gl) {
     return (long)WK * gl * (32 * WM + 32 * NT * WN) * kch * 4;
 }
 
-// may this launch use the LDS-DMA variant?  Raw operands (no GroupNorm prologue), no upsampling; every tensor it
-// stages must be addressable with 32-bit byte offsets below kOOB (2^30).
+// every tensor a launch stages must be addressable with 32-bit byte offsets below kOOB (2^30); larger batches are
+// cut into sample ranges by lfvdm_conv_igemm
 inline bool glds_ok(const lfvdm_conv_args* a) {
     const long Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1, lim = 1L << 30;
     const long Cmax = a->C0 > a->C1 ? a->C0 : a->C1, C2max = a->s2C0 > a->s2C1 ? a->s2C0 : a->s2C1;
-    return !a->coefA && (long)a->N * a->Hs * a->Ws * Cmax * 4 < lim &&
-           (long)a->N * a->Ho * a->Wo * C2max * 4 < lim && (long)a->Cout * a->ksize * a->ksize * Cin * 4 < lim &&
-           (long)a->Cout * C2 * 4 < lim;
+    return (long)a->N * a->Hs * a->Ws * Cmax * 4 < lim && (long)a->N * a->Ho * a->Wo * C2max * 4 < lim &&
+           (long)a->Cout * a->ksize * a->ksize * Cin * 4 < lim && (long)a->Cout * C2 * 4 < lim;
 }
 
 template <int WM, int WN, int WK, int NT, int KCH>
 int launch_kc(const lfvdm_conv_args* a, hipStream_t s, long M, int kz, int gl) {
-    if (gl && glds_ok(a)) {
-        const bool simple = a->C1 == 0 && a->s2C0 + a->s2C1 == 0 && a->up == 0;
-        if constexpr (glds_lds_bytes(WM, WN, WK, NT, KCH, 3) <= 160 * 1024) {
-            if (gl == 3) return simple ? launch_pro<WM, WN, WK, NT, KCH, 0, true, 3>(a, s, M, kz)
-                                       : launch_pro<WM, WN, WK, NT, KCH, 0, false, 3>(a, s, M, kz);
-        }
-        if constexpr (glds_lds_bytes(WM, WN, WK, NT, KCH, 2) <= 160 * 1024) {
-            return simple ? launch_pro<WM, WN, WK, NT, KCH, 0, true, 2>(a, s, M, kz)
-                          : launch_pro<WM, WN, WK, NT, KCH, 0, false, 2>(a, s, M, kz);
-        }
+    const bool simple = a->C1 == 0 && a->s2C0 + a->s2C1 == 0 && a->up == 0;
+    if constexpr (glds_lds_bytes(WM, WN, WK, NT, KCH, 3) <= 160 * 1024) {
+        if (gl == 3) return simple ? launch_pro<WM, WN, WK, NT, KCH, true, 3>(a, s, M, kz)
+                                   : launch_pro<WM, WN, WK, NT, KCH, false, 3>(a, s, M, kz);
     }
-    if (!a->coefA) {
-        if (a->up == 0 && a->s2C0 + a->s2C1 == 0) return launch_pro<WM, WN, WK, NT, KCH, 0, true>(a, s, M, kz);
-        return launch_pro<WM, WN, WK, NT, KCH, 0, false>(a, s, M, kz);
+    if constexpr (glds_lds_bytes(WM, WN, WK, NT, KCH, 2) <= 160 * 1024) {
+        return simple ? launch_pro<WM, WN, WK, NT, KCH, true, 2>(a, s, M, kz)
+                      : launch_pro<WM, WN, WK, NT, KCH, false, 2>(a, s, M, kz);
     }
-    if (a->act == LFVDM_ACT_SILU) return launch_pro<WM, WN, WK, NT, KCH, 2, false>(a, s, M, kz);
-    return launch_pro<WM, WN, WK, NT, KCH, 1, false>(a, s, M, kz);
+    return LFVDM_E_UNSUPPORTED;
 }
 
 template <int WM, int WN, int WK, int NT>
 int launch_cfg(const lfvdm_conv_args* a, hipStream_t s, long M, int kch, int kz, int gl) {
-    if constexpr (WM * WN >= 4 && NT == 1) {   // 64-channel chunks need a 256-thread k-group (register budget)
+    if constexpr (NT == 1) {   // 64-channel chunks: single-filter-tile configurations
         if (kch == 64) return launch_kc<WM, WN, WK, NT, 64>(a, s, M, kz, gl);
     }
     return launch_kc<WM, WN, WK, NT, 32>(a, s, M, kz, gl);
@@ -990,11 +772,11 @@ constexpr TileCfg kCfgs[] = {
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 // Modelled makespan (cycles) of one launch: 256 CUs x 4 SIMDs, 64 cycles per 32x32x2 MFMA, one barrier
-// per 32-channel chunk, loads prefetched two chunks ahead.
+// per chunk.  Only the starting point: every launch shape is timed over its legal variants on first sight.
 double model_cycles(const TileCfg& c, int Cout, long M, int NK, int kch, int kz) {
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
     const int waves = c.WM * c.WN * c.WK;
-    const double lds = (double)c.WK * 2.0 * (BM + BN) * (kch + 4) * 4.0;
+    const double lds = (double)c.WK * 2.0 * (BM + BN) * kch * 4.0;
     int resident = (int)(160.0 * 1024.0 / lds);
     const int by_vgpr = (c.vgpr_waves * 4) / waves;
     if (by_vgpr < resident) resident = by_vgpr;
@@ -1013,46 +795,37 @@ double model_cycles(const TileCfg& c, int Cout, long M, int NK, int kch, int kz)
     return (double)rounds * (chunks * per_iter + 3500.0 + 900.0 + 250.0 * c.WK) + (kz > 1 ? 2500.0 : 0.0);
 }
 
-// Joint choice of tile configuration and K chunk width (64-channel chunks only when every channel
-// count involved is a multiple of 64 and the k-group has 256 threads).
 struct Pick { int id, kch, NK, kz, gl; };
 
-// tune code (lfvdm_conv_args::tune): 0 = heuristic, else 1 + id + 16*(kch == 64) + 32*log2(kz) + 256*g
-// (g = 0 register staging, 1 / 2 = LDS-DMA with 2 / 3 stages)
-inline int encode_tune(int id, int kch, int kz, int gl = 0) {
+// tune code (lfvdm_conv_args::tune): 0 = heuristic, else 1 + id + 16*(kch == 64) + 32*log2(kz) + 256*(gl - 1), gl = 2 / 3
+// LDS-DMA stages (codes without the stage field belong to the register-staged loop of earlier library versions: ignored)
+inline int encode_tune(int id, int kch, int kz, int gl) {
     int l = 0;
     while ((1 << l) < kz) ++l;
-    return 1 + id + 16 * (kch == 64 ? 1 : 0) + 32 * l + 256 * (gl ? gl - 1 : 0);
-}
-bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz);
-// is the LDS-DMA variant with `gl` stages legal for (id, kch, kz)?
-bool glds_valid(const lfvdm_conv_args* a, int id, int kch, int kz, int gl) {
-    if (gl != 2 && gl != 3) return false;
-    if (!cfg_valid(a, id, kch, kz) || !glds_ok(a)) return false;
-    const TileCfg c = kCfgs[id];
-    return glds_lds_bytes(c.WM, c.WN, c.WK, c.NT, kch, gl) <= 160 * 1024;
+    return 1 + id + 16 * (kch == 64 ? 1 : 0) + 32 * l + 256 * (gl - 1);
 }
 // fused output GroupNorm: the tile must hold whole samples and whole groups, and the unit statistics must fit
-// behind the reduction tile in the first k-group's LDS (checked against the smallest stage layout: 2 unpadded stages)
+// behind the reduction tile in the first k-group's LDS (checked against the smallest stage layout: 2 stages of 32 channels)
 inline bool gn_tile_ok(const lfvdm_conv_args* a, int BM, int BN) {
     const int P = a->Ho * a->Wo, gw = a->Cout / 32;
     if (a->Cout % 32 || a->out_mode != LFVDM_OUT_ROWS || P <= 0 || BM % P || gw <= 0 || BN % gw || a->Cout % 4) return false;
     const int U = (BM / P) * (BN / gw);
     return BM * (BN + 1) + 2 * U <= 2 * (BM + BN) * 32;
 }
-// is (id, kch, kz) a legal configuration for these arguments?
-bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz) {
+// is (tile id, chunk width, split-K, stages) a legal configuration for these arguments?
+bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz, int gl) {
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
     if (id < 0 || id >= kNumCfgs || id == 7 || (kch != 32 && kch != 64) || kz < 1 || (kz > 8 && kz != kHybridKz)) return false;
+    if (gl != 2 && gl != 3) return false;
     const TileCfg c = kCfgs[id];
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
     if (a->Cout <= 32 && BN > 32) return false;
     if (a->gn_out && !gn_tile_ok(a, BM, BN)) return false;
     const bool can64 = Cin % 64 == 0 && a->C0 % 64 == 0 && C2 % 64 == 0 && a->s2C0 % 64 == 0;
-    if (kch == 64 && (!can64 || c.WM * c.WN < 4 || c.NT > 1)) return false;
+    if (kch == 64 && (!can64 || c.NT > 1)) return false;
     const int NK = a->ksize * a->ksize * (Cin / kch) + C2 / kch;
     if (c.WK > NK) return false;
-    if ((double)c.WK * 2.0 * (BM + BN) * (kch + 4) * 4.0 > 160.0 * 1024.0) return false;
+    if (glds_lds_bytes(c.WM, c.WN, c.WK, c.NT, kch, gl) > 160 * 1024) return false;
     // split-K over workgroups needs the caller's workspace (slabs + tile tickets) and the rows layout
     if (kz > 1) {
         if (!a->splitk_ws || !a->splitk_cnt || a->out_mode != LFVDM_OUT_ROWS) return false;
@@ -1074,48 +847,43 @@ Pick pick_cfg(const lfvdm_conv_args* a, long M) {
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
     if (a->tune > 0) {   // explicit choice (autotuner); fall through to the model if it is not legal here
         const int t = a->tune - 1;
-        const int id = t & 15, kch = (t & 16) ? 64 : 32, kz = 1 << ((t >> 5) & 7), g = (t >> 8) & 3;
-        const int gl = g ? g + 1 : 0;
-        if (gl ? glds_valid(a, id, kch, kz, gl) : cfg_valid(a, id, kch, kz))
-            return {id, kch, a->ksize * a->ksize * (Cin / kch) + C2 / kch, kz, gl};
+        const int id = t & 15, kch = (t & 16) ? 64 : 32, kz = 1 << ((t >> 5) & 7), gl = ((t >> 8) & 3) + 1;
+        if (cfg_valid(a, id, kch, kz, gl)) return {id, kch, a->ksize * a->ksize * (Cin / kch) + C2 / kch, kz, gl};
     }
-    const bool can64 = !getenv("LFVDM_CONV_KC32") && Cin % 64 == 0 && a->C0 % 64 == 0 && C2 % 64 == 0 && a->s2C0 % 64 == 0;
     static const int forced = getenv("LFVDM_CONV_CFG") ? atoi(getenv("LFVDM_CONV_CFG")) : -1;  // tuning aid
-    static const int forced_kz = getenv("LFVDM_CONV_KZ") ? atoi(getenv("LFVDM_CONV_KZ")) : -1;
-    const bool can_split = false;   // the built-in model never splits K over workgroups (see cfg_valid)
-    Pick best = {-1, 32, a->ksize * a->ksize * (Cin / 32) + C2 / 32, 1, 0};
+    Pick best = {-1, 32, a->ksize * a->ksize * (Cin / 32) + C2 / 32, 1, 2};
     double best_t = 1e30;
     for (int i = 0; i < kNumCfgs; ++i) {
-        const TileCfg c = kCfgs[i];
         if (forced >= 0 && i != forced) continue;
-        if (i == 7) continue;   // 64x128 with two k-groups exceeds the register budget (spills): not offered
-        const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
-        if (a->Cout <= 32 && BN > 32) continue;
-        if (a->gn_out && !gn_tile_ok(a, BM, BN)) continue;
         for (int kch = 32; kch <= 64; kch += 32) {
-            if (kch == 64 && (!can64 || c.WM * c.WN < 4 || c.NT > 1)) continue;
+            if (!cfg_valid(a, i, kch, 1, 2)) continue;          // the built-in model never splits K over workgroups
             const int NK = a->ksize * a->ksize * (Cin / kch) + C2 / kch;
-            if (c.WK > NK) continue;
-            if ((double)c.WK * 2.0 * (BM + BN) * (kch + 4) * 4.0 > 160.0 * 1024.0) continue;   // LDS budget
-            for (int kz = 1; kz <= 8; kz *= 2) {
-                if (kz > 1 && (!can_split || NK < 2 * kz * c.WK)) continue;
-                if (forced_kz > 0 && kz != forced_kz && !(kz == 1 && (!can_split || NK < 2 * forced_kz * c.WK))) continue;
-                const double est = model_cycles(c, a->Cout, M, NK, kch, kz);
-                if (est < best_t) { best_t = est; best = {i, kch, NK, kz, 0}; }
-            }
+            const double est = model_cycles(kCfgs[i], a->Cout, M, NK, kch, 1);
+            if (est < best_t) { best_t = est; best = {i, kch, NK, 1, 2}; }
         }
     }
-    if (best.id < 0) {
-        if (a->gn_out) return best;     // no tile holds whole samples and groups: the launch is refused
-        best.id = 0;                    // nothing passed the filters (tiny K with a narrow output): the 64x64 tile always works
-    }
-    // plain convolutions default to the LDS-DMA loop (faster on every measured shape, tools/conv_glds_compare.sh)
-    static const bool no_glds = getenv("LFVDM_CONV_NO_GLDS") != nullptr;
-    if (!no_glds && glds_valid(a, best.id, best.kch, best.kz, 2)) best.gl = 2;
+    if (best.id < 0 && !a->gn_out) best.id = 0;   // nothing passed the filters (tiny K with a narrow output): the 64x64 tile always
+                                                  // works; with a fused GroupNorm no tile holds whole samples and groups: refused
     return best;
 }
 
 }  // namespace
+
+static int conv_igemm_one(const lfvdm_conv_args* a, hipStream_t s) {
+    const long M = (long)a->N * a->Ho * a->Wo;
+    const Pick pk = pick_cfg(a, M);
+    const int kch = pk.kch, kz = pk.kz, gl = pk.gl;
+    switch (pk.id) {
+        case 0: return launch_cfg<2, 2, 1, 1>(a, s, M, kch, kz, gl);
+        case 1: return launch_cfg<2, 2, 1, 2>(a, s, M, kch, kz, gl);
+        case 2: return launch_cfg<1, 2, 2, 1>(a, s, M, kch, kz, gl);
+        case 3: return launch_cfg<1, 2, 4, 1>(a, s, M, kch, kz, gl);
+        case 4: return launch_cfg<1, 1, 8, 1>(a, s, M, kch, kz, gl);
+        case 5: return launch_cfg<2, 2, 2, 1>(a, s, M, kch, kz, gl);
+        case 6: return launch_cfg<1, 1, 4, 1>(a, s, M, kch, kz, gl);
+    }
+    return LFVDM_E_UNSUPPORTED;
+}
 
 extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -1127,7 +895,9 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     if (a->stride != 1 && a->stride != 2) return LFVDM_E_SHAPE;
     if (a->C1 > 0 && !a->src1) return LFVDM_E_SHAPE;
     if (C2 > 0 && (!a->W2 || !a->s2src0 || (a->s2C1 > 0 && !a->s2src1))) return LFVDM_E_SHAPE;
-    if ((a->coefA == nullptr) != (a->coefB == nullptr)) return LFVDM_E_SHAPE;
+    // the operand prologue (GroupNorm coefficients applied while staging) is gone: normalise with lfvdm_gn_apply or a
+    // producer's gn_* epilogue and pass the raw tensor
+    if (a->coefA || a->coefB) return LFVDM_E_UNSUPPORTED;
     if (a->out_mode == LFVDM_OUT_ROWS && (a->Cout % 4 || a->ldo % 4 || (a->res && a->ldr % 4))) return LFVDM_E_SHAPE;
     {   // output size must agree with the conv arithmetic the kernel assumes
         const int Hin = a->up ? 2 * a->Hs : a->Hs, Win = a->up ? 2 * a->Ws : a->Ws;
@@ -1135,27 +905,40 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
         if ((Hin + 2 * pad - a->ksize) / a->stride + 1 != a->Ho) return LFVDM_E_SHAPE;
         if ((Win + 2 * pad - a->ksize) / a->stride + 1 != a->Wo) return LFVDM_E_SHAPE;
     }
-    const long M = (long)a->N * a->Ho * a->Wo;
-    // the kernel's per-lane address arithmetic is 32-bit (element offsets)
-    if ((long)a->N * a->Hs * a->Ws * (a->C0 > a->C1 ? a->C0 : a->C1) >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
-    if (M * (long)(C2 > a->Cout ? C2 : a->Cout) >= (1L << 31) || (long)a->N * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
-    if ((long)a->Cout * a->ksize * a->ksize * Cin >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
+    if ((long)a->Cout * a->ksize * a->ksize * Cin >= (1L << 28) || (long)a->Cout * C2 >= (1L << 28)) return LFVDM_E_UNSUPPORTED;
     if (9L * Cin + C2 >= (1L << 20)) return LFVDM_E_UNSUPPORTED;     // K-slice arithmetic of the kernel: NK * KZ < 2^21
     if (a->gn_out && (!a->gn_gamma || !a->gn_beta || a->gn_film_div <= 0 || (a->gn_film && a->gn_film_ld < 2 * a->Cout)))
         return LFVDM_E_SHAPE;
-    const Pick pk = pick_cfg(a, M);
-    const int kch = pk.kch, kz = pk.kz, gl = pk.gl;
-    switch (pk.id) {
-        case 0: return launch_cfg<2, 2, 1, 1>(a, s, M, kch, kz, gl);
-        case 1: return launch_cfg<2, 2, 1, 2>(a, s, M, kch, kz, gl);
-        case 2: return launch_cfg<1, 2, 2, 1>(a, s, M, kch, kz, gl);
-        case 3: return launch_cfg<1, 2, 4, 1>(a, s, M, kch, kz, gl);
-        case 4: return launch_cfg<1, 1, 8, 1>(a, s, M, kch, kz, gl);
-        case 5: return launch_cfg<2, 2, 2, 1>(a, s, M, kch, kz, gl);
-        case 6: return launch_cfg<1, 1, 4, 1>(a, s, M, kch, kz, gl);
-        case 7: return launch_cfg<2, 2, 2, 2>(a, s, M, kch, kz, gl);
+    if (glds_ok(a)) return conv_igemm_one(a, s);
+    // Per-lane byte offsets are 32-bit and end below 2^30: a batch whose tensors exceed that (pixel space at large
+    // batch) is processed in sample ranges - samples are independent in every operand and in the fused GroupNorm; the
+    // FiLM rows of the epilogue are indexed by sample / gn_film_div, so ranges start at multiples of it.
+    const long Cmax = a->C0 > a->C1 ? a->C0 : a->C1, C2max = a->s2C0 > a->s2C1 ? a->s2C0 : a->s2C1;
+    long per = (long)a->Hs * a->Ws * Cmax * 4;
+    if ((long)a->Ho * a->Wo * C2max * 4 > per) per = (long)a->Ho * a->Wo * C2max * 4;
+    long nmax = ((1L << 30) - 1) / per;
+    const int step = (a->gn_out && a->gn_film) ? a->gn_film_div : 1;
+    nmax = nmax / step * step;
+    if (nmax < 1) return LFVDM_E_UNSUPPORTED;              // one sample alone exceeds the offset range
+    const long P = (long)a->Ho * a->Wo, Ps = (long)a->Hs * a->Ws;
+    for (long n0 = 0; n0 < a->N; n0 += nmax) {
+        lfvdm_conv_args b = *a;
+        b.N = (int)(a->N - n0 < nmax ? a->N - n0 : nmax);
+        b.src0 = a->src0 + n0 * Ps * a->C0;
+        if (a->src1) b.src1 = a->src1 + n0 * Ps * a->C1;
+        if (a->s2src0) b.s2src0 = a->s2src0 + n0 * P * a->s2C0;
+        if (a->s2src1) b.s2src1 = a->s2src1 + n0 * P * a->s2C1;
+        if (a->res) b.res = a->res + n0 * P * a->ldr;
+        if (a->resA) { b.resA = a->resA + n0 * a->Cout; b.resB = a->resB + n0 * a->Cout; }
+        b.out = a->out + (a->out_mode == LFVDM_OUT_NCHW ? n0 * a->Cout * P : n0 * P * a->ldo);
+        if (a->gn_out) {
+            b.gn_out = a->gn_out + n0 * P * a->Cout;
+            if (a->gn_film) b.gn_film = a->gn_film + (n0 / a->gn_film_div) * a->gn_film_ld;
+        }
+        if (!glds_ok(&b)) return LFVDM_E_UNSUPPORTED;
+        if (int rc = conv_igemm_one(&b, s)) return rc;
     }
-    return LFVDM_E_UNSUPPORTED;
+    return LFVDM_OK;
 }
 
 extern "C" int lfvdm_pack_conv_weight(const float* w, float* o, int Cout, int Cin, int ksize, void* stream) {
@@ -1172,16 +955,11 @@ extern "C" int lfvdm_pack_conv_weight(const float* w, float* o, int Cout, int Ci
 // All legal tune codes for these arguments (for an autotuner); returns how many were written.
 extern "C" int lfvdm_conv_igemm_candidates(const lfvdm_conv_args* a, int* codes, int max_codes) {
     int n = 0;
-    for (int id = 0; id < kNumCfgs; ++id)
-        for (int kch = 32; kch <= 64; kch += 32)
-            for (int kz = 1; kz <= kHybridKz; kz *= 2)
-                if (cfg_valid(a, id, kch, kz) && n < max_codes) codes[n++] = encode_tune(id, kch, kz);
-    static const bool no_glds = getenv("LFVDM_CONV_NO_GLDS") != nullptr;    // A/B aid
-    for (int gl = 2; gl <= 3 && !no_glds; ++gl)
+    for (int gl = 2; gl <= 3; ++gl)
         for (int id = 0; id < kNumCfgs; ++id)
             for (int kch = 32; kch <= 64; kch += 32)
                 for (int kz = 1; kz <= kHybridKz; kz *= 2)
-                    if (glds_valid(a, id, kch, kz, gl) && n < max_codes) codes[n++] = encode_tune(id, kch, kz, gl);
+                    if (cfg_valid(a, id, kch, kz, gl) && n < max_codes) codes[n++] = encode_tune(id, kch, kz, gl);
     return n;
 }
 

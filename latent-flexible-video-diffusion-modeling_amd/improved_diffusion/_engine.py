@@ -4,8 +4,8 @@ gfx950 kernel launches (C ABI of include/lfvdm_hip.h) for one input shape.
 Design (MI355X-first, not a translation of the reference's ATen op stream, unet.py:428-464):
   * activations are channels-last [B*T][H][W][C]; no layout permutes exist anywhere — temporal
     attention strides over frames, spatial attention over pixels of the same buffer;
-  * GroupNorm+SiLU(+FiLM) is never materialised: a statistics kernel emits per-(sample,channel)
-    affine coefficients that the consuming implicit-GEMM applies while staging its A operand;
+  * GroupNorm(+FiLM)+SiLU is evaluated ONCE per use - in the epilogue of the GEMM that produces its input where a
+    tile holds whole samples, else by lfvdm_gn_apply - and the implicit GEMMs stage raw operands by LDS-DMA;
   * skip concat, nearest-2x upsample, the 1x1 skip conv and every residual add are operands /
     epilogues of the implicit-GEMM kernel;
   * everything that depends only on (t, frame_indices) — time-embedding MLP, all ResBlock FiLM
@@ -30,8 +30,6 @@ def _p(t):
     return t.data_ptr()
 
 
-# LFVDM_FUSED_GN=1 restores the older plan that folds GroupNorm/FiLM/SiLU into the operand load of the consuming GEMM
-FUSED_GN = os.environ.get("LFVDM_FUSED_GN", "0") == "1"
 # LFVDM_SPATIAL_FUSED=0: keep the qkv projection of the spatial attention as its own GEMM launch (A/B aid)
 SPATIAL_FUSED = os.environ.get("LFVDM_SPATIAL_FUSED", "1") != "0"
 # LFVDM_GN_EPILOGUE=0: never evaluate a GroupNorm in the epilogue of the GEMM that produces its input (A/B aid)
@@ -340,8 +338,6 @@ class Plan:
         self.s_qkv = self.buf(Mmax * 3 * maxC)
         self.s_o = self.buf(Mmax * maxC)
         self.s_xn = self.buf(Mmax * maxC)
-        self.s_cA, self.s_cB = self.buf(N * max(maxCin, maxC)), self.buf(N * max(maxCin, maxC))
-        self.s_cA2, self.s_cB2 = self.buf(N * max(maxCin, maxC)), self.buf(N * max(maxCin, maxC))
 
         # ---- network body
         conv0 = m.input_blocks[0][0]
@@ -367,23 +363,16 @@ class Plan:
         (hb, hc), = cur["parts"]
         gn, conv = m.out[0], m.out[2]
         self.out = self.buf(B, T, m.out_channels, H, W)
-        if FUSED_GN:
-            self.add(L.lfvdm_gn_coef, _p(hb), None, hc, 0, N, H * W, _p(gn.weight), _p(gn.bias), None, 1, 0, gn.eps,
-                     _p(self.s_cA), _p(self.s_cB))
-            self.add_conv(src0=hb, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA, coefB=self.s_cB, act=nat.ACT_SILU,
-                          W=self.packed(conv.weight), bias=conv.bias, Cout=m.out_channels, out=self.out,
-                          ldo=m.out_channels, out_mode=nat.OUT_NCHW)
-        else:
-            act = self.gn_apply(hb, None, hc, 0, N, H * W, gn, None, nat.ACT_SILU, "act1")
-            self.add_conv(src0=act, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv.weight), bias=conv.bias,
-                          Cout=m.out_channels, out=self.out, ldo=m.out_channels, out_mode=nat.OUT_NCHW)
+        act = self.gn_apply(hb, None, hc, 0, N, H * W, gn, None, nat.ACT_SILU, "act1")
+        self.add_conv(src0=act, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv.weight), bias=conv.bias,
+                      Cout=m.out_channels, out=self.out, ldo=m.out_channels, out_mode=nat.OUT_NCHW)
 
     def _stage(self, blk, cur, after=None):
         from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
         layers = list(blk)
         for i, layer in enumerate(layers):
             nxt = layers[i + 1] if i + 1 < len(layers) else after
-            ngn = nxt.in_layers[0] if (isinstance(nxt, ResBlock) and NEXT_GN_EPILOGUE and not FUSED_GN) else None
+            ngn = nxt.in_layers[0] if (isinstance(nxt, ResBlock) and NEXT_GN_EPILOGUE) else None
             if isinstance(layer, ResBlock):
                 cur = self._res(layer, cur, ngn)
             elif isinstance(layer, FactorizedAttentionBlock):
@@ -423,31 +412,21 @@ class Plan:
         h1 = self.buf(N * P, Cout)
         film = self.film[rb]
         out = self.buf(N * P, Cout)
-        if FUSED_GN:
-            self.add(L.lfvdm_gn_coef, _p(a), pb, C0, C1, N, P, _p(gn1.weight), _p(gn1.bias), None, 1, 0, gn1.eps,
-                     _p(self.s_cA), _p(self.s_cB))
-            self.add_conv(src0=a, src1=b, C0=C0, C1=C1, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA, coefB=self.s_cB,
-                          act=nat.ACT_SILU, W=self.packed(conv1.weight), bias=conv1.bias, Cout=Cout, out=h1, ldo=Cout)
-            self.add(L.lfvdm_gn_coef, _p(h1), None, Cout, 0, N, P, _p(gn2.weight), _p(gn2.bias), _p(film), self.T, self.rows_ld,
-                     gn2.eps, _p(self.s_cA2), _p(self.s_cB2))
-            kw = dict(src0=h1, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, coefA=self.s_cA2, coefB=self.s_cB2, act=nat.ACT_SILU,
-                      W=self.packed(conv2.weight), bias=conv2.bias, Cout=Cout, out=out, ldo=Cout)
-        else:
-            # GroupNorm(+FiLM)+SiLU evaluated ONCE into a scratch tensor (the concat of the two sources becomes
-            # real); the implicit GEMMs then stage raw operands (see lfvdm_gn_apply for why this wins on gfx950)
-            act1 = cur.get("act1")          # already evaluated by the producer's epilogue?
-            if act1 is None:
-                act1 = self.gn_apply(a, b, C0, C1, N, P, gn1, None, nat.ACT_SILU, "act1")
-            c1 = dict(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight), bias=conv1.bias,
-                      Cout=Cout, out=h1, ldo=Cout)
-            # low-resolution levels: GroupNorm-2 + FiLM + SiLU in the epilogue of conv1 (whole samples per tile);
-            # the raw h1 is not needed by anything else and is not written
-            act2 = self.scratch("act2", N * P, Cout)
-            if not self.conv_fused_gn(gn=gn2, gn_film=film, gn_out=act2, gn_act=nat.ACT_SILU, gn_skip_raw=1, **c1):
-                self.add_conv(**c1)
-                act2 = self.gn_apply(h1, None, Cout, 0, N, P, gn2, film, nat.ACT_SILU, "act2")
-            kw = dict(src0=act2, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv2.weight), bias=conv2.bias,
-                      Cout=Cout, out=out, ldo=Cout)
+        # GroupNorm(+FiLM)+SiLU evaluated ONCE into a scratch tensor (the concat of the two sources becomes
+        # real); the implicit GEMMs then stage raw operands (see lfvdm_gn_apply for why this wins on gfx950)
+        act1 = cur.get("act1")          # already evaluated by the producer's epilogue?
+        if act1 is None:
+            act1 = self.gn_apply(a, b, C0, C1, N, P, gn1, None, nat.ACT_SILU, "act1")
+        c1 = dict(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight), bias=conv1.bias,
+                  Cout=Cout, out=h1, ldo=Cout)
+        # low-resolution levels: GroupNorm-2 + FiLM + SiLU in the epilogue of conv1 (whole samples per tile);
+        # the raw h1 is not needed by anything else and is not written
+        act2 = self.scratch("act2", N * P, Cout)
+        if not self.conv_fused_gn(gn=gn2, gn_film=film, gn_out=act2, gn_act=nat.ACT_SILU, gn_skip_raw=1, **c1):
+            self.add_conv(**c1)
+            act2 = self.gn_apply(h1, None, Cout, 0, N, P, gn2, film, nat.ACT_SILU, "act2")
+        kw = dict(src0=act2, C0=Cout, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv2.weight), bias=conv2.bias,
+                  Cout=Cout, out=out, ldo=Cout)
         if isinstance(rb.skip_connection, nn.Identity):
             assert b is None
             kw.update(res=a, ldr=Cout)
@@ -488,39 +467,23 @@ class Plan:
                     bias=ta.proj_out.bias, Cout=Cc, res=self.s_xn, ldr=Cc, out=yt, ldo=Cc)
         # --- spatial: GN over (C/32 x HW) per frame.  Low-resolution levels: evaluated in the epilogue of the temporal
         # projection (whole frames per tile; the raw block output is read by nothing else)
-        ysn = None
-        if not FUSED_GN:
-            ysn = self.scratch("act1", M, Cc)
-            if not self.conv_fused_gn(gn=sa.norm, gn_out=ysn, gn_act=nat.ACT_NONE, gn_skip_raw=1, **proj):
-                ysn = None
-        if ysn is None:
+        ysn = self.scratch("act1", M, Cc)
+        if not self.conv_fused_gn(gn=sa.norm, gn_out=ysn, gn_act=nat.ACT_NONE, gn_skip_raw=1, **proj):
             self.add_conv(**proj)
-        if FUSED_GN:
-            self.add(L.lfvdm_gn_coef, _p(yt), None, Cc, 0, N, P, _p(sa.norm.weight), _p(sa.norm.bias), None, 1, 0, sa.norm.eps,
-                     _p(self.s_cA), _p(self.s_cB))
-            self.add_conv(src0=yt, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=self.s_cA, coefB=self.s_cB,
-                          W=sa.qkv.weight, bias=sa.qkv.bias, Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
+            ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
+        # qkv projection inside the attention launch where a frame, the head's filters and its q / k / v fit the LDS
+        fused_sa = (SPATIAL_FUSED and not self.want_attn and L.lfvdm_attn_spatial_fused_ok(N, P, Cc, heads) == 0)
+        if fused_sa:
+            self.add(L.lfvdm_attn_spatial_fused, _p(ysn), _p(sa.qkv.weight), _p(sa.qkv.bias), _p(self.s_o), N, P, Cc, heads)
         else:
-            if ysn is None:
-                ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
-            # qkv projection inside the attention launch where a frame, the head's filters and its q / k / v fit the LDS
-            fused_sa = (SPATIAL_FUSED and not self.want_attn and L.lfvdm_attn_spatial_fused_ok(N, P, Cc, heads) == 0)
-            if fused_sa:
-                self.add(L.lfvdm_attn_spatial_fused, _p(ysn), _p(sa.qkv.weight), _p(sa.qkv.bias), _p(self.s_o), N, P, Cc, heads)
-            else:
-                self.add_conv(src0=ysn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.qkv.weight, bias=sa.qkv.bias,
-                              Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
-        asp = None
-        if self.want_attn:
-            asp = self.buf(N, heads, P, P)
-            self.attn_s.append(asp)
-        if FUSED_GN or not fused_sa:
+            self.add_conv(src0=ysn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.qkv.weight, bias=sa.qkv.bias,
+                          Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
+            asp = None
+            if self.want_attn:
+                asp = self.buf(N, heads, P, P)
+                self.attn_s.append(asp)
             self.add(L.lfvdm_attn_spatial, _p(self.s_qkv), _p(self.s_o), _p(asp) if asp is not None else None, None, N, P, Cc, heads)
         ys = self.buf(M, Cc)
-        if FUSED_GN:
-            self.add_conv(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
-                          bias=sa.proj_out.bias, Cout=Cc, res=yt, ldr=Cc, resA=self.s_cA, resB=self.s_cB, out=ys, ldo=Cc)
-            return dict(parts=[(ys, Cc)], H=H, W=W)
         nact = self._final_conv(dict(src0=self.s_o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=sa.proj_out.weight,
                                      bias=sa.proj_out.bias, Cout=Cc, res=ysn, ldr=Cc, out=ys, ldo=Cc), next_gn, M)
         res = dict(parts=[(ys, Cc)], H=H, W=W)

@@ -40,6 +40,15 @@ def close(a, b, atol, rtol=1e-4):
     assert torch.allclose(a, b, atol=atol, rtol=rtol), f"max|d|={err:.3e} (scale {float(b.abs().max()):.3e})"
 
 
+def gn_act(nat, a, b, C0, C1, N, P, gamma, beta, film, film_div, film_ld, act):
+    """lfvdm_gn_apply: act(GroupNorm32(cat(a, b)) (* (1 + scale) + shift)) materialised as one [N*P][C0+C1] tensor."""
+    out = torch.empty(N * P, C0 + C1, device="cuda")
+    nat.check(nat.lib().lfvdm_gn_apply(nat.ptr(a), nat.ptr(b) if b is not None else None, C0, C1, N, P, nat.ptr(gamma), nat.ptr(beta),
+                                       film.data_ptr() if film is not None else None, film_div, film_ld, 1e-5, act, nat.ptr(out),
+                                       None, None, None, nat.stream()), "lfvdm_gn_apply")
+    return out
+
+
 def packed(nat, w):
     o = torch.empty(w.shape[0], w.shape[2] * w.shape[3], w.shape[1], device="cuda")
     nat.pack_conv_weight(w.cuda().contiguous(), o)
@@ -84,8 +93,8 @@ def test_conv_stride2_and_upsample(nat):
 
 @pytest.mark.parametrize("N,C0,C1,Cout,H", [(4, 64, 64, 64, 16), (6, 128, 64, 128, 8), (40, 128, 128, 128, 2)])
 def test_resblock_fused(nat, N, C0, C1, Cout, H):
-    """gn_coef + conv(GN+SiLU prologue) + gn_coef(FiLM) + conv(+1x1 skip segment) vs oracle res_block on a
-    virtual concat input (unet.py:194-207,460)."""
+    """gn_apply (virtual concat made real) + conv + gn_apply(FiLM) + conv(+1x1 skip segment over the two raw sources) vs the
+    oracle res_block on a concat input (unet.py:194-207,460): the launch sequence of the plan's 16x16 ResBlocks."""
     Cin = C0 + C1
     xa, xb = rnd("rb/xa", N, C0, H, H), rnd("rb/xb", N, C1, H, H, scale=1.5)
     x = torch.cat([xa, xb], 1)
@@ -102,18 +111,16 @@ def test_resblock_fused(nat, N, C0, C1, Cout, H):
     a, b = cl(xa), cl(xb)
     P = H * H
     film = F.linear(uo.silu(emb), sd["p.emb_layers.1.weight"], sd["p.emb_layers.1.bias"]).cuda().contiguous()
-    cA, cB = torch.empty(N, Cin, device="cuda"), torch.empty(N, Cin, device="cuda")
-    nat.gn_coef(a, b, C0, C1, N, P, d["p.in_layers.0.weight"], d["p.in_layers.0.bias"], None, 1, 0, 1e-5, cA, cB)
+    act1 = gn_act(nat, a, b, C0, C1, N, P, d["p.in_layers.0.weight"], d["p.in_layers.0.bias"], None, 1, 0, nat.ACT_SILU)
     h1 = torch.empty(N * P, Cout, device="cuda")
-    nat.conv_igemm(src0=a, src1=b, C0=C0, C1=C1, N=N, Hs=H, Ws=H, Ho=H, Wo=H, coefA=cA, coefB=cB, act=nat.ACT_SILU,
+    nat.conv_igemm(src0=act1, C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H,
                    W=packed(nat, sd["p.in_layers.2.weight"]), bias=d["p.in_layers.2.bias"], Cout=Cout, out=h1, ldo=Cout)
     ref_h1 = F.conv2d(uo.silu(uo.group_norm32(x, sd["p.in_layers.0.weight"], sd["p.in_layers.0.bias"])),
                       sd["p.in_layers.2.weight"], sd["p.in_layers.2.bias"], padding=1)
     close(from_cl(h1, N, H, H, Cout), ref_h1, 5e-5)
-    cA2, cB2 = torch.empty(N, Cout, device="cuda"), torch.empty(N, Cout, device="cuda")
-    nat.gn_coef(h1, None, Cout, 0, N, P, d["p.out_layers.0.weight"], d["p.out_layers.0.bias"], film, T, 2 * Cout, 1e-5, cA2, cB2)
+    act2 = gn_act(nat, h1, None, Cout, 0, N, P, d["p.out_layers.0.weight"], d["p.out_layers.0.bias"], film, T, 2 * Cout, nat.ACT_SILU)
     out = torch.empty(N * P, Cout, device="cuda")
-    nat.conv_igemm(src0=h1, C0=Cout, N=N, Hs=H, Ws=H, Ho=H, Wo=H, coefA=cA2, coefB=cB2, act=nat.ACT_SILU,
+    nat.conv_igemm(src0=act2, C0=Cout, N=N, Hs=H, Ws=H, Ho=H, Wo=H,
                    W=packed(nat, sd["p.out_layers.3.weight"]), bias=d["p.out_layers.3.bias"], Cout=Cout,
                    s2src0=a, s2src1=b, s2C0=C0, s2C1=C1, W2=d["p.skip_connection.weight"].view(Cout, Cin).contiguous(),
                    bias2=d["p.skip_connection.bias"], out=out, ldo=Cout)
@@ -133,14 +140,13 @@ def test_resblock_identity_skip(nat):
     d = {k: v.cuda() for k, v in sd.items()}
     a, P = cl(x), H * H
     film = F.linear(uo.silu(emb), sd["p.emb_layers.1.weight"], sd["p.emb_layers.1.bias"]).cuda().contiguous()
-    cA, cB = torch.empty(N, Cc, device="cuda"), torch.empty(N, Cc, device="cuda")
-    nat.gn_coef(a, None, Cc, 0, N, P, d["p.in_layers.0.weight"], d["p.in_layers.0.bias"], None, 1, 0, 1e-5, cA, cB)
+    act1 = gn_act(nat, a, None, Cc, 0, N, P, d["p.in_layers.0.weight"], d["p.in_layers.0.bias"], None, 1, 0, nat.ACT_SILU)
     h1 = torch.empty(N * P, Cc, device="cuda")
-    nat.conv_igemm(src0=a, C0=Cc, N=N, Hs=H, Ws=H, Ho=H, Wo=H, coefA=cA, coefB=cB, act=nat.ACT_SILU,
+    nat.conv_igemm(src0=act1, C0=Cc, N=N, Hs=H, Ws=H, Ho=H, Wo=H,
                    W=packed(nat, sd["p.in_layers.2.weight"]), bias=d["p.in_layers.2.bias"], Cout=Cc, out=h1, ldo=Cc)
-    nat.gn_coef(h1, None, Cc, 0, N, P, d["p.out_layers.0.weight"], d["p.out_layers.0.bias"], film, T, 2 * Cc, 1e-5, cA, cB)
+    act2 = gn_act(nat, h1, None, Cc, 0, N, P, d["p.out_layers.0.weight"], d["p.out_layers.0.bias"], film, T, 2 * Cc, nat.ACT_SILU)
     out = torch.empty(N * P, Cc, device="cuda")
-    nat.conv_igemm(src0=h1, C0=Cc, N=N, Hs=H, Ws=H, Ho=H, Wo=H, coefA=cA, coefB=cB, act=nat.ACT_SILU,
+    nat.conv_igemm(src0=act2, C0=Cc, N=N, Hs=H, Ws=H, Ho=H, Wo=H,
                    W=packed(nat, sd["p.out_layers.3.weight"]), bias=d["p.out_layers.3.bias"], Cout=Cc,
                    res=a, ldr=Cc, out=out, ldo=Cc)
     close(from_cl(out, N, H, H, Cc), ref, 1e-4)
@@ -392,7 +398,8 @@ def test_attn_temporal_second_generation_kernel(nat, B, T, P, Cc, heads):
 
 
 def test_spatial_attention_block(nat):
-    """gn_coef + qkv GEMM (affine prologue) + spatial core + proj GEMM (affine residual) vs oracle."""
+    """gn_apply + qkv GEMM + spatial core + proj GEMM (residual on the normalised tensor, rpe.py:172) vs oracle; a launch that
+    still asks for the removed operand prologue (coefA / coefB) is refused."""
     N, P, Cc, heads = 3, 64, 64, 4
     shapes = {"qkv.weight": (3 * Cc, Cc), "qkv.bias": (3 * Cc,), "proj_out.weight": (Cc, Cc), "proj_out.bias": (Cc,),
               "norm.weight": (Cc,), "norm.bias": (Cc,)}
@@ -401,18 +408,28 @@ def test_spatial_attention_block(nat):
     ref, _ = uo.rpe_attention(sd, "p", x, None, None, None, heads, False)
     d = {k: v.cuda() for k, v in sd.items()}
     xc = x[0].permute(0, 2, 1).contiguous().cuda()  # [N][P][C]
-    cA, cB = torch.empty(N, Cc, device="cuda"), torch.empty(N, Cc, device="cuda")
-    nat.gn_coef(xc, None, Cc, 0, N, P, d["p.norm.weight"], d["p.norm.bias"], None, 1, 0, 1e-5, cA, cB)
     M = N * P
+    xn = gn_act(nat, xc, None, Cc, 0, N, P, d["p.norm.weight"], d["p.norm.bias"], None, 1, 0, nat.ACT_NONE)
     qkv = torch.empty(M, 3 * Cc, device="cuda")
-    nat.conv_igemm(src0=xc, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=cA, coefB=cB, W=d["p.qkv.weight"],
+    nat.conv_igemm(src0=xn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.qkv.weight"],
                    bias=d["p.qkv.bias"], Cout=3 * Cc, out=qkv, ldo=3 * Cc)
+    cA = torch.ones(N, Cc, device="cuda")
+    with pytest.raises(RuntimeError):
+        nat.conv_igemm(src0=xn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, coefA=cA, coefB=cA, W=d["p.qkv.weight"],
+                       bias=d["p.qkv.bias"], Cout=3 * Cc, out=qkv.clone(), ldo=3 * Cc)
     o = torch.empty(M, Cc, device="cuda")
     nat.attn_spatial(qkv, o, None, N, P, Cc, heads)
     y = torch.empty(M, Cc, device="cuda")
     nat.conv_igemm(src0=o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.proj_out.weight"], bias=d["p.proj_out.bias"],
-                   Cout=Cc, res=xc.view(M, Cc), ldr=Cc, resA=cA, resB=cB, out=y, ldo=Cc)
+                   Cout=Cc, res=xn, ldr=Cc, out=y, ldo=Cc)
     close(y.view(N, P, Cc).permute(0, 2, 1), ref[0], 1e-4)
+    # the affine residual of the epilogue (res * resA[n] + resB[n]): the raw tensor with the GroupNorm coefficients == xn
+    cA, cB = torch.empty(N, Cc, device="cuda"), torch.empty(N, Cc, device="cuda")
+    nat.gn_coef(xc, None, Cc, 0, N, P, d["p.norm.weight"], d["p.norm.bias"], None, 1, 0, 1e-5, cA, cB)
+    y2 = torch.empty(M, Cc, device="cuda")
+    nat.conv_igemm(src0=o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=d["p.proj_out.weight"], bias=d["p.proj_out.bias"],
+                   Cout=Cc, res=xc.view(M, Cc), ldr=Cc, resA=cA, resB=cB, out=y2, ldo=Cc)
+    close(y2, y, 2e-5)
 
 
 def test_diffusion_ops(nat):

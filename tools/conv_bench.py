@@ -12,8 +12,7 @@ def run(N, Cin, Cout, H, k=3, coef=True, reps=20):
     cA = th.randn(N, Cin, device="cuda"); cB = th.randn(N, Cin, device="cuda")
     out = th.empty(N * H * H, Cout, device="cuda")
     kw = dict(src0=x, C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, ksize=k, W=w, bias=b, Cout=Cout, out=out, ldo=Cout)
-    if coef:
-        kw.update(coefA=cA, coefB=cB, act=nat.ACT_SILU)
+    # (coef: the operand-prologue variant of rounds 1-2 is gone; the argument is kept so that old command lines still run)
     for _ in range(3):
         nat.conv_igemm(**kw)
     th.cuda.synchronize()
