@@ -768,9 +768,8 @@ extern "C" int lfvdm_attn_temporal_sel(const float* qkv, const float* Rq, const 
     if (!Rq || !Rk || !Rv) return LFVDM_E_SHAPE;
     const int F = C / heads;
     hipStream_t s = (hipStream_t)stream;
-    // second-generation kernel (attention_temporal2.hip) for head dims 8 / 16 / 32; LFVDM_ATTN_V1 forces the first one
-    static const bool force_v1 = getenv("LFVDM_ATTN_V1") != nullptr;      // A/B aid
-    if (!force_v1) {
+    // second-generation kernel (attention_temporal2.hip) for head dims 16 / 32 / 64 and launches that do not fill the chip
+    {
         const int rc = lfvdm_attn_temporal2_try(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
         if (rc != LFVDM_E_UNSUPPORTED) return rc;
     }

@@ -23,10 +23,7 @@ struct T2Geom {
     int TG, TGN, PPW, NW;      // frame groups, frames per group, pixels per wave, waves per workgroup
     int strips;                // pixel strips of NW*PPW pixels
     int NL, HL, XPG;           // line groups (b, head / HL), heads per 128-byte line, XCDs per line group (0: plain map)
-    int dbg;                   // developer aid (tools/attn_t2_sweep.py): 1 = staging only, 2 = no staging
 };
-
-int g_t2_force_tg = 0, g_t2_force_nw = 0, g_t2_dbg = 0;      // set by lfvdm_attn_temporal2_debug (tools only)
 
 template <int F, int TCAP>
 struct T2Cfg {
@@ -92,7 +89,6 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         };
-        if (g.dbg < 2)
         for (int pc = wave; pc < nR; pc += g.NW) {
             const int ps = pc * 64 + lane;
             const int row3 = (int)(((float)ps + 0.5f) * invRS);        // (query frame, array) row
@@ -107,7 +103,6 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
             const float* base = arr == 0 ? Rsrc[0] : (arr == 1 ? Rsrc[1] : Rsrc[2]);
             dma(ok ? base + (size_t)row * C + 4 * u : qkv, Rimg + (size_t)pc * 256);
         }
-        if (g.dbg < 2)
         for (int pc = wave; pc < nKV; pc += g.NW) {
             const int ps = pc * 64 + lane;
             const int row2 = (int)(((float)ps + 0.5f) * invRS);        // (pixel, k | v) row
@@ -145,7 +140,7 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
     constexpr int ISTRIDE = 4 * NQ * 4;                     // floats between consecutive i
     int kb[NQ], rbs[NQ];
     {
-        const int jr = (active && g.dbg != 3) ? jw : 0, tr = (active && g.dbg != 3) ? tq : 0;   // dbg 3: every lane reads row 0
+        const int jr = active ? jw : 0, tr = active ? tq : 0;
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int low = (NQ * sq + u) & 15, high = (NQ * sq + u) & ~15;
@@ -160,7 +155,7 @@ void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restric
     auto quad_x1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); };
     auto quad_x2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); };
 
-    if (g.dbg != 1) {            // (inactive lanes run along on row 0: the quad exchanges need all four lanes)
+    {                            // (inactive lanes run along on row 0: the quad exchanges need all four lanes)
         float logit[KQ];
         // packed fp32 math on naturally adjacent register pairs (q, k, R rows arrive as b128 = two aligned pairs)
 #pragma unroll
@@ -285,13 +280,6 @@ int launch_t2(const float* qkv, const float* Rq, const float* Rk, const float* R
             if (t2_lds_bytes(TGN, NW * PPW, RS) <= 160 * 1024) best_nw = NW;
         if (best_nw == 0) best_tg = 0;
     }
-    if (g_t2_force_tg > 0) {
-        best_tg = g_t2_force_tg;
-        best_nw = g_t2_force_nw;
-        const int TGN = (T + best_tg - 1) / best_tg, PPW = 16 / (TGN > 16 ? 16 : TGN);
-        if (TGN > 16 || t2_lds_bytes(TGN, best_nw * PPW, RS) > 160 * 1024) return LFVDM_E_SHAPE;
-    }
-    g.dbg = g_t2_dbg;
     if (best_tg == 0) return LFVDM_E_UNSUPPORTED;
     g.TG = best_tg; g.NW = best_nw;
     g.TGN = (T + g.TG - 1) / g.TG;
@@ -331,20 +319,13 @@ int launch_t2_f(const float* qkv, const float* Rq, const float* Rk, const float*
 
 }  // namespace
 
-// Developer aid: force the decomposition / switch off phases (tools/attn_t2_sweep.py).  Not part of the product ABI.
-extern "C" void lfvdm_attn_temporal2_debug(int tg, int nw, int dbg) {
-    g_t2_force_tg = tg;
-    g_t2_force_nw = nw;
-    g_t2_dbg = dbg;
-}
-
 // Internal entry (attention.hip dispatches here first): LFVDM_E_UNSUPPORTED = shape not covered, use the first kernel.
 int lfvdm_attn_temporal2_try(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
                              float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
     const int F = C / heads;
     // Large launches (e.g. 16x16 maps at 128 channels, batch 2: 25.9 us vs 30) keep every CU busy in the first kernel
     // too, which stages each R slice once per 12 pixels instead of once per 12 pixels AND frame group: use it there.
-    if ((long)B * P * F >= 16384 && g_t2_force_tg == 0) return LFVDM_E_UNSUPPORTED;
+    if ((long)B * P * F >= 16384) return LFVDM_E_UNSUPPORTED;
     if (F == 16) return launch_t2_f<16>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (F == 32) return launch_t2_f<32>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (F == 64) return launch_t2_f<64>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
