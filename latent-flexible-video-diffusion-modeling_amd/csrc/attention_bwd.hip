@@ -16,8 +16,15 @@
 // R tensors [B][T][T][C]; workspace matrices [(b*P + p)*heads + h][T][T].
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common_hip.h"
 #include "lfvdm_hip.h"
+
+// (attention_temporal2.hip) the rows kernel in the second-generation decomposition; LFVDM_E_UNSUPPORTED = not covered
+int lfvdm_attn_temporal2_bwd_rows_try(const float* qkv, const float* dO, const float* Rq, const float* Rk, const float* Rv,
+                                      const float* mask, float* dqkv, float* Pg, float* dSg, int B, int T, int P, int C, int heads,
+                                      hipStream_t s);
 
 namespace {
 
@@ -651,9 +658,15 @@ int launch_tb(const float* qkv, const float* d_o, const float* Rq, const float* 
     if (int rc = limit_rows.ensure(reinterpret_cast<const void*>(&attn_temporal_bwd_rows_kernel<TMAX, FC>), lds_rows)) return rc;
     if (int rc = limit_cols.ensure(reinterpret_cast<const void*>(&attn_temporal_bwd_cols_kernel<TMAX, FC>), lds_cols)) return rc;
     const dim3 grid((unsigned)((P + 4 * PPW - 1) / (4 * PPW)), (unsigned)heads, (unsigned)B);
-    hipLaunchKernelGGL((attn_temporal_bwd_rows_kernel<TMAX, FC>), grid, dim3(256), lds_rows, s, qkv, d_o, Rq, Rk, Rv, mask, dqkv,
-                       Pg, dSg, T, P, C, heads, PPW);
-    LFVDM_CHECK_LAUNCH();
+    static const bool rows_v1 = getenv("LFVDM_ATTN_BWD_ROWS_V1") != nullptr;     // A/B aid
+    int rc2 = rows_v1 ? LFVDM_E_UNSUPPORTED : lfvdm_attn_temporal2_bwd_rows_try(qkv, d_o, Rq, Rk, Rv, mask, dqkv, Pg, dSg, B, T, P, C, heads, s);
+    if (rc2 == LFVDM_E_UNSUPPORTED) {
+        hipLaunchKernelGGL((attn_temporal_bwd_rows_kernel<TMAX, FC>), grid, dim3(256), lds_rows, s, qkv, d_o, Rq, Rk, Rv, mask, dqkv,
+                           Pg, dSg, T, P, C, heads, PPW);
+        LFVDM_CHECK_LAUNCH();
+    } else if (rc2 != LFVDM_OK) {
+        return rc2;
+    }
     hipLaunchKernelGGL((attn_temporal_bwd_cols_kernel<TMAX, FC>), grid, dim3(256), lds_cols, s, qkv, d_o, Rq, Pg, dSg, dqkv, T, P,
                        C, heads, PPW);
     LFVDM_CHECK_LAUNCH();

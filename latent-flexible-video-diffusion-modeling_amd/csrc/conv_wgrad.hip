@@ -33,6 +33,17 @@ __device__ __forceinline__ int fdiv(int a, int d, float rd) {
     return q;
 }
 
+// exact a / d for 0 <= a, d >= 1 with a quotient below 2^21 (v_rcp_f32 is accurate to 1 ulp: the truncated product is off by
+// at most one, fdiv's fix-up repairs it).  The kernel prologues are instruction-bound: a generic 32-bit division is ~25
+// instructions, a 64-bit one ~150.
+__device__ __forceinline__ int qdiv(int a, int d) { return fdiv(a, d, __builtin_amdgcn_rcpf((float)d)); }
+// even partition of n chunks over `parts` slices without wide products: slice i = [beg, end)
+__device__ __forceinline__ void slice_of(int n, int parts, int i, int& beg, int& end) {
+    const int q = qdiv(n, parts), r = n - q * parts;
+    beg = i * q + min(i, r);
+    end = beg + q + (i < r ? 1 : 0);
+}
+
 template <class T>
 __device__ __forceinline__ T selv(bool c, T a, T b) {
     return c ? a : b;
@@ -57,10 +68,11 @@ __device__ __forceinline__ void wgrad_wave_task(const lfvdm_conv_args& p, int ms
     // wave task = (k tile, co tile, m slice)
     const long ntasks = (long)NKT * NCT * msplit;
     if (task >= ntasks) return;
-    const int ms = (int)(task % msplit);
-    const int ct = (int)((task / msplit) % NCT);
-    const int kt = (int)(task / ((long)msplit * NCT));
-    const int tap = kt / cpt;
+    const int t1 = qdiv((int)task, msplit);
+    const int ms = (int)task - t1 * msplit;
+    const int kt = qdiv(t1, NCT);
+    const int ct = t1 - kt * NCT;
+    const int tap = qdiv(kt, cpt);
     const int cc = (kt - tap * cpt) * 32;
     const int dy = p.ksize == 3 ? tap / 3 - 1 : 0;
     const int dx = p.ksize == 3 ? tap - (tap / 3) * 3 - 1 : 0;
@@ -69,12 +81,13 @@ __device__ __forceinline__ void wgrad_wave_task(const lfvdm_conv_args& p, int ms
     const int Csrc = selv(second, p.C1, p.C0);
     const int cl = second ? cc - p.C0 : cc;
     const int Hin = p.up ? 2 * p.Hs : p.Hs, Win = p.up ? 2 * p.Ws : p.Ws;
-    const int c_beg = (int)(((long)nchunks * ms) / msplit), c_end = (int)(((long)nchunks * (ms + 1)) / msplit);
+    int c_beg, c_end;
+    slice_of(nchunks, msplit, ms, c_beg, c_end);
     const int co0 = ct * 32;
 
     const int col = (lane & 7) * 4;
     const int rsub = lane >> 3;
-    const float rHoWo = 1.0f / (float)HoWo, rWo = 1.0f / (float)p.Wo;
+    const float rHoWo = __builtin_amdgcn_rcpf((float)HoWo), rWo = __builtin_amdgcn_rcpf((float)p.Wo);     // quotients < 2^21
     const float* dout = p.res;
 
     f32x16 acc;
@@ -219,10 +232,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_coop_kernel(const lfvdm_conv_a
     const int nchunks = (M + 31) / 32;
 
     const int task = blockIdx.x;                       // (k group, co group, m slice)
-    const int ms = task % msplit;
-    const int cg = (task / msplit) % NCG;
-    const int kg = task / (msplit * NCG);
-    const int tap = kg / cpg;
+    const int t1 = qdiv(task, msplit);
+    const int ms = task - t1 * msplit;
+    const int kg = qdiv(t1, NCG);
+    const int cg = t1 - kg * NCG;
+    const int tap = qdiv(kg, cpg);
     const int cc = (kg - tap * cpg) * 32 * KT;         // first input channel of the group
     const int dy = p.ksize == 3 ? tap / 3 - 1 : 0;
     const int dx = p.ksize == 3 ? tap - (tap / 3) * 3 - 1 : 0;
@@ -231,9 +245,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_coop_kernel(const lfvdm_conv_a
     const int Csrc = selv(second, p.C1, p.C0);
     const int cl = second ? cc - p.C0 : cc;
     const int Hin = p.up ? 2 * p.Hs : p.Hs, Win = p.up ? 2 * p.Ws : p.Ws;
-    const int c_beg = (int)(((long)nchunks * ms) / msplit), c_end = (int)(((long)nchunks * (ms + 1)) / msplit);
+    int c_beg, c_end;
+    slice_of(nchunks, msplit, ms, c_beg, c_end);
     const int co0 = cg * 32 * COT;
-    const float rHoWo = 1.0f / (float)HoWo, rWo = 1.0f / (float)p.Wo;
+    const float rHoWo = __builtin_amdgcn_rcpf((float)HoWo), rWo = __builtin_amdgcn_rcpf((float)p.Wo);     // quotients < 2^21
     const float* dout = p.res;
     const bool has_coef = p.coefA != nullptr;
     const bool silu = p.act == LFVDM_ACT_SILU;
@@ -399,10 +414,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
     const int nchunks = (M + 31) / 32;
 
     const int task = blockIdx.x;                       // (k group, co group, m slice)
-    const int ms = task % msplit;
-    const int cg = (task / msplit) % NCG;
-    const int kg = task / (msplit * NCG);
-    const int tap = kg / cpg;
+    const int t1 = qdiv(task, msplit);
+    const int ms = task - t1 * msplit;
+    const int kg = qdiv(t1, NCG);
+    const int cg = t1 - kg * NCG;
+    const int tap = qdiv(kg, cpg);
     const int cc = (kg - tap * cpg) * 32 * KT;
     const int dy = p.ksize == 3 ? tap / 3 - 1 : 0;
     const int dx = p.ksize == 3 ? tap - (tap / 3) * 3 - 1 : 0;
@@ -411,9 +427,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
     const int Csrc = selv(second, p.C1, p.C0);
     const int cl = second ? cc - p.C0 : cc;
     const int Hin = p.up ? 2 * p.Hs : p.Hs, Win = p.up ? 2 * p.Ws : p.Ws;
-    const int c_beg = (int)(((long)nchunks * ms) / msplit), c_end = (int)(((long)nchunks * (ms + 1)) / msplit);
+    int c_beg, c_end;
+    slice_of(nchunks, msplit, ms, c_beg, c_end);
     const int co0 = cg * 32 * COT;
-    const float rHoWo = 1.0f / (float)HoWo, rWo = 1.0f / (float)p.Wo;
+    const float rHoWo = __builtin_amdgcn_rcpf((float)HoWo), rWo = __builtin_amdgcn_rcpf((float)p.Wo);     // quotients < 2^21
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)((unsigned)M * p.ldr * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)src, 0, (int)((unsigned)p.N * p.Hs * p.Ws * Csrc * 4u), 0x00020000);
