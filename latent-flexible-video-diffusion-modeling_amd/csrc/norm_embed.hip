@@ -628,11 +628,36 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     }
     const int Ci = CIT ? CIT : C + 1;
     const int K = Ci * 9;
-    // w is OIHW = [co][k]; consecutive threads take consecutive co, so the LDS writes are bank-conflict free (walking
-    // k fastest put every write of a wave into one bank: stride Cout)
-    for (int i = threadIdx.x; i < K * Cout; i += 256) {
-        const int k = i / Cout, co = i - k * Cout;
-        wl[i] = w[(size_t)co * K + k];
+    constexpr int CP = Cout + 4;                  // padded LDS row: the transposing writes below spread over the banks
+    // w is OIHW = [co][k]: read it as it lies (consecutive threads -> consecutive floats: coalesced; the first version
+    // walked co fastest, 256 cache lines per wave load, in every one of the 160 workgroups) and transpose in LDS
+    {
+        // (four 16-byte loads in flight per thread: the one-load-per-trip form was eleven dependent L2 round trips)
+        const float rK = __builtin_amdgcn_rcpf((float)K);
+        const int total4 = (K * Cout) >> 2;                   // Cout is a multiple of 16
+        for (int i0 = threadIdx.x; i0 < total4; i0 += 256 * 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i4 = i0 + 256 * u;
+                v[u] = i4 < total4 ? ld4(w + 4 * (size_t)i4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i4 = i0 + 256 * u;
+                if (i4 < total4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * i4 + e;
+                        int co = (int)((float)i * rK);
+                        int k = i - co * K;
+                        if (k < 0) { k += K; co -= 1; }
+                        if (k >= K) { k -= K; co += 1; }
+                        wl[k * CP + co] = v[u][e];
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -671,7 +696,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int ci = 0; ci < CIT; ++ci) {
-                const float* wk = wg + (ci * 9 + tap) * Cout;
+                const float* wk = wg + (ci * 9 + tap) * CP;
 #pragma unroll
                 for (int q = 0; q < QW; ++q) acc[q] += v[tap][ci] * ld4(wk + q * 4);
             }
@@ -685,7 +710,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
                 float v = ob;
                 if (ci < C) v = xn[ci * HW + ip] * (1.0f - ob) + x0n[ci * HW + ip] * ob;
                 v = inb ? v : 0.f;
-                const float* wk = wg + (ci * 9 + tap) * Cout;
+                const float* wk = wg + (ci * 9 + tap) * CP;
 #pragma unroll
                 for (int q = 0; q < QW; ++q) acc[q] += v * ld4(wk + q * 4);
             }
@@ -1018,7 +1043,7 @@ extern "C" int lfvdm_gn_temporal(const float* x, const float* gamma, const float
 static int conv_in_launch(const float* x, const float* x0, const float* obs, const float* w, const float* bias, float* out,
                           int N, int C, int H, int W, int Cout, const ConvInTick& tk, hipStream_t s) {
     if (N <= 0 || C <= 0 || Cout % 16 || Cout > 256 || H <= 0 || W <= 0) return LFVDM_E_SHAPE;
-    size_t lds = (size_t)(C + 1) * 9 * Cout * sizeof(float);
+    size_t lds = (size_t)(C + 1) * 9 * (Cout + 4) * sizeof(float);      // padded rows (see the kernel)
     if (lds > 64 * 1024) return LFVDM_E_UNSUPPORTED;
     if (lds < 64 * sizeof(int64_t)) lds = 64 * sizeof(int64_t);
     const long total = (long)N * H * W;

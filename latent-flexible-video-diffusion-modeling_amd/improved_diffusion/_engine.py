@@ -57,6 +57,9 @@ class _TableBudget:
 
     def reserve(self, plan, nbytes):
         if nbytes > self.remaining():
+            import gc
+            gc.collect()            # plans of dropped samplers may only be waiting for the cycle collector
+        if nbytes > self.remaining():
             return False
         key = id(plan)
         self._held[key] = nbytes

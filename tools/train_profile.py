@@ -48,7 +48,7 @@ for i in range(steps):
     loop.run_step(); loop.step += 1
     th.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"step {i}: {dt*1e3:8.2f} ms  fwd+bwd {acc['fb']*1e3:8.2f}  optimizer {acc['opt']*1e3:6.2f}  masks {acc['sample_all_masks']*1e3:6.2f}  micro {acc['_graphed_micro_step']*1e3:6.2f}  log {acc['_flush_loss_log']*1e3:6.2f}  replay(host) {acc.get('replay_host', 0)*1e3:6.2f}", flush=True)
-g = loop._graph_state.get("graph")
+g = loop._graph_state.get("graph") if "--replays" in sys.argv else None     # (extra replays would skew per-step kernel statistics)
 if g is not None:
     ts = []
     for _ in range(40):
