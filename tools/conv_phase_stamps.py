@@ -87,29 +87,29 @@ def main():
         L.lfvdm_debug_stamps(buf)
         rows = [[buf[w * NS + j] for j in range(NS)] for w in range(NW)]
         rows = [r for r in rows if r[0]]
+        # stamps older than the workgroup's own entry were left by the predecessor launch: not passed in this one
+        rows = [[x if x >= r[0] else 0 for x in r] for r in rows]
         t0 = min(r[0] for r in rows)
 
-        def med(f, sel=lambda r: True):
-            v = [f(r) for r in rows if sel(r)]
-            return st.median(v) / 100.0 if v else 0.0
+        def med(i, j, sel=lambda r: True):
+            """median over workgroups of stamp j - stamp i; None where a workgroup did not pass both"""
+            v = [r[j] - r[i] for r in rows if sel(r) and r[i] and r[j] and r[j] >= r[i]]
+            return st.median(v) / 100.0 if v else None
 
         split = any(r[4] for r in rows)
         last = (lambda r: r[6] > 0) if split else (lambda r: True)
         skew = (max(r[0] for r in rows) - t0) / 100.0
         span = (max(max(r) for r in rows) - t0) / 100.0
-        cols = [skew, med(lambda r: r[1] - r[0]), med(lambda r: r[2] - r[1]), med(lambda r: r[3] - r[2])]
+        cols = [skew, med(0, 1), med(1, 2), med(2, 3)]
         if split:
-            cols += [med(lambda r: r[4] - r[3]), med(lambda r: r[9] - r[4]), med(lambda r: r[10] - r[9]),
-                     med(lambda r: r[11] - r[10], last), med(lambda r: r[6] - r[5], last),
-                     med(lambda r: r[7] - r[6], last), med(lambda r: r[8] - r[7], last)]
+            cols += [med(3, 4), med(4, 9), med(9, 10), med(10, 11, last), med(5, 6, last), med(6, 7, last), med(7, 8, last)]
         else:
-            cols += [0, 0, 0, 0, 0, med(lambda r: r[7] - r[3]), med(lambda r: r[8] - r[7])]
+            cols += [None] * 5 + [med(3, 7), med(7, 8)]
         # finer split: first chunk landed (cold filters), GroupNorm: tile rewrite / statistics / last barrier / apply
-        cols += [med(lambda r: r[15] - r[1]), med(lambda r: r[12] - r[7], last), med(lambda r: r[13] - r[12], last),
-                 med(lambda r: r[14] - r[13], last), med(lambda r: r[8] - r[14], last)]
+        cols += [med(1, 15), med(7, 12, last), med(12, 13, last), med(13, 14, last), med(14, 8, last)]
         M = a.N * a.Ho * a.Wo
         print(f"{inst} {M:5d} {a.C0 + a.C1:3d} {a.Cout:4d} {a.ksize} {a.s2C0 + a.s2C1:3d} {int(bool(a.gn_out)):2d} {kz:2d} {len(rows):4d} | "
-              + " ".join(f"{c:5.2f}" for c in cols) + f" | {span:5.2f} {ev_us:5.2f}")
+              + " ".join("    -" if c is None else f"{c:5.2f}" for c in cols) + f" | {span:5.2f} {ev_us:5.2f}")
         if os.environ.get("STAMP_DUMP"):
             for r in sorted(rows, key=lambda r: r[0])[:int(os.environ["STAMP_DUMP"])]:
                 print("   ", [(x - t0) / 100.0 if x else None for x in r[:12]])

@@ -1,30 +1,33 @@
 #!/bin/bash
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun; results land in
-# gpurun_out/refresh/ and are copied into profiles/ by hand afterwards, prefixed with the round):
+# gpurun_out/refresh/ and are copied into profiles/ afterwards, prefixed with the round: ROUND=r03 by default):
 #   bash tools/refresh_profiles.sh
-# 1. default bench line (all legs)                         -> bench_line.json
-# 2. rocprofv3 kernel stats, sampling bench                -> bench_kernel_stats.csv
-# 3. rocprofv3 kernel stats, training step                 -> train_kernel_stats.csv
+# 1. rocprofv3 kernel stats, training step                 -> train_kernel_stats.csv (also placed in profiles/ on the
+#    box, so that the bench line's train.roofline.families is computed from THIS profile)
+# 2. default bench line (all legs)                         -> bench_line.json
+# 3. rocprofv3 kernel stats, sampling bench                -> bench_kernel_stats.csv
 # 4. PMC passes over eager denoising steps (tools/pmc_target.py), one counter group per pass:
 #    FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE  -> pmc_traffic.json (+ raw counter CSVs)
 # A step that is killed at its limit stops the chain.
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/refresh
+ROUND=${ROUND:-r03}
 rm -rf $OUT
 mkdir -p $OUT
 export LFVDM_TUNE_CACHE=$ROOT/profiles/tune_cache_mi355x.json      # read-only
 export LFVDM_TUNE_CACHE_OUT=$OUT/tune_cache_mi355x.json             # committed table + anything measured in these runs
 cd /tmp && export TMPDIR=/tmp
 step() { local lim=$1; shift; timeout -k 10 $lim "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed at its limit: stopping"; exit 1; fi; return 0; }
+step 300 rocprofv3 --kernel-trace --stats -d $OUT/tp -o tp --output-format csv -- python3 $ROOT/tools/train_profile.py 30 > $OUT/tp.log 2>&1
+cp $OUT/tp/tp_kernel_stats.csv $OUT/train_kernel_stats.csv
+cp $OUT/train_kernel_stats.csv $ROOT/profiles/${ROUND}_train_kernel_stats.csv
+echo "train profile done"
 step 500 python3 $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 echo "bench done"
 step 300 rocprofv3 --kernel-trace --stats -d $OUT/bp -o bp --output-format csv -- python3 $ROOT/bench.py --steps 300 --warmup 20 --train-steps 0 --pixel-steps 0 --long-video-windows 0 --no-cpu > $OUT/bp.log 2>&1
 cp $OUT/bp/bp_kernel_stats.csv $OUT/bench_kernel_stats.csv
 echo "bench profile done"
-step 300 rocprofv3 --kernel-trace --stats -d $OUT/tp -o tp --output-format csv -- python3 $ROOT/tools/train_profile.py 30 > $OUT/tp.log 2>&1
-cp $OUT/tp/tp_kernel_stats.csv $OUT/train_kernel_stats.csv
-echo "train profile done"
 step 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/pmc_target.py > $OUT/pmc_fetch.log 2>&1
 echo "pmc fetch done"
 step 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/pmc_target.py > $OUT/pmc_write.log 2>&1
@@ -32,6 +35,14 @@ echo "pmc write done"
 step 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ROOT/tools/pmc_target.py > $OUT/pmc_mfma.log 2>&1
 echo "pmc mfma done"
 python3 $ROOT/tools/pmc_summarize.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json $OUT/pmc_mfma
+# 5. in-kernel phase table of the implicit-GEMM launches (diagnostic build with -DLFVDM_STAMP, if present)
+if [ -f $ROOT/devlib/liblfvdm_stamp.so ]; then
+  cd $ROOT && step 200 python3 tools/conv_phase_stamps.py all > $OUT/conv_phase_stamps.txt 2>&1; cd /tmp
+  echo "phase stamps done"
+fi
+# 6. the parity tests that print their deviations from the reference fixtures
+cd $ROOT && step 400 python3 -m pytest tests/test_forward_gpu.py tests/test_sampler_gpu.py tests/test_train_gpu.py -m gpu -q -s --timeout 300 -k "reference or cfgC_training or replayed or full_size or fp64" > $OUT/parity_deviations.txt 2>&1; cd /tmp
+echo "parity deviations done"
 rm -rf $OUT/bp/*trace* $OUT/tp/*trace*
 [ -f $LFVDM_TUNE_CACHE_OUT ] || cp $LFVDM_TUNE_CACHE $LFVDM_TUNE_CACHE_OUT
 echo "refresh complete"
