@@ -184,17 +184,22 @@ int lfvdm_unpack_conv_grad(const float* g_packed, float* g_oihw, int Cout, int C
 typedef struct lfvdm_pack_job {
     const float* src;
     float* dst;
-    int32_t Cout, Cin, taps, transposed, blk0, pad_;
+    int32_t Cout, Cin, taps, transposed, blk0;
+    int32_t ld;      /* stride of the destination's fastest axis (0 = Cin / Cout): a larger value leaves zero-padded
+                        channels, written once by the caller - the 5-channel input conv and the 4-filter output conv
+                        are staged as 32-channel operands */
 } lfvdm_pack_job;
 int lfvdm_pack_conv_weights(const lfvdm_pack_job* jobs_dev, int njobs, int total_blocks, void* stream);
 
 /* Grouped version for a training step: every job folds one packed gradient [Cout][k*k][Cin] into the OIHW
  * parameter gradient (g += unpack(gp)) and zeroes gp for the next step.  row0 = first workgroup (filter row) of
- * the job, jobs sorted by row0; total_rows = sum of Cout; max_row_floats = max k*k*Cin (<= 16384). */
+ * the job, jobs sorted by row0; total_rows = sum of Cout; max_row_floats = max k*k*max(Cin, ldp) (<= 16384). */
 typedef struct lfvdm_unpack_job {
     float* gp;
     float* g;
     int32_t Cout, Cin, taps, row0;
+    int32_t ldp;     /* channel stride of gp (0 = Cin); > Cin for accumulators of zero-padded operands */
+    int32_t pad_;
 } lfvdm_unpack_job;
 int lfvdm_unpack_conv_grads(const lfvdm_unpack_job* jobs_dev, int njobs, int total_rows, int max_row_floats, void* stream);
 

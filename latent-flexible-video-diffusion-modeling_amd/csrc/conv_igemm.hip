@@ -998,4 +998,4 @@ extern "C" int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* n
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_abi_version(void) { return 7; }
+extern "C" int lfvdm_abi_version(void) { return 8; }

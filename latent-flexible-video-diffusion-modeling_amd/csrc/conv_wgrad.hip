@@ -650,17 +650,18 @@ __global__ __launch_bounds__(256) void unpack_conv_grads_kernel(const lfvdm_unpa
     while (j + 1 < njobs && jobs[j + 1].row0 <= (int)blockIdx.x) ++j;
     const lfvdm_unpack_job J = jobs[j];
     const int co = blockIdx.x - J.row0;
-    const int n = J.taps * J.Cin;
-    float* gp = J.gp + (size_t)co * n;
+    const int ldp = J.ldp ? J.ldp : J.Cin;       // the accumulator's channel stride (> Cin: zero-padded operand channels)
+    const int n = J.taps * J.Cin, np = J.taps * ldp;
+    float* gp = J.gp + (size_t)co * np;
     float* g = J.g + (size_t)co * n;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < np; i += 256) {
         urow[i] = gp[i];
         gp[i] = 0.f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256) {
         const int ci = i / J.taps, t = i - ci * J.taps;
-        g[i] += urow[t * J.Cin + ci];
+        g[i] += urow[t * ldp + ci];
     }
 }
 
@@ -691,17 +692,19 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const lfvdm_pack
     }
     __syncthreads();
     const int n = nco * nci * taps;
+    // ld > natural width: the destination keeps zero padding channels (written once by the host, never here)
+    const int ldd = J.ld ? J.ld : (J.transposed ? J.Cout : J.Cin);
     if (J.transposed) {
         for (int e = threadIdx.x; e < n; e += 256) {          // (ci, t, co) with co fastest
             const int r = qdiv(e, nco), c = e - r * nco;
             const int i = qdiv(r, taps), t = r - i * taps;
-            J.dst[((size_t)(ci0 + i) * taps + t) * J.Cout + co0 + c] = tile[c * row + i * taps + (taps - 1 - t)];
+            J.dst[((size_t)(ci0 + i) * taps + t) * ldd + co0 + c] = tile[c * row + i * taps + (taps - 1 - t)];
         }
     } else {
         for (int e = threadIdx.x; e < n; e += 256) {          // (co, t, ci) with ci fastest
             const int r = qdiv(e, nci), i = e - r * nci;
             const int c = qdiv(r, taps), t = r - c * taps;
-            J.dst[((size_t)(co0 + c) * taps + t) * J.Cin + ci0 + i] = tile[c * row + i * taps + t];
+            J.dst[((size_t)(co0 + c) * taps + t) * ldd + ci0 + i] = tile[c * row + i * taps + t];
         }
     }
 }

@@ -55,25 +55,38 @@ class _WeightPacks:
     def _stamp(base):
         return (nat.param_epoch[0], base._version)
 
-    @staticmethod
-    def _pack_one(key, out):
-        ptr_, (Cout, Cin, k, _), tr = key
+    def _pack_one(self, key, out):
+        ptr_, (Cout, Cin, k, _), tr, ld = key
+        if ld:      # zero-padded destination (input / output conv): rare single packs go through the library ops
+            e = self.ent.get(key)
+            base = e[0]() if e is not None else None
+            off = (ptr_ - base.data_ptr()) // 4
+            w4 = base.detach().reshape(-1)[off:off + Cout * Cin * k * k].view(Cout, Cin, k, k)
+            if tr:
+                out[:, :, :Cout].copy_(w4.flip(2, 3).reshape(Cout, Cin, k * k).permute(1, 2, 0))
+            else:
+                out[:, :, :Cin].copy_(w4.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin))
+            return
         fn = nat.lib().lfvdm_pack_conv_weight_t if tr else nat.lib().lfvdm_pack_conv_weight
         nat.check(fn(ptr_, out.data_ptr(), Cout, Cin, k, nat.stream()), "lfvdm_pack_conv_weight")
 
-    def get(self, w4, transposed):
+    def get(self, w4, transposed, ld=0):
+        """ld: channel stride of the packed copy when it is wider than the weight (zero padding channels: the 5-channel
+        input conv and the 4-filter output conv are staged as 32-channel operands); leaf parameters only."""
         base = w4._base if w4._base is not None else w4
         Cout, Cin, k, _ = w4.shape
         if not isinstance(base, nn.Parameter) or not w4.is_contiguous():
+            assert not ld, "padded packs are kept for leaf parameters only"
             out = _new(*((Cin, k * k, Cout) if transposed else (Cout, k * k, Cin)), like=w4)     # derived weight: pack now
             (nat.pack_conv_weight_t if transposed else nat.pack_conv_weight)(w4.contiguous(), out)
             return out
-        key = (w4.data_ptr(), tuple(w4.shape), bool(transposed))
+        key = (w4.data_ptr(), tuple(w4.shape), bool(transposed), int(ld))
         e = self.ent.get(key)
         if e is None or e[0]() is not base:       # new weight (or the address was re-used by another parameter)
-            out = _new(*((Cin, k * k, Cout) if transposed else (Cout, k * k, Cin)), like=w4)
-            self._pack_one(key, out)
+            shape = (Cin, k * k, ld or Cout) if transposed else (Cout, k * k, ld or Cin)
+            out = th.zeros(*shape, device=w4.device, dtype=th.float32) if ld else _new(*shape, like=w4)
             self.ent[key] = [weakref.ref(base), out, self._stamp(base)]
+            self._pack_one(key, out)
             self.table = None
             return out
         if e[2] != self._stamp(base):
@@ -85,7 +98,7 @@ class _WeightPacks:
         base = e[0]()
         if base is None:
             return False
-        ptr_, shape, _ = key
+        ptr_, shape = key[0], key[1]
         n = 1
         for d in shape:
             n *= d
@@ -116,8 +129,8 @@ class _WeightPacks:
                     self._restamp(e)
                 return
             jobs, blk = [], 0
-            for (ptr_, (Cout, Cin, k, _k), tr), e in self.ent.items():
-                jobs.append(nat.PackJob(ptr_, e[1].data_ptr(), Cout, Cin, k * k, int(tr), blk, 0))
+            for (ptr_, (Cout, Cin, k, _k), tr, ld), e in self.ent.items():
+                jobs.append(nat.PackJob(ptr_, e[1].data_ptr(), Cout, Cin, k * k, int(tr), blk, ld))
                 blk += ((Cout + 31) // 32) * ((Cin + 31) // 32)
             dev = next(iter(self.ent.values()))[1].device
             self.table, self.blocks, self.njobs = nat.jobs_to_device(jobs, dev), blk, len(jobs)
@@ -135,14 +148,14 @@ class _WeightPacks:
 _packs = _WeightPacks()
 
 
-def _pack(w):
+def _pack(w, ld=0):
     """OIHW -> [Cout][taps][Cin] (forward operand layout)."""
-    return _packs.get(w, False)
+    return _packs.get(w, False, ld)
 
 
-def _pack_t(w4):
+def _pack_t(w4, ld=0):
     """OIHW (or [O][I] as [O][I][1][1]) -> [Cin][taps][Cout], taps flipped (data-gradient operand)."""
-    return _packs.get(w4, True)
+    return _packs.get(w4, True, ld)
 
 
 def _grad_of(p):
@@ -164,12 +177,14 @@ class _PackedGrads:
         self.done = set()       # ids folded by partial folds of the running backward pass
         self.queued = False
 
-    def buffer(self, w):
+    def buffer(self, w, ld=0):
+        """ld: channel stride of the accumulator when the operand was zero-padded to more channels than the weight has."""
         ent = self.bufs.get(id(w))
-        if ent is None or ent[0]() is not w or ent[1].device != w.device:
+        if ent is None or ent[0]() is not w or ent[1].device != w.device or ent[1].shape[2] != (ld or w.shape[1]):
             Cout, Cin, k, _ = w.shape
-            ent = (weakref.ref(w), th.zeros(Cout, k * k, Cin, device=w.device, dtype=th.float32))
+            ent = (weakref.ref(w), th.zeros(Cout, k * k, ld or Cin, device=w.device, dtype=th.float32))
             self.bufs[id(w)] = ent
+            self.tables.clear()
         if not self.queued:     # fold at the end of the running backward pass (also under graph capture)
             self.queued = True
             th.autograd.Variable._execution_engine.queue_callback(self.flush)
@@ -201,9 +216,10 @@ class _PackedGrads:
             jobs, row0, mx = [], 0, 0
             for w, gp in live:
                 Cout, Cin, k, _ = w.shape
-                jobs.append(nat.UnpackJob(gp.data_ptr(), w.grad.data_ptr(), Cout, Cin, k * k, row0))
+                ldp = gp.shape[2]
+                jobs.append(nat.UnpackJob(gp.data_ptr(), w.grad.data_ptr(), Cout, Cin, k * k, row0, ldp if ldp != Cin else 0, 0))
                 row0 += Cout
-                mx = max(mx, k * k * Cin)
+                mx = max(mx, k * k * ldp)
             if len(self.tables) > 64:
                 self.tables.clear()
             ent = self.tables[key] = (nat.jobs_to_device(jobs, live[0][0].device), len(jobs), row0, mx)
@@ -238,9 +254,10 @@ def _wgrad_accumulate(w, b, **kw):
     linear weights straight into ``w.grad`` (packed == OIHW), 3x3 weights into their packed accumulator, which
     is folded into ``w.grad`` once per backward pass (``_PackedGrads``)."""
     kw.pop("ksize", None)
+    ld = kw.pop("ld", 0)
     k = w.shape[2] if w.dim() == 4 else 1
     gw = _grad_of(w)
-    out = _packed.buffer(w) if k == 3 else gw
+    out = _packed.buffer(w, ld) if k == 3 else gw
     gb = _grad_of(b) if b is not None else None
     nat.conv_wgrad(out=out, bias=gb, Cout=w.shape[0], ksize=k, out_mode=0, **kw)
 
@@ -266,27 +283,31 @@ class ConvFn(th.autograd.Function):
     (Downsample / Upsample of reference unet.py:60-114)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, N, H, W, stride, up):
-        Cout, Cin = w.shape[0], w.shape[1]
+    def forward(ctx, x, w, b, N, H, W, stride, up, cin_pad=0):
+        """cin_pad: the rows carry this many channels, of which the weight's Cin are real (the 5-channel input conv on
+        32-channel rows; in-place gradient mode only: the padded operand packs belong to leaf parameters)."""
+        Cout, Cin = w.shape[0], cin_pad or w.shape[1]
         Hin, Win = (2 * H, 2 * W) if up else (H, W)
         Ho, Wo = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
         out = _new(N * Ho * Wo, Cout, like=x)
-        nat.conv_igemm(src0=x, C0=Cin, N=N, Hs=H, Ws=W, up=int(up), stride=stride, Ho=Ho, Wo=Wo, W=_pack(w), bias=b,
+        nat.conv_igemm(src0=x, C0=Cin, N=N, Hs=H, Ws=W, up=int(up), stride=stride, Ho=Ho, Wo=Wo, W=_pack(w, cin_pad), bias=b,
                        Cout=Cout, out=out, ldo=Cout)
         ctx.save_for_backward(x, w)
         ctx.params = (w, b) if _leaf(w, b) else None   # in-place mode: accumulate into .grad
+        assert ctx.params is not None or not cin_pad
         ctx.geom = (N, H, W, stride, up, Ho, Wo)
+        ctx.cin_pad = cin_pad
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, w = ctx.saved_tensors
         N, H, W, stride, up, Ho, Wo = ctx.geom
-        Cout, Cin = w.shape[0], w.shape[1]
+        Cout, Cin = w.shape[0], ctx.cin_pad or w.shape[1]
         dout = dout.contiguous()
         wkw = dict(src0=x, C0=Cin, N=N, Hs=H, Ws=W, up=int(up), stride=stride, Ho=Ho, Wo=Wo, res=dout, ldr=Cout)
         if ctx.params is not None:
-            _wgrad_accumulate(ctx.params[0], ctx.params[1], **wkw)
+            _wgrad_accumulate(ctx.params[0], ctx.params[1], ld=ctx.cin_pad, **wkw)
             dw = db = None
         else:
             dw, db = _wgrad_into(tuple(w.shape), x, **wkw)
@@ -305,7 +326,7 @@ class ConvFn(th.autograd.Function):
                     dx = dfull.view(N, H, 2, W, 2, Cin).sum(dim=(2, 4)).reshape(N * H * W, Cin).contiguous()
                 else:
                     dx = dfull
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- linear on rows
@@ -525,6 +546,9 @@ class ResBlockFn(th.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- output head
+_head_rows = {}      # (rows, channels, device) -> zero-padded gradient rows of the output head (in-place mode)
+
+
 class HeadFn(th.autograd.Function):
     """out = conv3x3(SiLU(GN(h))) written in the (B,T,C,H,W) frame layout (reference unet.py:399-403,462-464)."""
 
@@ -537,6 +561,7 @@ class HeadFn(th.autograd.Function):
                        out_mode=nat.OUT_NCHW)
         ctx.save_for_backward(h, g, be, w, cA, cB, st, act)
         ctx.inplace = _leaf(g, be)
+        ctx.params = (w, b) if _leaf(w, b) else None
         ctx.geom = (N, H, W)
         return out
 
@@ -547,9 +572,22 @@ class HeadFn(th.autograd.Function):
         C, Cout, P = h.shape[1], w.shape[0], H * W
         # rows [M][32]: the data-gradient GEMM reduces over Cout, padded to one 32-channel chunk
         CP = (Cout + 31) // 32 * 32
+        geo = dict(N=N, Hs=H, Ws=W, Ho=H, Wo=W)
+        if ctx.params is not None:
+            # in-place mode: persistent zero-padded rows (only the real channels are rewritten), the weight gradient
+            # accumulated like any other 3x3 layer's, the data-gradient operand from the padded pack of the parameter
+            key = (N * P, CP, h.device)
+            drows = _head_rows.get(key)
+            if drows is None:
+                drows = _head_rows[key] = th.zeros(N * P, CP, device=h.device, dtype=th.float32)
+            drows.view(N, P, CP)[:, :, :Cout].copy_(dout.reshape(N, Cout, P).permute(0, 2, 1))
+            _wgrad_accumulate(ctx.params[0], ctx.params[1], src0=act, C0=C, res=drows, ldr=CP, **geo)
+            da = _new(N * P, C, like=h)
+            nat.conv_igemm(src0=drows, C0=CP, W=_pack_t(w, CP), Cout=C, out=da, ldo=C, **geo)
+            dh, _, dg, dbe, _ = _gn_backward(da, h, None, C, 0, N, P, cA, cB, st, nat.ACT_SILU, g, be, None, 1, inplace=ctx.inplace)
+            return dh, dg, dbe, None, None, None, None, None
         drows = th.zeros(N * P, CP, device=h.device, dtype=th.float32)
         drows[:, :Cout] = dout.permute(0, 2, 3, 1).reshape(N * P, Cout)
-        geo = dict(N=N, Hs=H, Ws=W, Ho=H, Wo=W)
         gp = th.zeros(CP, 9, C, device=h.device, dtype=th.float32)
         dbp = th.zeros(CP, device=h.device, dtype=th.float32)
         nat.conv_wgrad(src0=act, C0=C, res=drows, ldr=CP, out=gp, bias=dbp, Cout=CP, **geo)
@@ -1031,8 +1069,13 @@ class UNetFunction:
                                                    nat.ptr(obs.reshape(N).contiguous()), nat.ptr(rows), N, Cx, H, W, 32,
                                                    nat.stream()), "lfvdm_compose_rows")
         conv0 = m.input_blocks[0][0]
-        w0 = F.pad(conv0.weight, (0, 0, 0, 0, 0, 32 - (Cx + 1)))
-        h = ConvFn.apply(rows, w0, conv0.bias, N, H, W, 1, False)
+        if _leaf(conv0.weight, conv0.bias) and not rows.requires_grad:
+            # the weight's 5 input channels are packed into a 32-channel operand whose padding stays zero, and the weight
+            # gradient is accumulated in the same shape and folded with the others (no pad / slice / add launches)
+            h = ConvFn.apply(rows, conv0.weight, conv0.bias, N, H, W, 1, False, 32)
+        else:
+            w0 = F.pad(conv0.weight, (0, 0, 0, 0, 0, 32 - (Cx + 1)))
+            h = ConvFn.apply(rows, w0, conv0.bias, N, H, W, 1, False)
         cur = (h, H, W)
         hs = [cur]
 

@@ -61,7 +61,7 @@ class RowdotBwdJob(C.Structure):
 
 class PackJob(C.Structure):
     _fields_ = [("src", c_fp), ("dst", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32),
-                ("transposed", C.c_int32), ("blk0", C.c_int32), ("pad_", C.c_int32)]
+                ("transposed", C.c_int32), ("blk0", C.c_int32), ("ld", C.c_int32)]
 
 
 # bumped by code that rewrites parameters through raw pointers (the fused AdamW): cached packed weights are stale
@@ -69,7 +69,8 @@ param_epoch = [0]
 
 
 class UnpackJob(C.Structure):
-    _fields_ = [("gp", c_fp), ("g", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("row0", C.c_int32)]
+    _fields_ = [("gp", c_fp), ("g", c_fp), ("Cout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("row0", C.c_int32),
+                ("ldp", C.c_int32), ("pad_", C.c_int32)]
 
 
 class RpeJob(C.Structure):
