@@ -270,11 +270,13 @@ int lfvdm_gn_bwd_apply_params(const float* da, const float* src0, const float* s
                               const float* film, int film_ld, int T, float* dgamma, float* dbeta, float* dfilm,
                               int dfilm_ld, const float* add, int add_ld, void* stream);
 /* lfvdm_gn_bwd_stats + lfvdm_gn_bwd_apply_params in ONE launch (the training path): the per-channel sums stay in the
- * workgroup that owns the (sample, 8 groups) slice; dx is written (not accumulated) to out0 / out1. */
+ * workgroup that owns the (sample, 8 groups) slice; dx is written (not accumulated) to out0 / out1.  add2 (optional, like
+ * add): a third gradient of the same input - what the decoder's skip connection sends back to an encoder output. */
 int lfvdm_gn_bwd_fused(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
                        const float* coefA, const float* coefB, const float* stats, int act, float* out0, float* out1,
                        const float* gamma, const float* beta, const float* film, int film_ld, int T, float* dgamma,
-                       float* dbeta, float* dfilm, int dfilm_ld, const float* add, int add_ld, void* stream);
+                       float* dbeta, float* dfilm, int dfilm_ld, const float* add, int add_ld, const float* add2,
+                       int add2_ld, void* stream);
 /* GroupNorm(+FiLM) parameter gradients from the sums of lfvdm_gn_bwd_stats: dgamma / dbeta [C] are ACCUMULATED
  * (+=, fixed order), dfilm [N/T][2C] (d scale | d shift of unet.py:199-203; row strides film_ld / dfilm_ld) is
  * written when film != NULL. */

@@ -99,7 +99,8 @@ __device__ __forceinline__ int div_small(int a, int d) {
 }
 
 template <int WM, int WN, int WK, int NT, int KCH, bool SIMPLE, int GL>
-__global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfvdm_conv_args p_in, int hyb_nfull, int hyb_kz) {
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfvdm_conv_args p_in, int hyb_nfull, int hyb_kz,
+                                                                        int par_mt) {
     const lfvdm_conv_args p = p_in;   // private SSA copy: helpers take it by reference (keeps it out of scratch)
     using CF = Cfg<WM, WN, WK, NT, KCH, GL>;
     static_assert(GL == 2 || GL == 3, "two or three LDS-DMA stages");
@@ -118,12 +119,22 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     const int wm = wmn / WN, wn = wmn - wm * WN;
     const int gt = tid - wk * CF::GT;
     const int HoWo = p.Ho * p.Wo;
-    const int M = p.N * HoWo;
+    // Zero-inserted source (up == 2: the data gradient of a stride-2 convolution) BY OUTPUT PARITY (par_mt > 0, plain
+    // grid, gridDim.x = 4 * par_mt): an output pixel (oy, ox) only sees the taps with oy + dy and ox + dx even, i.e. 1, 2,
+    // 2 or 4 of the 9 depending on (oy & 1, ox & 1).  A workgroup takes rows of ONE parity class - enumerated on the
+    // source grid, M = N * Hs * Ws per class - and loops over that class's taps only: 9/4 taps per output pixel on
+    // average instead of 9 with three quarters of the staged pieces zero.  Heavy classes (4 taps) get the low block ids.
+    const bool par = !SIMPLE && par_mt > 0;
+    int pcls = 0;
+    if (par) pcls = 3 - div_small((int)blockIdx.x, par_mt);
+    const int ppy = pcls >> 1, ppx = pcls & 1;
+    const int M = par ? p.N * p.Hs * p.Ws : p.N * HoWo;
     // Workgroup -> (output tile, K slice).  Plain launches: grid (m tiles, n tiles, KZ slices).  "Tail split"
     // launches (hyb_kz > 0, flat grid): the first hyb_nfull tiles - a multiple of the CU count - are computed whole,
     // each remaining tile by hyb_kz workgroups, so that the last, partial wave of tiles does not cost a full tile time.
     int bx = blockIdx.x, by = blockIdx.y, KZ = gridDim.z, kz = blockIdx.z;
     size_t tile_id = (size_t)by * gridDim.x + bx;          // ticket / slab index of this tile
+    if (par) bx -= (3 - pcls) * par_mt;
     if (hyb_kz > 0) {
         const int MT = (M + BM - 1) / BM;
         const int b = blockIdx.x;
@@ -160,7 +171,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     const int n0 = by * BN;
     const int Cin = p.C0 + p.C1;
     const int taps = p.ksize * p.ksize;
-    const int NK1 = taps * (int)((unsigned)Cin / (unsigned)KC);
+    const int ltaps = par ? (1 + ppy) * (1 + ppx) : taps;      // taps the K loop walks (parity classes: the live ones)
+    const int NK1 = ltaps * (int)((unsigned)Cin / (unsigned)KC);
     const int NK = NK1 + (int)((unsigned)(p.s2C0 + p.s2C1) / (unsigned)KC);
 
     STAMP(0);
@@ -186,7 +198,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     RowInfo ri[CF::AE];
     auto decode_rows = [&]() {
         // quotients here are sample / image-row indices (< 2^21): the 1-ulp reciprocal is exact after fast_div's fix-up
-        const float rHoWo = __builtin_amdgcn_rcpf((float)HoWo), rWo = __builtin_amdgcn_rcpf((float)p.Wo);
+        const int dHW = par ? p.Hs * p.Ws : HoWo, dW = par ? p.Ws : p.Wo;     // grid the rows are enumerated on
+        const float rHoWo = __builtin_amdgcn_rcpf((float)dHW), rWo = __builtin_amdgcn_rcpf((float)dW);
         const int Hin = p.up ? 2 * p.Hs : p.Hs, Win = p.up ? 2 * p.Ws : p.Ws;
 #pragma unroll
         for (int j = 0; j < CF::AE; ++j) {
@@ -194,10 +207,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             ri[j].valid = m < M;
             const int mm = ri[j].valid ? m : 0;
             ri[j].m = mm;
-            ri[j].n = fast_div(mm, HoWo, rHoWo);
-            const int rem = mm - ri[j].n * HoWo;
-            ri[j].oy = fast_div(rem, p.Wo, rWo);
-            ri[j].ox = rem - ri[j].oy * p.Wo;
+            ri[j].n = fast_div(mm, dHW, rHoWo);
+            const int rem = mm - ri[j].n * dHW;
+            ri[j].oy = fast_div(rem, dW, rWo);
+            ri[j].ox = rem - ri[j].oy * dW;
+            if (par) {
+                ri[j].oy = 2 * ri[j].oy + ppy;
+                ri[j].ox = 2 * ri[j].ox + ppx;
+            }
             const int cy = ri[j].oy * p.stride, cx = ri[j].ox * p.stride;
             ri[j].pix = (ri[j].n * p.Hs + cy) * p.Ws + cx;
             // bit t = 3 * (dy + 1) + (dx + 1): tap inside the image.  The centre row / column always is (conv arithmetic
@@ -305,13 +322,18 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
     // scalar state and advanced after every issue - one division per kernel instead of one per chunk.  Chunks past the
     // group's slice (kc_raw >= kend: padding iterations of a group that owns fewer chunks) pass out-of-range offsets
     // on every lane, whatever the pair says.
-    int nx_ci = div_small(kbeg, taps), nx_tap = kbeg - nx_ci * taps;
+    int nx_ci = div_small(kbeg, ltaps), nx_tap = kbeg - nx_ci * ltaps;
     auto issue = [&](int kc_raw, int stage, bool doA = true, bool doW = true) {   // all but the per-lane offsets is wave-uniform
         const bool live = kc_raw < kend;
         const bool main_seg = SIMPLE ? true : kc_raw < NK1;
-        const int ci = main_seg ? nx_ci : kc_raw - NK1, tap = main_seg ? nx_tap : 0, cc = ci * KC;
+        const int ci = main_seg ? nx_ci : kc_raw - NK1, cc = ci * KC;
+        int tap = main_seg ? nx_tap : 0;
+        if (par) {      // l-th live tap of the class: dy = 0 (even rows) or -1, +1 (odd rows), the same for dx
+            const int ty = ppx ? (tap >> 1) : tap, tx = ppx ? (tap & 1) : 0;
+            tap = 3 * (ppy ? 2 * ty : 1) + (ppx ? 2 * tx : 1);
+        }
         nx_tap += 1;
-        if (nx_tap == taps) { nx_tap = 0; nx_ci += 1; }
+        if (nx_tap == ltaps) { nx_tap = 0; nx_ci += 1; }
         const int c0 = sel(main_seg, pC0, pS0);
         const bool second = SIMPLE ? false : cc >= c0;
         const int cl = second ? cc - c0 : cc;
@@ -539,13 +561,24 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         if (p.bias2) bsum += ld4(p.bias2 + cc);
         f32x4 rv[EPV], ra[EPV], rb[EPV];
         const float rHoWo = 1.0f / (float)HoWo;
+        // parity classes: class row (n, i, j) of the source grid -> output row (n, 2i + py, 2j + px)
+        const int sHW = p.Hs * p.Ws;
+        const float rsHW = __builtin_amdgcn_rcpf((float)sHW), rsW = __builtin_amdgcn_rcpf((float)p.Ws);
+        auto out_row = [&](int m) {
+            if (!par) return m;
+            const int n = fast_div(m, sHW, rsHW), rem = m - n * sHW;
+            const int i = fast_div(rem, p.Ws, rsW), j = rem - i * p.Ws;
+            return (n * p.Ho + 2 * i + ppy) * p.Wo + 2 * j + ppx;
+        };
+        int mo[EPV];
 #pragma unroll
         for (int i = 0; i < EPV; ++i) {
             const int m = min(m0 + min(row0 + i * RSTEP, BM - 1), M - 1);
+            mo[i] = out_row(m);
             rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             ra[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
             rb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (p.res) rv[i] = ld4(p.res + (unsigned)(m * p.ldr + cc));
+            if (p.res) rv[i] = ld4(p.res + (unsigned)(mo[i] * p.ldr + cc));
             if (p.resA) {
                 const int n = fast_div(m, HoWo, rHoWo);
                 ra[i] = ld4(p.resA + (unsigned)(n * p.Cout + cc));
@@ -566,7 +599,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
             if (p.res) t += rv[i] * ra[i] + rb[i];
             tv[i] = t;
             const int m = m0 + row;
-            if (store_raw && m < M && cok && row0 + i * RSTEP < BM) st4(p.out + ((size_t)m * p.ldo + co), t);
+            if (store_raw && m < M && cok && row0 + i * RSTEP < BM) st4(p.out + ((size_t)mo[i] * p.ldo + co), t);
         }
         STAMP(7);
         if (gn) {
@@ -715,6 +748,13 @@ inline HybridPlan hybrid_plan(long tiles) {
     return h;
 }
 
+// zero-inserted source handled by output parity classes (see the kernel): the data gradient of a stride-2 convolution
+inline bool parity_classes(const lfvdm_conv_args* a) {
+    static const bool off = getenv("LFVDM_CONV_NO_PARITY") != nullptr;        // A/B aid
+    return !off && a->up == 2 && a->ksize == 3 && a->stride == 1 && a->C1 == 0 && a->s2C0 + a->s2C1 == 0 && !a->gn_out &&
+           !a->resA && a->out_mode == LFVDM_OUT_ROWS;
+}
+
 template <int WM, int WN, int WK, int NT, int KCH, bool SIMPLE, int GL>
 int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
     using CF = Cfg<WM, WN, WK, NT, KCH, GL>;
@@ -723,22 +763,32 @@ int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
     if (int rc = limit.ensure(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), CF::LDS_BYTES))
         return rc;
     const long MT = (M + CF::BM - 1) / CF::BM, NT2 = (a->Cout + CF::BN - 1) / CF::BN;
+    if constexpr (!SIMPLE) {
+        if (parity_classes(a)) {
+            const long MTc = (M / 4 + CF::BM - 1) / CF::BM;
+            if (kz == kHybridKz || 4 * MTc >= (1L << 20)) return LFVDM_E_UNSUPPORTED;
+            hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), dim3((unsigned)(4 * MTc), (unsigned)NT2, (unsigned)kz),
+                               dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0, (int)MTc);
+            LFVDM_CHECK_LAUNCH();
+            return LFVDM_OK;
+        }
+    }
     if (kz == kHybridKz) {   // tail split (see the kernel): flat grid
         const HybridPlan h = hybrid_plan(MT * NT2);
         hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), dim3((unsigned)(h.nfull + h.tail * h.kz)),
-                           dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, (int)h.nfull, h.kz);
+                           dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, (int)h.nfull, h.kz, 0);
         LFVDM_CHECK_LAUNCH();
         return LFVDM_OK;
     }
     static const bool no_xmap = getenv("LFVDM_CONV_NO_XCD_MAP") != nullptr;       // A/B aid
     if (!no_xmap && (NT2 * kz) % 8 == 0 && MT * NT2 * kz < (1L << 20)) {   // XCD-aware map (see the kernel): flat grid
         hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), dim3((unsigned)(MT * NT2 * kz)), dim3(CF::NTHREADS),
-                           CF::LDS_BYTES, s, *a, (int)NT2, -kz);
+                           CF::LDS_BYTES, s, *a, (int)NT2, -kz, 0);
         LFVDM_CHECK_LAUNCH();
         return LFVDM_OK;
     }
     const dim3 grid((unsigned)MT, (unsigned)NT2, (unsigned)kz);
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), grid, dim3(CF::NTHREADS), CF::LDS_BYTES, s, *a, 0, 0, 0);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
@@ -845,14 +895,17 @@ bool cfg_valid(const lfvdm_conv_args* a, int id, int kch, int kz, int gl) {
     if (a->gn_out && !gn_tile_ok(a, BM, BN)) return false;
     const bool can64 = Cin % 64 == 0 && a->C0 % 64 == 0 && C2 % 64 == 0 && a->s2C0 % 64 == 0;
     if (kch == 64 && (!can64 || c.NT > 1)) return false;
-    const int NK = a->ksize * a->ksize * (Cin / kch) + C2 / kch;
+    const bool pc = parity_classes(a);
+    // (parity classes: the lightest class walks ONE tap)
+    const int NK = pc ? Cin / kch : a->ksize * a->ksize * (Cin / kch) + C2 / kch;
     if (c.WK > NK) return false;
+    if (pc && kz == kHybridKz) return false;
     if (glds_lds_bytes(c.WM, c.WN, c.WK, c.NT, kch, gl) > 160 * 1024) return false;
     // split-K over workgroups needs the caller's workspace (slabs + tile tickets) and the rows layout
     if (kz > 1) {
         if (!a->splitk_ws || !a->splitk_cnt || a->out_mode != LFVDM_OUT_ROWS) return false;
         const long M = (long)a->N * a->Ho * a->Wo;
-        const long tiles = ((M + BM - 1) / BM) * ((a->Cout + BN - 1) / BN);
+        const long tiles = (pc ? 4 * ((M / 4 + BM - 1) / BM) : (M + BM - 1) / BM) * ((a->Cout + BN - 1) / BN);
         if (kz == kHybridKz) {
             const HybridPlan h = hybrid_plan(tiles);
             if (h.nfull == 0 || h.tail == 0 || 4 * h.tail > 3 * kNumCUs || NK < h.kz * c.WK) return false;

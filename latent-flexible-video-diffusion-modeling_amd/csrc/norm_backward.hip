@@ -82,6 +82,8 @@ struct GnParamGradArgs {
     int film_ld, dfilm_ld, T;
     const float* add;     // optional [N*P][add_ld] rows added to dx (the skip path's gradient of a ResBlock input)
     int add_ld;
+    const float* add2;    // a second optional addend (the gradient the decoder's skip connection sends to the same tensor)
+    int add2_ld;
 };
 
 __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
         float* o = out + (pos0 + p) * Cd + cd;
         if (acc) dx += ld4(o);
         if (pg.add != nullptr) dx += ld4(pg.add + (pos0 + p) * pg.add_ld + c);
+        if (pg.add2 != nullptr) dx += ld4(pg.add2 + (pos0 + p) * pg.add2_ld + c);
         st4(o, dx);
     }
 }
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_fused_kernel(
             x[u] = ldcat(s0, s1p, C0, C1, pos0 + pp, c);
             dz[u] = ld4(da + (pos0 + pp) * C + c);
             ad[u] = pg.add != nullptr ? ld4(pg.add + (pos0 + pp) * pg.add_ld + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (pg.add2 != nullptr) ad[u] += ld4(pg.add2 + (pos0 + pp) * pg.add2_ld + c);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -609,7 +613,7 @@ extern "C" int lfvdm_gn_bwd_apply(const float* da, const float* src0, const floa
     const int C = C0 + C1;
     if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
     if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
-    const GnParamGradArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, nullptr, 0};
+    const GnParamGradArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, nullptr, 0, nullptr, 0};
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
                        C0, C1, P, coefA, coefB, stats, sums, act, out0, out1, acc0, acc1, none);
     LFVDM_CHECK_LAUNCH();
@@ -628,7 +632,7 @@ extern "C" int lfvdm_gn_bwd_apply_params(const float* da, const float* src0, con
     if (!dgamma || !dbeta) return LFVDM_E_SHAPE;
     if (add && (add_ld < C || add_ld % 4)) return LFVDM_E_SHAPE;
     if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T || film_ld < 2 * C || dfilm_ld < 2 * C)) return LFVDM_E_SHAPE;
-    const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1, add, add_ld};
+    const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1, add, add_ld, nullptr, 0};
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
                        C0, C1, P, coefA, coefB, stats, sums, act, out0, out1, acc0, acc1, pg);
     LFVDM_CHECK_LAUNCH();
@@ -639,14 +643,15 @@ extern "C" int lfvdm_gn_bwd_fused(const float* da, const float* src0, const floa
                                   const float* coefA, const float* coefB, const float* stats, int act, float* out0,
                                   float* out1, const float* gamma, const float* beta, const float* film, int film_ld, int T,
                                   float* dgamma, float* dbeta, float* dfilm, int dfilm_ld, const float* add, int add_ld,
-                                  void* stream) {
+                                  const float* add2, int add2_ld, void* stream) {
     const int C = C0 + C1;
     if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024) return LFVDM_E_SHAPE;
     if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
     if (!dgamma || !dbeta) return LFVDM_E_SHAPE;
     if (add && (add_ld < C || add_ld % 4)) return LFVDM_E_SHAPE;
+    if (add2 && (add2_ld < C || add2_ld % 4)) return LFVDM_E_SHAPE;
     if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T || film_ld < 2 * C || dfilm_ld < 2 * C)) return LFVDM_E_SHAPE;
-    const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1, add, add_ld};
+    const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1, add, add_ld, add2, add2_ld};
     hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
                        C0, C1, P, coefA, coefB, stats, act, out0, out1, pg);
     LFVDM_CHECK_LAUNCH();

@@ -277,13 +277,32 @@ def _wgrad_into(grad_w_shape, like, **kw):
     return g, db
 
 
+_SKIP_SLOTS = os.environ.get("LFVDM_NO_SKIP_SLOTS") is None      # A/B aid
+
+
+class _SkipSlot:
+    """Hand-off of a skip connection's gradient (in-place mode).  An encoder output h feeds the next stage AND a decoder
+    ResBlock; autograd would sum the two gradients of h with an add kernel per skip.  Instead the decoder block (whose
+    backward always runs first: it comes later in the forward pass) leaves its gradient here and returns nothing for h,
+    and the kernel that produces the next stage's gradient of h adds it on the way out (``res`` of the data-gradient
+    GEMM, ``add2`` of the fused GroupNorm backward)."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+    def take(self):
+        g, self.g = self.g, None
+        return g
+
+
 # ----------------------------------------------------------------------------- plain conv (in / down / up)
 class ConvFn(th.autograd.Function):
     """3x3 conv on channels-last rows [N*H*W][Cin] with optional stride 2 / nearest-2x upsample
     (Downsample / Upsample of reference unet.py:60-114)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, N, H, W, stride, up, cin_pad=0):
+    def forward(ctx, x, w, b, N, H, W, stride, up, cin_pad=0, x_slot=None):
         """cin_pad: the rows carry this many channels, of which the weight's Cin are real (the 5-channel input conv on
         32-channel rows; in-place gradient mode only: the padded operand packs belong to leaf parameters)."""
         Cout, Cin = w.shape[0], cin_pad or w.shape[1]
@@ -297,6 +316,8 @@ class ConvFn(th.autograd.Function):
         assert ctx.params is not None or not cin_pad
         ctx.geom = (N, H, W, stride, up, Ho, Wo)
         ctx.cin_pad = cin_pad
+        ctx.x_slot = x_slot      # _SkipSlot: a gradient of x that the decoder leaves for this node to add
+        assert x_slot is None or stride == 2
         return out
 
     @staticmethod
@@ -317,7 +338,9 @@ class ConvFn(th.autograd.Function):
             if stride == 2:   # transposed conv: zero-insertion gather of dout on the (2Ho x 2Wo) grid
                 assert 2 * Ho == H and 2 * Wo == W, "stride-2 data gradient needs even sizes"
                 dx = _new(N * H * W, Cin, like=x)
-                nat.conv_igemm(src0=dout, C0=Cout, N=N, Hs=Ho, Ws=Wo, up=2, Ho=H, Wo=W, W=wt, Cout=Cin, out=dx, ldo=Cin)
+                extra = ctx.x_slot.take() if ctx.x_slot is not None else None
+                rkw = dict(res=extra, ldr=Cin) if extra is not None else {}
+                nat.conv_igemm(src0=dout, C0=Cout, N=N, Hs=Ho, Ws=Wo, up=2, Ho=H, Wo=W, W=wt, Cout=Cin, out=dx, ldo=Cin, **rkw)
             else:
                 Hin, Win = (2 * H, 2 * W) if up else (H, W)
                 dfull = _new(N * Hin * Win, Cin, like=x)
@@ -326,7 +349,7 @@ class ConvFn(th.autograd.Function):
                     dx = dfull.view(N, H, 2, W, 2, Cin).sum(dim=(2, 4)).reshape(N * H * W, Cin).contiguous()
                 else:
                     dx = dfull
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- linear on rows
@@ -395,10 +418,12 @@ def _gn_forward(a, b, C0, C1, N, P, gamma, beta, film, T):
 
 
 def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, T, want_dx=(True, True), dfilm_out=None,
-                 inplace=False, add=None):
-    """Returns (dx_a, dx_b, dgamma, dbeta, dfilm).  da: [N*P][C] gradient w.r.t. act(GN(x)).  add: optional
-    [N*P][C] rows (a second gradient of the same input) folded into dx by the in-place kernel."""
+                 inplace=False, add=None, add2=None):
+    """Returns (dx_a, dx_b, dgamma, dbeta, dfilm).  da: [N*P][C] gradient w.r.t. act(GN(x)).  add, add2: optional
+    [N*P][C] rows (further gradients of the same input) folded into dx by the in-place kernel."""
     C = C0 + C1
+    if add2 is not None and not (inplace and not nat.deterministic()):
+        add = add2 if add is None else add + add2
     L = nat.lib()
     dxa = _new(N * P, C0, like=da)
     dxb = _new(N * P, C1, like=da) if C1 else None
@@ -433,7 +458,7 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
             film.data_ptr() if film is not None else None, film.stride(0) if film is not None else 0, T,
             nat.ptr(_grad_of(gamma)), nat.ptr(_grad_of(beta)), dfilm.data_ptr() if dfilm is not None else None,
             dfilm.stride(0) if dfilm is not None else 0, nat.ptr(add), add.stride(0) if add is not None else 0,
-            nat.stream()), "lfvdm_gn_bwd_fused")
+            nat.ptr(add2), add2.stride(0) if add2 is not None else 0, nat.stream()), "lfvdm_gn_bwd_fused")
         return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
     sums = _new(N, C, 2, like=da)
     nat.check(L.lfvdm_gn_bwd_stats(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
@@ -475,7 +500,10 @@ class ResBlockFn(th.autograd.Function):
     """reference unet.py:194-207 with use_scale_shift_norm=True, on a virtual concat input (a | b)."""
 
     @staticmethod
-    def forward(ctx, a, b, film, g1, be1, w1, b1, g2, be2, w2, b2, ws, bs, N, H, W, T, dfilm_slot=None, drop_p=0.0):
+    def forward(ctx, a, b, film, g1, be1, w1, b1, g2, be2, w2, b2, ws, bs, N, H, W, T, dfilm_slot=None, drop_p=0.0,
+                a_slot=None, b_slot=None):
+        """a_slot / b_slot (``_SkipSlot``, in-place mode): a_slot holds a further gradient of ``a`` to be added to this
+        node's; b_slot receives this node's gradient of ``b`` instead of autograd."""
         C0 = a.shape[1]
         C1 = b.shape[1] if b is not None else 0
         Cin, Cout, P = C0 + C1, w1.shape[0], H * W
@@ -497,8 +525,9 @@ class ResBlockFn(th.autograd.Function):
         ctx.save_for_backward(a, b, film, g1, be1, w1, g2, be2, w2, ws, h1, cA1, cB1, st1, cA2, cB2, st2, act1, act2, keep)
         ctx.params = (w1, b1, w2, b2, ws, bs)
         ctx.inplace = _leaf(g1, be1, w1, b1, g2, be2, w2, b2, ws, bs)
-        assert ctx.inplace or dfilm_slot is None
+        assert ctx.inplace or (dfilm_slot is None and a_slot is None and b_slot is None)
         ctx.dfilm_slot = dfilm_slot
+        ctx.a_slot, ctx.b_slot = a_slot, b_slot
         ctx.geom = (N, H, W, T, C0, C1, Cout)
         return out
 
@@ -534,15 +563,22 @@ class ResBlockFn(th.autograd.Function):
         nat.conv_igemm(src0=dh1, C0=Cout, W=_pack_t(w1), Cout=Cin, out=da1, ldo=Cin, **geo)
         # skip path first: its gradient w.r.t. the block input is folded into the GroupNorm-1 backward launch
         dws = dbs = None
+        extra = ctx.a_slot.take() if ctx.a_slot is not None else None      # the decoder's gradient of `a` (C1 == 0 then)
         if ws is None:
             skip_grad = dout                       # identity skip (C1 == 0, Cin == Cout)
         else:
             dws, dbs = wgrad(pws, pbs, src0=a, src1=b, C0=C0, C1=C1, ksize=1, res=dout, ldr=Cout, **geo)
             skip_grad = _new(N * P, Cin, like=a)
-            nat.conv_igemm(src0=dout, C0=Cout, ksize=1, W=_pack_t(ws), Cout=Cin, out=skip_grad, ldo=Cin, **geo)
+            rkw = {}
+            if extra is not None:                  # rides in the epilogue of the skip path's data-gradient GEMM
+                rkw, extra = dict(res=extra, ldr=Cin), None
+            nat.conv_igemm(src0=dout, C0=Cout, ksize=1, W=_pack_t(ws), Cout=Cin, out=skip_grad, ldo=Cin, **geo, **rkw)
         dxa, dxb, dg1, dbe1, _ = _gn_backward(da1, a, b, C0, C1, N, P, cA1, cB1, st1, nat.ACT_SILU, g1, be1, None, T,
-                                              inplace=inplace, add=skip_grad)
-        return (dxa, dxb, dfilm, dg1, dbe1, dw1, db1, dg2, dbe2, dw2, db2, dws, dbs, None, None, None, None, None, None)
+                                              inplace=inplace, add=skip_grad, add2=extra)
+        if ctx.b_slot is not None:
+            ctx.b_slot.g, dxb = dxb, None
+        return (dxa, dxb, dfilm, dg1, dbe1, dw1, db1, dg2, dbe2, dw2, db2, dws, dbs, None, None, None, None, None, None,
+                None, None)
 
 
 # ----------------------------------------------------------------------------- output head
@@ -1079,7 +1115,7 @@ class UNetFunction:
         cur = (h, H, W)
         hs = [cur]
 
-        def stage(blk, cur, skip=None):
+        def stage(blk, cur, skip=None, a_slot=None, b_slot=None):
             h, Hc, Wc = cur
             b = skip
             for layer in blk:
@@ -1090,8 +1126,8 @@ class UNetFunction:
                     h = ResBlockFn.apply(h, b, film, layer.in_layers[0].weight, layer.in_layers[0].bias,
                                          layer.in_layers[2].weight, layer.in_layers[2].bias, layer.out_layers[0].weight,
                                          layer.out_layers[0].bias, layer.out_layers[3].weight, layer.out_layers[3].bias,
-                                         ws, bs, N, Hc, Wc, T, slot, drop.p if drop.training else 0.0)
-                    b = None
+                                         ws, bs, N, Hc, Wc, T, slot, drop.p if drop.training else 0.0, a_slot, b_slot)
+                    b = a_slot = b_slot = None
                 elif isinstance(layer, FactorizedAttentionBlock):
                     ta, sa = layer.temporal_attention, layer.spatial_attention
                     if rpe_grp is not None:
@@ -1107,7 +1143,8 @@ class UNetFunction:
                                             sa.proj_out.bias, N, Hc * Wc, layer.num_heads,
                                             attns["spatial"] if attns is not None else None)
                 elif isinstance(layer, Downsample):
-                    h = ConvFn.apply(h, layer.op.weight, layer.op.bias, N, Hc, Wc, 2, False)
+                    h = ConvFn.apply(h, layer.op.weight, layer.op.bias, N, Hc, Wc, 2, False, 0, a_slot)
+                    a_slot = None
                     Hc, Wc = Hc // 2, Wc // 2
                 elif isinstance(layer, Upsample):
                     h = ConvFn.apply(h, layer.conv.weight, layer.conv.bias, N, Hc, Wc, 1, True)
@@ -1125,12 +1162,22 @@ class UNetFunction:
                 return cur
             return (xch.mark(cur[0], key), cur[1], cur[2])
 
-        for i, blk in enumerate(list(m.input_blocks)[1:], start=1):
-            cur = stage(blk, enter(cur, (0, i)))
+        # in-place mode: the decoder's gradient of every skip tensor goes through a _SkipSlot to the kernel that produces
+        # the encoder-side gradient of the same tensor (no autograd sum per skip connection)
+        def slot_for(nxt):
+            first = nxt[0] if len(nxt) else None
+            ok = _mode.inplace and th.is_grad_enabled() and isinstance(first, (ResBlock, Downsample)) and _SKIP_SLOTS
+            return _SkipSlot() if ok and all(p.is_leaf for p in first.parameters()) else None
+
+        enc = list(m.input_blocks)[1:]
+        slots = [slot_for(enc[0] if enc else m.middle_block)]
+        for i, blk in enumerate(enc, start=1):
+            cur = stage(blk, enter(cur, (0, i)), a_slot=slots[-1])
             hs.append(cur)
-        cur = stage(m.middle_block, enter(cur, (1, 0)))
+            slots.append(slot_for(enc[i] if i < len(enc) else m.middle_block))
+        cur = stage(m.middle_block, enter(cur, (1, 0)), a_slot=slots[-1])
         for i, blk in enumerate(m.output_blocks):
-            cur = stage(blk, enter(cur, (2, i)), skip=hs.pop()[0])
+            cur = stage(blk, enter(cur, (2, i)), skip=hs.pop()[0], b_slot=slots.pop())
         cur = enter(cur, (3, 0))
         h, Hc, Wc = cur
         out = HeadFn.apply(h, m.out[0].weight, m.out[0].bias, m.out[2].weight, m.out[2].bias, N, Hc, Wc)

@@ -116,7 +116,7 @@ _SIGS = {
     "lfvdm_gn_bwd_apply_params": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i,
                                    c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp], c_i),
     "lfvdm_gn_bwd_fused": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i,
-                            c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp], c_i),
+                            c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp], c_i),
     "lfvdm_gn_param_grads": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rowdot_bwd": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_temporal_bwd": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp], c_i),

@@ -841,6 +841,37 @@ def test_conv_upsampled_source_every_tune_code(nat, N, Cin, Cout, H, up):
     assert int(cnt.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H", [(3, 64, 64, 7), (40, 128, 128, 2), (2, 96, 160, 16)])
+def test_conv_zero_inserted_source_with_residual(nat, N, Cin, Cout, H):
+    """The zero-inserted source is computed by output parity classes (rows enumerated on the source grid, 1 / 2 / 2 / 4
+    live taps): the residual and the output rows go through the class -> output-row map, so check a launch with a
+    residual - what the data gradient of a Downsample conv with a skip connection's gradient riding along issues -
+    over every launch variant, against a dense convolution of the explicitly zero-filled image."""
+    import ctypes as C
+    x, w = rnd("ez/x", N, Cin, H, H), rnd("ez/w", Cout, Cin, 3, 3, scale=0.05)
+    Ho = 2 * H
+    r = rnd("ez/r", N, Cout, Ho, Ho)
+    xin = torch.zeros(N, Cin, Ho, Ho)
+    xin[:, :, ::2, ::2] = x
+    ref = F.conv2d(xin, w, None, padding=1) + r
+    out = torch.empty(N * Ho * Ho, Cout, device="cuda")
+    ws = torch.empty(1 << 22, device="cuda")
+    cnt = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    keep = dict(src0=cl(x), W=packed(nat, w), res=cl(r))
+    a = nat.fill_conv_args(C0=Cin, N=N, Hs=H, Ws=H, Ho=Ho, Wo=Ho, Cout=Cout, out=out, ldo=Cout, ksize=3, up=2, ldr=Cout, **keep)
+    a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+    codes = (C.c_int * 256)()
+    n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
+    assert n > 0
+    for code in [0] + [codes[i] for i in range(n)]:
+        a.tune = code
+        out.fill_(float("nan"))
+        nat.conv_igemm_struct(a)
+        err = float((from_cl(out, N, Ho, Ho, Cout).cpu() - ref).abs().max())
+        assert err < 5e-5, f"tune code {code}: max|d| = {err:.3e}"
+    assert int(cnt.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("N,C0,C1,S0,S1,Cout,H", [(5, 64, 32, 64, 32, 64, 8), (3, 128, 0, 96, 32, 96, 5), (40, 64, 64, 0, 0, 128, 4),
                                                   (2, 32, 32, 32, 0, 32, 16)])
 def test_conv_concat_and_skip_segment_every_tune_code(nat, N, C0, C1, S0, S1, Cout, H):
