@@ -781,8 +781,12 @@ int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
         return LFVDM_OK;
     }
     static const bool no_xmap = getenv("LFVDM_CONV_NO_XCD_MAP") != nullptr;       // A/B aid
-    if (!no_xmap && (NT2 * kz) % 8 == 0 && MT * NT2 * kz < (1L << 20)) {   // XCD-aware map (see the kernel): flat grid
-        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), dim3((unsigned)(MT * NT2 * kz)), dim3(CF::NTHREADS),
+    // XCD-aware map (see the kernel): flat grid, only when the (filter tile, K slice) pairs are a multiple of 8.  Padding
+    // other counts up (idle workgroups that return at once) was measured: 1063 -> 983 steps/s - the XCDs that own a
+    // padding pair sit idle while the others run two
+    const long pairs = NT2 * kz, pairs8 = (pairs + 7) / 8 * 8;
+    if (!no_xmap && pairs == pairs8 && MT * pairs8 < (1L << 20)) {
+        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), dim3((unsigned)(MT * pairs8)), dim3(CF::NTHREADS),
                            CF::LDS_BYTES, s, *a, (int)NT2, -kz, 0);
         LFVDM_CHECK_LAUNCH();
         return LFVDM_OK;
@@ -869,11 +873,14 @@ double model_cycles(const TileCfg& c, int Cout, long M, int NK, int kch, int kz)
 
 struct Pick { int id, kch, NK, kz, gl; };
 
-// tune code (lfvdm_conv_args::tune): 0 = heuristic, else 1 + id + 16*(kch == 64) + 32*log2(kz) + 256*(gl - 1), gl = 2 / 3
-// LDS-DMA stages (codes without the stage field belong to the register-staged loop of earlier library versions: ignored)
+// tune code (lfvdm_conv_args::tune): 0 = heuristic, else 1 + id + 16*(kch == 64) + 32*l + 256*(gl - 1), gl = 2 / 3
+// LDS-DMA stages, l = index of the split-K factor in kKzTable: powers of two, the tail split, and 3 / 6 / 5 - a layer
+// with 80 output tiles (64x64 tiles of a 128-filter conv on 8x8 maps) fills 160 of the 256 CUs at kz = 2 and takes
+// 1.25 rounds at kz = 4; kz = 3 makes it 240 workgroups in one round
+constexpr int kKzTable[8] = {1, 2, 4, 8, 16 /* = kHybridKz */, 3, 6, 5};
 inline int encode_tune(int id, int kch, int kz, int gl) {
     int l = 0;
-    while ((1 << l) < kz) ++l;
+    while (l < 7 && kKzTable[l] != kz) ++l;
     return 1 + id + 16 * (kch == 64 ? 1 : 0) + 32 * l + 256 * (gl - 1);
 }
 // fused output GroupNorm: the tile must hold whole samples and whole groups, and the unit statistics must fit
@@ -922,7 +929,7 @@ Pick pick_cfg(const lfvdm_conv_args* a, long M) {
     const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
     if (a->tune > 0) {   // explicit choice (autotuner); fall through to the model if it is not legal here
         const int t = a->tune - 1;
-        const int id = t & 15, kch = (t & 16) ? 64 : 32, kz = 1 << ((t >> 5) & 7), gl = ((t >> 8) & 3) + 1;
+        const int id = t & 15, kch = (t & 16) ? 64 : 32, kz = kKzTable[(t >> 5) & 7], gl = ((t >> 8) & 3) + 1;
         if (cfg_valid(a, id, kch, kz, gl)) return {id, kch, a->ksize * a->ksize * (Cin / kch) + C2 / kch, kz, gl};
     }
     static const int forced = getenv("LFVDM_CONV_CFG") ? atoi(getenv("LFVDM_CONV_CFG")) : -1;  // tuning aid
@@ -1033,8 +1040,8 @@ extern "C" int lfvdm_conv_igemm_candidates(const lfvdm_conv_args* a, int* codes,
     for (int gl = 2; gl <= 3; ++gl)
         for (int id = 0; id < kNumCfgs; ++id)
             for (int kch = 32; kch <= 64; kch += 32)
-                for (int kz = 1; kz <= kHybridKz; kz *= 2)
-                    if (cfg_valid(a, id, kch, kz, gl) && n < max_codes) codes[n++] = encode_tune(id, kch, kz, gl);
+                for (int l = 0; l < 8; ++l)
+                    if (cfg_valid(a, id, kch, kKzTable[l], gl) && n < max_codes) codes[n++] = encode_tune(id, kch, kKzTable[l], gl);
     return n;
 }
 

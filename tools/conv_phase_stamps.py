@@ -69,7 +69,7 @@ def main():
             continue
         seen.add(key)
         t = a.tune - 1
-        kz = 1 << ((t >> 5) & 7) if a.tune > 0 else 1
+        kz = (1, 2, 4, 8, 16, 3, 6, 5)[(t >> 5) & 7] if a.tune > 0 else 1      # 16 = tail split
         e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         for _ in range(5):
             fn(*args, s)

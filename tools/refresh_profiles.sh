@@ -37,12 +37,15 @@ echo "pmc mfma done"
 python3 $ROOT/tools/pmc_summarize.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json $OUT/pmc_mfma
 # 5. in-kernel phase table of the implicit-GEMM launches (diagnostic build with -DLFVDM_STAMP, if present)
 if [ -f $ROOT/devlib/liblfvdm_stamp.so ]; then
-  cd $ROOT && step 200 python3 tools/conv_phase_stamps.py all > $OUT/conv_phase_stamps.txt 2>&1; cd /tmp
+  cd $ROOT && LFVDM_TUNE_CACHE_OUT= step 200 python3 tools/conv_phase_stamps.py all > $OUT/conv_phase_stamps.txt 2>&1; cd /tmp
   echo "phase stamps done"
 fi
 # 6. the parity tests that print their deviations from the reference fixtures
 cd $ROOT && step 400 python3 -m pytest tests/test_forward_gpu.py tests/test_sampler_gpu.py tests/test_train_gpu.py -m gpu -q -s --timeout 300 -k "reference or cfgC_training or replayed or full_size or fp64" > $OUT/parity_deviations.txt 2>&1; cd /tmp
 echo "parity deviations done"
+# 7. the whole 1000-frame hierarchy-2 video (BASELINE.json configs[3] at full size: 97 windows x 250 steps)
+step 400 python3 $ROOT/bench.py --steps 50 --warmup 10 --train-steps 0 --pixel-steps 0 --no-cpu --long-video-windows 97 > $OUT/long_video_line.json 2> $OUT/long_video.err
+echo "long video done"
 rm -rf $OUT/bp/*trace* $OUT/tp/*trace*
 [ -f $LFVDM_TUNE_CACHE_OUT ] || cp $LFVDM_TUNE_CACHE $LFVDM_TUNE_CACHE_OUT
 echo "refresh complete"
