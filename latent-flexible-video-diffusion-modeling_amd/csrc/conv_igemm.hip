@@ -152,19 +152,22 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const lfv
         bx = tile - by * MT;
         tile_id = (size_t)(tile - hyb_nfull);
     } else if (hyb_kz < 0) {
-        // XCD-aware flat grid (hyb_nfull = filter tiles, -hyb_kz = K slices; filter tiles x K slices a multiple of 8):
-        // consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  All output-row tiles of one
-        // (filter tile, K slice) run on ONE XCD, so every filter byte is fetched into one L2 instead of eight - at the
-        // low-resolution levels the filters ARE the traffic (590 KB of filters against 82 KB of activations for a
-        // 128 -> 128 3x3 layer on 2x2 maps; 7.3 MB per launch at the fabric with the plain map).  Speed only.
+        // XCD-aware flat grid (hyb_nfull = filter tiles, -hyb_kz = K slices, gridDim.x = 8 * per): consecutive workgroup
+        // ids go round-robin to the 8 XCDs, each with its own L2.  The (filter tile, K slice, output-row tile) triples are
+        // laid out pair-major and XCD x takes the contiguous range [x * per, (x + 1) * per): the row tiles of one (filter
+        // tile, K slice) pair run on ONE XCD (two where a range boundary cuts the pair), so every filter byte is fetched
+        // into one or two L2s instead of up to eight - at the low-resolution levels the filters ARE the traffic (590 KB of
+        // filters against 82 KB of activations for a 128 -> 128 3x3 layer on 2x2 maps) - and every XCD gets the same
+        // number of workgroups (+-1) whatever the pair count.  Traffic only: these launches wait on latency.
         const int MT = (M + BM - 1) / BM;
         KZ = -hyb_kz;
-        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-        const int cl = div_small(slot, MT);
-        bx = slot - cl * MT;
-        const int combo = xcd + 8 * cl;
-        by = div_small(combo, KZ);
-        kz = combo - by * KZ;
+        const int id = blockIdx.x, per = (int)(gridDim.x >> 3);
+        const int L = (id & 7) * per + (id >> 3);
+        if (L >= MT * hyb_nfull * KZ) return;          // padding of the last range (whole workgroup, before any barrier)
+        const int pair = div_small(L, MT);
+        bx = L - pair * MT;
+        by = div_small(pair, KZ);
+        kz = pair - by * KZ;
         tile_id = (size_t)by * MT + bx;
     }
     const int m0 = bx * BM;
@@ -781,12 +784,11 @@ int launch_pro(const lfvdm_conv_args* a, hipStream_t s, long M, int kz) {
         return LFVDM_OK;
     }
     static const bool no_xmap = getenv("LFVDM_CONV_NO_XCD_MAP") != nullptr;       // A/B aid
-    // XCD-aware map (see the kernel): flat grid, only when the (filter tile, K slice) pairs are a multiple of 8.  Padding
-    // other counts up (idle workgroups that return at once) was measured: 1063 -> 983 steps/s - the XCDs that own a
-    // padding pair sit idle while the others run two
-    const long pairs = NT2 * kz, pairs8 = (pairs + 7) / 8 * 8;
-    if (!no_xmap && pairs == pairs8 && MT * pairs8 < (1L << 20)) {
-        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), dim3((unsigned)(MT * pairs8)), dim3(CF::NTHREADS),
+    // XCD-aware map (see the kernel) for split-K launches: flat grid of 8 equal per-XCD ranges.  (Padding the PAIR count to
+    // a multiple of 8 instead was measured: 1063 -> 983 steps/s - the XCDs that own a padding pair idle while others run two.)
+    const long total = MT * NT2 * kz, per = (total + 7) / 8;
+    if (!no_xmap && kz > 1 && total >= 16 && 8 * per < (1L << 20)) {
+        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, NT, KCH, SIMPLE, GL>), dim3((unsigned)(8 * per)), dim3(CF::NTHREADS),
                            CF::LDS_BYTES, s, *a, (int)NT2, -kz, 0);
         LFVDM_CHECK_LAUNCH();
         return LFVDM_OK;
