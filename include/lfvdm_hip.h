@@ -469,6 +469,17 @@ int lfvdm_p_sample_rng(const float* x, const float* eps, float* noise_out, const
                        const float* sqrt_recipm1_acp, const float* coef1, const float* coef2, const float* log_var,
                        int clip, float* sample, float* pred_xstart, float* mean_out, int B, int inner,
                        const int64_t* seed, void* stream);
+/* The U-Net's 3x3 output convolution (unet.py:399-403,462-464) and the update above in ONE launch - the last two
+ * launches of a replayed sampling step: eps = conv(act) + bias from the channels-last rows act [B*T*H*W][C] = SiLU(GN(h))
+ * and the packed filters Wp [Cout][9][C] (lfvdm_pack_conv_weight), then lfvdm_p_sample_rng's arithmetic with the same
+ * noise stream (noise_in != NULL: that noise instead, seed unused).  eps_out / noise_out / pred_xstart / mean_out may be
+ * NULL; x and sample may alias.  _ok: 0 if the shape is covered (Cout 3 or 4, C 64 / 128 / 256, W % 4 == 0). */
+int lfvdm_conv_out_psample_ok(int N, int H, int W, int C, int Cout);
+int lfvdm_conv_out_psample(const float* act, const float* Wp, const float* bias, float* eps_out, const float* x,
+                           const float* noise_in, float* noise_out, const int64_t* t, const float* sqrt_recip_acp,
+                           const float* sqrt_recipm1_acp, const float* coef1, const float* coef2, const float* log_var,
+                           int clip, float* sample, float* pred_xstart, float* mean_out, int B, int T, int H, int W, int C,
+                           int Cout, const int64_t* seed, void* stream);
 /* Sampler clock of the captured denoising step (the loop `for i in indices: t = th.tensor([i]*B)` of
  * gaussian_diffusion.py:509-512 and _WrappedModel's timestep map, respace.py:117-122, kept on the device):
  * t[b] <- max(t[b] - 1, 0);  model_t[b] <- model_timestep_table[t[b]]. */

@@ -109,6 +109,94 @@ __global__ __launch_bounds__(256) void p_sample_rng_kernel(const float* x, const
     }
 }
 
+// ---- The U-Net's output convolution and the update in ONE launch (the last two launches of a replayed sampling step:
+// a 64 -> 4 convolution run as an implicit GEMM with 28 of its 32 filter columns padding, 10.4 us, and the update,
+// 5.2 us).  eps = conv3x3(act) + bias with act = SiLU(GN(h)) as channels-last rows (reference unet.py:399-403,462-464),
+// then exactly p_sample_rng_kernel's arithmetic and noise on it.  Direct convolution: SIXTEEN lanes share an output pixel
+// and split its input channels (each lane CPL float4 of every tap: a pixel's 256-byte channel rows are read contiguously),
+// partial sums combined with four butterfly steps inside the 16-lane row; a wave = four consecutive x positions = one
+// noise quad of each output channel, so the lanes (pixel j, channel co < CO) finish with the update of their own element.
+// The packed filters [CO][9][C] (lfvdm_pack_conv_weight) sit in LDS; the four pixels of a wave read the same addresses.
+struct HeadUpdate {
+    const float *act, *Wp, *bias, *x, *noise_in;
+    float *eps_out, *noise_out, *sample, *pred, *mean_out;
+    const int64_t *t, *seed;
+    const float *t_recip, *t_recipm1, *t_c1, *t_c2, *t_logvar;
+    int N, T, H, W, C, clip;
+};
+
+template <int CO, int CPL>
+__global__ __launch_bounds__(256) void conv_out_psample_kernel(const HeadUpdate p) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [CO * 9][C]
+    const int tid = threadIdx.x;
+    const int C = p.C;
+    for (int i = tid; i < (CO * 9 * C) >> 2; i += 256) st4(wl + 4 * i, ld4(p.Wp + 4 * (size_t)i));
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int WQ = p.W >> 2;
+    const long quad = (long)blockIdx.x * 4 + wave;
+    if (quad >= (long)p.N * p.H * WQ) return;                       // whole wave, after the only barrier
+    const int n = (int)(quad / (p.H * WQ));
+    const int rem = (int)(quad - (long)n * p.H * WQ);
+    const int y = rem / WQ, xq = rem - y * WQ;
+    const int j = lane >> 4, cl = lane & 15;
+    const int x = 4 * xq + j;
+    float acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+        const bool inb = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const float* a = p.act + ((size_t)(n * p.H + (inb ? iy : y)) * p.W + (inb ? ix : x)) * C;
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) {
+            const int c = (cl + 16 * u) * 4;
+            f32x4 a4 = ld4(a + c);
+            if (!inb) a4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                const f32x4 w4 = ld4(wl + (co * 9 + tap) * C + c);
+                acc[co] += (a4.x * w4.x + a4.y * w4.y) + (a4.z * w4.z + a4.w * w4.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) acc[co] += __shfl_xor(acc[co], o, 64);
+    if (cl >= CO) return;
+    float e = acc[0];
+#pragma unroll
+    for (int co = 1; co < CO; ++co) e = cl == co ? acc[co] : e;
+    const int co = cl;
+    e += p.bias[co];
+    const int b = n / p.T, tt = n - b * p.T;
+    const int inner = p.T * CO * p.H * p.W;
+    const int i = ((tt * CO + co) * p.H + y) * p.W + x;             // element of the (T, C, H, W) frame stack
+    const size_t at = (size_t)b * inner + i;
+    const int64_t tb = p.t[b];
+    const float r = p.t_recip[tb], rm1 = p.t_recipm1[tb], c1 = p.t_c1[tb], c2 = p.t_c2[tb];
+    const float sigma = tb != 0 ? expf(0.5f * p.t_logvar[tb]) : 0.f;
+    float z;
+    if (p.noise_in) {
+        z = p.noise_in[at];
+    } else {
+        const unsigned long long key = (unsigned long long)p.seed[0];
+        const f32x4 z4 = normal4((unsigned)(i >> 2), (unsigned)b, (unsigned)tb, (unsigned)key, (unsigned)(key >> 32));
+        z = j == 0 ? z4.x : j == 1 ? z4.y : j == 2 ? z4.z : z4.w;  // x = 4 * xq + j and W % 4 == 0: i & 3 == j
+    }
+    const float xv = p.x[at];
+    float p0 = r * xv - rm1 * e;
+    if (p.clip) p0 = fminf(fmaxf(p0, -1.f), 1.f);
+    const float mean = c1 * p0 + c2 * xv;
+    p.sample[at] = mean + sigma * z;
+    if (p.eps_out) p.eps_out[at] = e;
+    if (p.noise_out) p.noise_out[at] = z;
+    if (p.pred) p.pred[at] = p0;
+    if (p.mean_out) p.mean_out[at] = mean;
+}
+
 // out[b] = (1/inner_total) * sum_{t, i} (a - b)^2 * mask[b, t]; one workgroup of 1024 threads per batch row, float4 loads
 // (fixed summation order: deterministic).  The first version walked the row with 256 scalar-loading threads: 24 us for
 // 82 k elements, twice per training step.
@@ -260,6 +348,37 @@ extern "C" int lfvdm_p_sample_rng(const float* x, const float* eps, float* noise
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(p_sample_rng_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, eps, noise_out, t, sqrt_recip_acp,
                        sqrt_recipm1_acp, coef1, coef2, log_var, clip, sample, pred_xstart, mean_out, inner, seed);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_conv_out_psample_ok(int N, int H, int W, int C, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || W % 4 || (Cout != 3 && Cout != 4)) return LFVDM_E_UNSUPPORTED;
+    if (C != 64 && C != 128 && C != 256) return LFVDM_E_UNSUPPORTED;
+    if ((long)N * H * W * C >= (1L << 31) / 4) return LFVDM_E_UNSUPPORTED;
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_conv_out_psample(const float* act, const float* Wp, const float* bias, float* eps_out, const float* x,
+                                      const float* noise_in, float* noise_out, const int64_t* t, const float* sqrt_recip_acp,
+                                      const float* sqrt_recipm1_acp, const float* coef1, const float* coef2,
+                                      const float* log_var, int clip, float* sample, float* pred_xstart, float* mean_out,
+                                      int B, int T, int H, int W, int C, int Cout, const int64_t* seed, void* stream) {
+    if (B <= 0 || T <= 0 || !act || !Wp || !bias || !x || !sample || !t || (!noise_in && !seed)) return LFVDM_E_SHAPE;
+    if (int rc = lfvdm_conv_out_psample_ok(B * T, H, W, C, Cout)) return rc;
+    const HeadUpdate p = {act, Wp, bias, x, noise_in, eps_out, noise_out, sample, pred_xstart, mean_out, t, seed, sqrt_recip_acp,
+                          sqrt_recipm1_acp, coef1, coef2, log_var, B * T, T, H, W, C, clip};
+    const long quads = (long)B * T * H * (W / 4);
+    const dim3 grid((unsigned)((quads + 3) / 4));
+    const size_t lds = (size_t)Cout * 9 * C * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define LFVDM_HEAD(CO, CPL) hipLaunchKernelGGL((conv_out_psample_kernel<CO, CPL>), grid, dim3(256), lds, s, p)
+    if (Cout == 4) {
+        if (C == 64) LFVDM_HEAD(4, 1); else if (C == 128) LFVDM_HEAD(4, 2); else LFVDM_HEAD(4, 4);
+    } else {
+        if (C == 64) LFVDM_HEAD(3, 1); else if (C == 128) LFVDM_HEAD(3, 2); else LFVDM_HEAD(3, 4);
+    }
+#undef LFVDM_HEAD
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

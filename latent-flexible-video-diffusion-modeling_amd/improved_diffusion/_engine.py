@@ -367,8 +367,11 @@ class Plan:
         gn, conv = m.out[0], m.out[2]
         self.out = self.buf(B, T, m.out_channels, H, W)
         act = self.gn_apply(hb, None, hc, 0, N, H * W, gn, None, nat.ACT_SILU, "act1")
-        self.add_conv(src0=act, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv.weight), bias=conv.bias,
+        wp = self.packed(conv.weight)
+        self.add_conv(src0=act, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=wp, bias=conv.bias,
                       Cout=m.out_channels, out=self.out, ldo=m.out_channels, out_mode=nat.OUT_NCHW)
+        self.head = dict(act=act, Wp=wp, bias=conv.bias, C=hc, Cout=m.out_channels, step=len(self.steps) - 1)
+        self.head_fused = False
 
     def _stage(self, blk, cur, after=None):
         from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
@@ -547,6 +550,27 @@ class Plan:
         # no host synchronisation: the job table and the index tensor were allocated on this stream and are released to the
         # caching allocator in stream order, so the launch above is done with them before anything can reuse the memory -
         # and a windowed sampler (97 chains per video) keeps the host ahead of the device across windows
+
+    def fuse_head_update(self, t_buf, tables, clip, seed, noise, pred, inject_noise):
+        """Sampler only (its plan is private): replace the last launch - the output convolution - by
+        lfvdm_conv_out_psample, which also does the x_{t-1} update on ``x_in`` (reference gaussian_diffusion.py:369-401)
+        with the chain's in-kernel noise (or ``noise`` as given when ``inject_noise``).  -> False if the shape is not
+        covered (the sampler then issues the update as its own launch)."""
+        L = nat.lib()
+        h = self.head
+        if self.head_fused:
+            return True
+        if h["step"] != len(self.steps) - 1 or L.lfvdm_conv_out_psample_ok(self.B * self.T, self.H, self.W, h["C"], h["Cout"]) != 0:
+            return False
+        self.keep.append((t_buf, tables, seed, noise, pred))
+        args = (_p(h["act"]), _p(h["Wp"]), _p(h["bias"]), _p(self.out), _p(self.x_in), _p(noise) if inject_noise else None,
+                None if inject_noise else _p(noise), _p(t_buf), _p(tables["sqrt_recip_alphas_cumprod"]),
+                _p(tables["sqrt_recipm1_alphas_cumprod"]), _p(tables["posterior_mean_coef1"]),
+                _p(tables["posterior_mean_coef2"]), _p(tables["model_log_variance"]), int(bool(clip)), _p(self.x_in), _p(pred),
+                None, self.B, self.T, self.H, self.W, h["C"], h["Cout"], _p(seed))
+        self.steps[h["step"]] = (L.lfvdm_conv_out_psample, args)
+        self.head_fused = True
+        return True
 
     def tick(self, t_buf, ts_table):
         """The sampler's clock (t <- max(t-1, 0); model timestep <- table[t]); with timestep tables it also fetches

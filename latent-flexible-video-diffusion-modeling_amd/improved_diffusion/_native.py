@@ -110,6 +110,8 @@ _SIGS = {
     "lfvdm_conv_in_tick": ([c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i,
                             c_fp], c_i),
     "lfvdm_p_sample_rng": ([c_fp] * 9 + [c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp], c_i),
+    "lfvdm_conv_out_psample_ok": ([c_i] * 5, c_i),
+    "lfvdm_conv_out_psample": ([c_fp] * 13 + [c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp], c_i),
     "lfvdm_masked_mse_bwd": ([c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_bwd_stats": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_apply": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp], c_i),
@@ -444,6 +446,18 @@ def p_sample_rng(x, eps, noise_out, t, recip, recipm1, c1, c2, logvar, clip, sam
     check(lib().lfvdm_p_sample_rng(ptr(x), ptr(eps), ptr(noise_out), ptr(t, torch.int64), ptr(recip), ptr(recipm1), ptr(c1),
                                    ptr(c2), ptr(logvar), int(bool(clip)), ptr(sample), ptr(pred), ptr(mean), B,
                                    x.numel() // B, ptr(seed, torch.int64), stream()), "lfvdm_p_sample_rng")
+
+
+def conv_out_psample(act, wp, bias, eps_out, x, noise_in, noise_out, t, recip, recipm1, c1, c2, logvar, clip, sample, seed,
+                     pred=None, mean=None):
+    """The U-Net's output conv and the x_{t-1} update in one launch (lfvdm_conv_out_psample).  act: channels-last rows
+    [B*T*H*W][C]; wp: packed filters [Cout][9][C]; x / sample / eps_out: (B, T, Cout, H, W)."""
+    B, T, Cout, H, W = x.shape
+    check(lib().lfvdm_conv_out_psample(ptr(act), ptr(wp), ptr(bias), ptr(eps_out), ptr(x), ptr(noise_in), ptr(noise_out),
+                                       ptr(t, torch.int64), ptr(recip), ptr(recipm1), ptr(c1), ptr(c2), ptr(logvar),
+                                       int(bool(clip)), ptr(sample), ptr(pred), ptr(mean), B, T, H, W, act.shape[-1], Cout,
+                                       ptr(seed, torch.int64) if seed is not None else None, stream()),
+          "lfvdm_conv_out_psample")
 
 
 def prepare_batch(pool, table, batch, frame_indices, obs_mask, latent_mask):

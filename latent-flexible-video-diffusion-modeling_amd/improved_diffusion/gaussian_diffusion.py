@@ -501,6 +501,11 @@ class GraphSampler:
         def tick():     # device-side clock: t <- max(t - 1, 0), model timestep <- table[t]  (t_buf holds "previous t");
             pl.tick(self.t_buf, self.ts_table)      # with timestep tables it also fetches the FiLM rows of the new t
 
+        # the x_{t-1} update rides in the plan's last launch (output conv + update: lfvdm_conv_out_psample) where the
+        # shape allows; LFVDM_FUSED_HEAD=0 keeps the two launches (A/B aid)
+        fused = (os.environ.get("LFVDM_FUSED_HEAD", "1") != "0"
+                 and (self.inject_noise or os.environ.get("LFVDM_SAMPLER_NOISE", "kernel") != "torch")
+                 and pl.fuse_head_update(self.t_buf, tb, self.clip, self.seed, self.noise, self.pred, self.inject_noise))
         if pl.time_steps and os.environ.get("LFVDM_TICK_IN_CONV", "1") != "0":
             pl.launch(tick=(self.t_buf, self.ts_table))      # the clock rides in the first launch of the forward
             self.extra_launches = 1                           # (the update; bench.py reports launches per step)
@@ -508,6 +513,9 @@ class GraphSampler:
             tick()
             pl.launch()
             self.extra_launches = 2
+        if fused:
+            self.extra_launches -= 1
+            return
         if not self.inject_noise and os.environ.get("LFVDM_SAMPLER_NOISE", "kernel") != "torch":
             nat.p_sample_rng(pl.x_in, pl.out, self.noise, self.t_buf, tb["sqrt_recip_alphas_cumprod"],
                              tb["sqrt_recipm1_alphas_cumprod"], tb["posterior_mean_coef1"], tb["posterior_mean_coef2"],

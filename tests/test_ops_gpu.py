@@ -768,6 +768,38 @@ def test_p_sample_rng_draws_standard_normal_noise(nat):
     assert torch.equal(out[3], mean[3])                                    # t = 0: the sample is the posterior mean
 
 
+@pytest.mark.parametrize("B,T,H,W,C,Cout", [(2, 20, 16, 16, 64, 4), (1, 3, 8, 12, 128, 3), (2, 2, 4, 4, 256, 4)])
+def test_conv_out_psample_equals_conv_then_update(nat, B, T, H, W, C, Cout):
+    """lfvdm_conv_out_psample = the output convolution (unet.py:402,462-464) + lfvdm_p_sample_rng in one launch: its eps
+    equals the dense convolution, its noise is the SAME stream as lfvdm_p_sample_rng's for the chain's seed (bitwise), and
+    its sample / pred_xstart are bitwise what the two-launch form gives on that eps; with injected noise it uses that noise."""
+    N = B * T
+    a = rnd("co/a", N, C, H, W)
+    w, bias = rnd("co/w", Cout, C, 3, 3, scale=0.05), rnd("co/b", Cout)
+    ref_eps = F.conv2d(a, w, bias, padding=1).view(B, T, Cout, H, W)
+    x = rnd("co/x", B, T, Cout, H, W).cuda()
+    S = 1000
+    tabs = [torch.rand(S, device="cuda") + 0.5 for _ in range(4)] + [torch.randn(S, device="cuda") * 0.3]
+    t = torch.tensor(([7, 0] * B)[:B], dtype=torch.int64, device="cuda")
+    seed = torch.tensor([0x7654321], dtype=torch.int64, device="cuda")
+    act, wp = cl(a), packed(nat, w)
+    eps, nz, out, pred = (torch.empty_like(x) for _ in range(4))
+    nat.conv_out_psample(act, wp, bias.cuda(), eps, x, None, nz, t, *tabs, True, out, seed, pred)
+    err = float((eps.cpu() - ref_eps).abs().max())
+    assert err < 5e-5, err
+    out2, nz2, pred2 = (torch.empty_like(x) for _ in range(3))
+    nat.p_sample_rng(x.view(B, -1), eps.view(B, -1), nz2.view(B, -1), t, *tabs, True, out2.view(B, -1), seed, pred2.view(B, -1))
+    assert torch.equal(nz, nz2) and torch.equal(out, out2) and torch.equal(pred, pred2)
+    given = rnd("co/n", B, T, Cout, H, W).cuda()
+    out3, out4 = torch.empty_like(x), torch.empty_like(x)
+    nat.conv_out_psample(act, wp, bias.cuda(), None, x, given, None, t, *tabs, True, out3, None)
+    nat.p_sample(x.view(B, -1), eps.view(B, -1), given.view(B, -1), t, *tabs, True, out4.view(B, -1))
+    assert torch.equal(out3, out4)
+    xin = x.clone()                                     # in place, as the sampler runs it
+    nat.conv_out_psample(act, wp, bias.cuda(), None, xin, None, None, t, *tabs, True, xin, seed)
+    assert torch.equal(xin, out)
+
+
 def test_sampler_tick(nat):
     t = torch.tensor([5, 0, 999], dtype=torch.int64, device="cuda")
     table = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.25
