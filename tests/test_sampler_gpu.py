@@ -198,6 +198,48 @@ def test_timestep_tables_give_bitwise_the_per_step_result(monkeypatch):
     assert outs["0"][2] - outs["1"][2] == 4, "three embedding launches and the RPE launch leave the step"
 
 
+def test_run_is_bitwise_n_single_steps():
+    """``GraphSampler.run`` replays K captured steps per graph launch (a launch costs ~18 us of GPU time whatever it
+    holds).  The clock is on the device and the noise is keyed by (chain seed, t, element), so the grouping cannot change
+    a value: 19 steps through ``run`` (two 8-step launches + three single ones), 19 ``step`` calls and a ``run`` that is
+    interrupted by a ``step`` must agree BITWISE, and the chain must end at the same timestep."""
+    cfg, sd, inp = load_case("micro")
+    d = {k: v.cuda() for k, v in inp.items()}
+    mk = dict(frame_indices=d["frame_indices"], obs_mask=d["obs_mask"], latent_mask=d["latent_mask"], x0=d["x0"])
+    shape = tuple(inp["x"].shape)
+    model = build_native(cfg, sd)
+    diff = make_diffusion(1000, "")
+    s = diff._graph_sampler(model, shape, True)
+    assert s.K == 8
+    outs = []
+    for mode in ("step", "run", "mixed"):
+        s.begin(d["x"].clone(), mk)
+        s.seed.fill_(12345)                          # the same noise key for the three chains
+        if mode == "step":
+            for i in range(999, 980, -1):
+                out = s.step(i)
+        elif mode == "run":
+            out = s.run(999, 19)
+            assert s.graph_k is not None
+        else:
+            s.run(999, 9)
+            s.step(990)
+            out = s.run(989, 9)
+        assert s.expected_t == 980 and s.t_buf.tolist() == [981] * shape[0]
+        outs.append((out["sample"].clone(), out["pred_xstart"].clone()))
+    for a, b in outs[1:]:
+        assert torch.equal(outs[0][0], a) and torch.equal(outs[0][1], b)
+    # the public loop (25 respaced steps = 3 launches of 8 + 1) equals the progressive generator's last state
+    diff25 = make_diffusion(1000, "25")
+    torch.manual_seed(3)
+    a, _ = diff25.p_sample_loop(model, shape, clip_denoised=True, model_kwargs=mk, return_decoded=False)
+    torch.manual_seed(3)
+    last = None
+    for last in diff25.p_sample_loop_progressive(model, shape, clip_denoised=True, model_kwargs=mk):
+        pass
+    assert torch.equal(a, last["sample"])
+
+
 def test_replayed_cfgB_sampler_plan_follows_the_reference_trajectory():
     """The plan the benchmark times - BASELINE.json configs[1] (ch64, batch 2, 20 frames, 4x16x16), autotuned tile
     codes, timestep tables, GroupNorm epilogues, hipGraph replay - against three steps of the REFERENCE's p_sample
