@@ -265,3 +265,32 @@ def test_replayed_cfgB_sampler_plan_follows_the_reference_trajectory():
         err = float((out.cpu() - torch.from_numpy(g["traj"][j])).abs().max())
         print(f"[cfgB replay] step {j} (t={i}): max|d| vs reference trajectory {err:.2e}")
         assert err < 2e-4 * (j + 1), (j, err)
+    assert s.plan.head_fused, "the benchmarked plan ends in the fused output conv + update"
+
+
+def test_fused_head_chain_equals_the_two_launch_chain(monkeypatch):
+    """cfg-B sampler with the output conv + update in one launch (lfvdm_conv_out_psample, the default) against the same
+    chain with the two launches (LFVDM_FUSED_HEAD=0): same noise stream (same chain seed), so the only difference is the
+    summation order inside the 64 -> 4 convolution - the samples of 12 steps stay within 2e-5."""
+    from improved_diffusion.gaussian_diffusion import GraphSampler
+    cfg, sd, inp = load_case("cfgB")
+    model = build_native(cfg, sd)
+    d = {k: v.cuda() for k, v in inp.items()}
+    mk = dict(frame_indices=d["frame_indices"], obs_mask=d["obs_mask"], latent_mask=d["latent_mask"], x0=d["x0"])
+    shape = tuple(inp["x"].shape)
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("LFVDM_FUSED_HEAD", fused)
+        s = GraphSampler(make_diffusion(1000, ""), model, shape, True)
+        s.begin(d["x"].clone(), mk)
+        s.seed.fill_(777)
+        assert s.plan.head_fused == (fused == "1")
+        out = s.run(999, 12)
+        outs.append((out["sample"].clone(), out["pred_xstart"].clone(), s.noise.clone(), len(s.plan.steps) + s.extra_launches))
+        del s
+    assert torch.equal(outs[0][2], outs[1][2]), "the noise of the last step is the same Philox stream"
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-5
+    # (pred_xstart = r * x - rm1 * eps amplifies eps by sqrt(1/abar - 1) ~ 1e3 at the top of the chain before the clip)
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 5e-3
+    assert outs[1][3] - outs[0][3] == 1, "one launch less per step"
+
