@@ -87,7 +87,8 @@ __global__ __launch_bounds__(1024) void attn_spatial_fused_kernel(const float* _
     // ---- projection: [PP][3 FP] = Xs [PP][C] . Ws^T.  Work item = (16-token row tile, 16-wide feature group fg): the q, k
     // and v tiles of that group share the token fragment and run as three independent MFMA chains; bias added, q pre-scaled
     {
-        const float scale = rsqrtf((float)FP);
+        // q carries 1/sqrt(F) AND log2(e): the softmax below exponentiates in base 2 (one v_exp_f32 per logit, no multiply)
+        const float scale = rsqrtf((float)FP) * 1.4426950408889634f;
         const int NRT = PP >> 4;
         const int CG = C >> 4;                              // 16-wide reduction groups
         for (int item = wave; item < NRT * FG; item += NW) {
@@ -164,23 +165,27 @@ __global__ __launch_bounds__(1024) void attn_spatial_fused_kernel(const float* _
                     for (int j = 0; j < 4; ++j) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[j][e], qf[g][e], s[j], 0, 0, 0);
             }
             float mx = -INFINITY;
+            if (kb + 64 > P) {                              // ragged last block only (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb + 16 * j + 4 * kk + r >= P) s[j][r] = -INFINITY;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (kb + 16 * j + 4 * kk + r >= P) s[j][r] = -INFINITY;
-                    mx = fmaxf(mx, s[j][r]);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __expf(m_run - m_new);      // m_run = -inf on the first block -> 0
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // m_run = -inf on the first block -> 0
             float psum = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __expf(s[j][r] - m_new);
+                    const float pv = __builtin_amdgcn_exp2f(s[j][r] - m_new);
                     s[j][r] = pv;
                     psum += pv;
                 }
