@@ -582,13 +582,13 @@ static int det_finish(const lfvdm_conv_args* a, long msplit, hipStream_t s) {
 }
 
 template <int COT, int KT, int NS>
-static int launch_wgrad_dma(const lfvdm_conv_args* a, hipStream_t s, int nchunks) {
+static int launch_wgrad_dma(const lfvdm_conv_args* a, hipStream_t s, int nchunks, long msplit_req) {
     const int Cin = a->C0 + a->C1;
     const int NKG = a->ksize * a->ksize * (Cin / (32 * KT));
     const int NCG = (a->Cout + 32 * COT - 1) / (32 * COT);
     const long tiles = (long)NKG * NCG;
     static const long target = getenv("LFVDM_WGRAD_WGS") ? atol(getenv("LFVDM_WGRAD_WGS")) : 384;
-    long msplit = (target + tiles - 1) / tiles;
+    long msplit = msplit_req > 0 ? msplit_req : (target + tiles - 1) / tiles;      // (tuned per layer shape, or 1.5 per CU)
     if (msplit > nchunks / 2) msplit = nchunks / 2;
     if (msplit < 1) msplit = 1;
     constexpr size_t lds = (size_t)(NS * (32 * COT * 32 + 32 * KT * 32) + 8 * COT * 32) * sizeof(float);
@@ -743,6 +743,13 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
         // 1x1 / linear layers and the low-resolution levels (smaller tiles = fewer bytes of atomics per workgroup)
         const bool big3 = a->ksize == 3 && M >= 2560;
         int cot = (a->Cout >= 128 && big3) ? 4 : a->Cout >= 64 ? 2 : 0;
+        // tune code (lfvdm_conv_args::tune, measured per layer shape by the caller): 1 + tile + 4 * stages + 16 * M slices;
+        // tile 1 / 2 = 64 / 128 filters per workgroup, stages 1 / 2 = two / three LDS-DMA stages, 0 = this heuristic
+        const int tcode = a->tune > 0 ? a->tune - 1 : 0;
+        const int t_cot = tcode & 3, t_ns = (tcode >> 2) & 3;
+        const long t_ms = tcode >> 4;
+        if (t_cot == 1 && a->Cout >= 64) cot = 2;
+        if (t_cot == 2 && a->Cout >= 128) cot = 4;
         int kt = 0;
         for (int k : {2})
             if (kt == 0 && Cin % (32 * k) == 0 && a->C0 % (32 * k) == 0) kt = k;
@@ -754,10 +761,11 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
         if (cot && kt && !getenv("LFVDM_WGRAD_WAVE")) {
             hipStream_t s = (hipStream_t)stream;
             if (wgrad_dma_ok(a, M) && kt == 2) {
-                const int ns = getenv("LFVDM_WGRAD_STAGES") ? atoi(getenv("LFVDM_WGRAD_STAGES")) : 3;
+                int ns = getenv("LFVDM_WGRAD_STAGES") ? atoi(getenv("LFVDM_WGRAD_STAGES")) : 3;
+                if (t_ns) ns = t_ns == 1 ? 2 : 3;
                 int rc;
-                if (cot == 4) rc = ns == 2 ? launch_wgrad_dma<4, 2, 2>(a, s, nchunks) : launch_wgrad_dma<4, 2, 3>(a, s, nchunks);
-                else rc = ns == 2 ? launch_wgrad_dma<2, 2, 2>(a, s, nchunks) : launch_wgrad_dma<2, 2, 3>(a, s, nchunks);
+                if (cot == 4) rc = ns == 2 ? launch_wgrad_dma<4, 2, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<4, 2, 3>(a, s, nchunks, t_ms);
+                else rc = ns == 2 ? launch_wgrad_dma<2, 2, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<2, 2, 3>(a, s, nchunks, t_ms);
                 if (rc != LFVDM_OK) return rc;
                 LFVDM_CHECK_LAUNCH();
                 return LFVDM_OK;

@@ -355,12 +355,77 @@ def det_workspace(device):
     return ws
 
 
+def _wgrad_codes(a):
+    """Candidate launch codes of lfvdm_conv_wgrad for this layer shape (1 + tile + 4 * stages + 16 * M slices)."""
+    Cin, M = a.C0 + a.C1, a.N * a.Ho * a.Wo
+    if Cin % 64 or a.C0 % 64 or a.Cout < 64 or a.coefA:
+        return []
+    nchunks = (M + 31) // 32
+    codes = []
+    for tile, cot in ((1, 2), (2, 4)):
+        if cot == 4 and a.Cout < 128:
+            continue
+        tiles = a.ksize * a.ksize * (Cin // 64) * ((a.Cout + 32 * cot - 1) // (32 * cot))
+        for stages in (2, 1):
+            for target in (256, 320, 384, 448, 512, 640, 768, 1024):
+                ms = max(1, min((target + tiles - 1) // tiles, nchunks // 2))
+                code = 1 + tile + 4 * stages + 16 * ms
+                if code not in codes:
+                    codes.append(code)
+    return codes
+
+
+def _tuned_wgrad_code(a, out_floats):
+    """Cached launch code of this weight-gradient shape; measured on first sight (outside stream capture) on SCRATCH
+    outputs - the real launch accumulates.  The weight-gradient kernels are a quarter of a training step and how their
+    (filter tile, channel tile, M slice) workgroups divide the 256 CUs differs per layer."""
+    cache = tune_cache()
+    key = (-1,) + tune_key(a)
+    code = cache.get(key)
+    if code is not None:
+        return code
+    if os.environ.get("LFVDM_AUTOTUNE", "1") == "0" or torch.cuda.is_current_stream_capturing() or deterministic():
+        return 0
+    codes = _wgrad_codes(a)
+    if not codes:
+        cache[key] = 0
+        return 0
+    L, s = lib(), stream()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    scratch, sb = torch.zeros(out_floats, device=dev), torch.zeros(max(a.Cout, 1), device=dev)
+    real_out, real_bias = a.out, a.bias
+    a.out = scratch.data_ptr()
+    if real_bias:
+        a.bias = sb.data_ptr()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best, best_t = 0, float("inf")
+    for code in [0] + codes:
+        a.tune = code
+        if L.lfvdm_conv_wgrad(C.byref(a), s) != 0:
+            continue
+        t_min = float("inf")
+        for _ in range(3):
+            ev0.record()
+            for _ in range(4):
+                L.lfvdm_conv_wgrad(C.byref(a), s)
+            ev1.record()
+            ev1.synchronize()
+            t_min = min(t_min, ev0.elapsed_time(ev1))
+        if t_min < best_t * 0.98:
+            best, best_t = code, t_min
+    a.out, a.bias, a.tune = real_out, real_bias, 0
+    cache[key] = best
+    return best
+
+
 def conv_wgrad(**kw):
     """Weight/bias gradient launch; kw as conv_igemm plus res=dout rows, out=packed dW, bias=db."""
     a = fill_conv_args(**kw)
     if deterministic():
         ws = det_workspace(kw["out"].device)
         a.splitk_ws, a.splitk_ws_floats = ws.data_ptr(), ws.numel()
+    else:
+        a.tune = _tuned_wgrad_code(a, kw["out"].numel())
     check(lib().lfvdm_conv_wgrad(C.byref(a), stream()), "lfvdm_conv_wgrad")
 
 
