@@ -659,9 +659,16 @@ __global__ __launch_bounds__(256) void unpack_conv_grads_kernel(const lfvdm_unpa
         gp[i] = 0.f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int ci = i / J.taps, t = i - ci * J.taps;
-        g[i] += urow[t * ldp + ci];
+    if (J.taps == 9) {          // i / 9 by multiplication (exact below 74906; a row has at most 16384 floats): the generic
+        for (int i = threadIdx.x; i < n; i += 256) {      // division is ~40 instructions per element of a copy kernel
+            const int ci = (int)(((unsigned)i * 58255u) >> 19), t = i - ci * 9;
+            g[i] += urow[t * ldp + ci];
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int ci = i / J.taps, t = i - ci * J.taps;
+            g[i] += urow[t * ldp + ci];
+        }
     }
 }
 
@@ -684,28 +691,27 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const lfvdm_pack
     const int taps = J.taps;
     const int row = 32 * taps + 1;          // padded LDS stride between filters
     const int run = nci * taps;             // contiguous source floats per filter
-    // (index arithmetic through qdiv: the generic integer divisions - three per element - made this copy kernel
-    // instruction-bound: 149 us per training step for 366 MB of traffic)
-    for (int e = threadIdx.x; e < nco * run; e += 256) {
-        const int c = qdiv(e, run), r = e - c * run;
-        tile[c * row + r] = J.src[((size_t)(co0 + c) * J.Cin + ci0) * taps + r];
+    // Thread (i = lane of 32, w = one of 8 rows of lanes): every index is a loop variable - the first version decoded
+    // (filter, channel, tap) from a flat element index with three integer divisions per element and was instruction-bound
+    // (149 us per training step for 366 MB of traffic; reciprocal divisions: 125 us).
+    const int i = threadIdx.x & 31, w = threadIdx.x >> 5;
+    for (int c = w; c < nco; c += 8) {
+        const float* src = J.src + ((size_t)(co0 + c) * J.Cin + ci0) * taps;
+        for (int r = i; r < run; r += 32) tile[c * row + r] = src[r];
     }
     __syncthreads();
-    const int n = nco * nci * taps;
     // ld > natural width: the destination keeps zero padding channels (written once by the host, never here)
     const int ldd = J.ld ? J.ld : (J.transposed ? J.Cout : J.Cin);
-    if (J.transposed) {
-        for (int e = threadIdx.x; e < n; e += 256) {          // (ci, t, co) with co fastest
-            const int r = qdiv(e, nco), c = e - r * nco;
-            const int i = qdiv(r, taps), t = r - i * taps;
-            J.dst[((size_t)(ci0 + i) * taps + t) * ldd + co0 + c] = tile[c * row + i * taps + (taps - 1 - t)];
-        }
-    } else {
-        for (int e = threadIdx.x; e < n; e += 256) {          // (co, t, ci) with ci fastest
-            const int r = qdiv(e, nci), i = e - r * nci;
-            const int c = qdiv(r, taps), t = r - c * taps;
-            J.dst[((size_t)(co0 + c) * taps + t) * ldd + ci0 + i] = tile[c * row + i * taps + t];
-        }
+    if (J.transposed) {                     // [ci][t][co], taps flipped: lanes along co (LDS stride `row`: odd)
+        if (i < nco)
+            for (int ii = w; ii < nci; ii += 8)
+                for (int t = 0; t < taps; ++t)
+                    J.dst[((size_t)(ci0 + ii) * taps + t) * ldd + co0 + i] = tile[i * row + ii * taps + (taps - 1 - t)];
+    } else {                                // [co][t][ci]: lanes along ci (LDS stride `taps`: 9 or 1, odd)
+        if (i < nci)
+            for (int c = w; c < nco; c += 8)
+                for (int t = 0; t < taps; ++t)
+                    J.dst[((size_t)(co0 + c) * taps + t) * ldd + ci0 + i] = tile[c * row + i * taps + t];
     }
 }
 
