@@ -275,7 +275,10 @@ def tune_cache_save():
 
 def autotune_launch(a, rounds=3, reps=6):
     """Time every legal variant of this implicit-GEMM launch (the launch is idempotent) and return the fastest
-    code.  Must not be called while the stream is capturing."""
+    code.  Must not be called while the stream is capturing.  LFVDM_TUNE_REPS / LFVDM_TUNE_ROUNDS: longer measurements
+    (what the committed table was made with: 20 x 5)."""
+    rounds = int(os.environ.get("LFVDM_TUNE_ROUNDS", rounds))
+    reps = int(os.environ.get("LFVDM_TUNE_REPS", reps))
     L, s = lib(), stream()
     codes = (C.c_int * 256)()
     n = L.lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
@@ -404,9 +407,9 @@ def _tuned_wgrad_code(a, out_floats):
         if L.lfvdm_conv_wgrad(C.byref(a), s) != 0:
             continue
         t_min = float("inf")
-        for _ in range(3):
+        for _ in range(int(os.environ.get("LFVDM_TUNE_ROUNDS", 3))):
             ev0.record()
-            for _ in range(4):
+            for _ in range(int(os.environ.get("LFVDM_TUNE_REPS", 4))):
                 L.lfvdm_conv_wgrad(C.byref(a), s)
             ev1.record()
             ev1.synchronize()
