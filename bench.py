@@ -593,6 +593,7 @@ def main():
                                "batch=2 1000-step DDPM on synthetic 4x16x16 latents (BASELINE.json configs[1])",
                    "batch": B, "frames": T, "latent": "4x16x16", "parallelism": f"replicas x{world} (no collective)",
                    "frames_steps_per_s": round(world * total_steps * B * T / el, 1), "finite": finite,
+                   "steps_per_graph_launch": int(getattr(sampler, "K", 1)),
                    "gpus_requested": args.gpus},
     }
     # ---- the collective, self-checked: what the launcher asked for is what the process group is

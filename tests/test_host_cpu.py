@@ -327,3 +327,29 @@ def test_vae_boundary_matches_reference_golden():
     pix = su.create_gaussian_diffusion(steps=1000, diffusion_space_kwargs={"diffusion_space": "pixel", "pre_encoded": False,
                                                                          "pre_encoded_stats_dict": None})
     assert pix.decode(z) is z and pix.encode(px) is px
+
+
+def test_wgrad_tune_codes_are_well_formed():
+    """Candidate launch codes of the weight-gradient tuner (_native._wgrad_codes: 1 + tile + 4 * stages + 16 * M slices):
+    unique, only legal tiles for the filter count, at most half as many M slices as 32-row chunks, none for shapes the
+    LDS-DMA kernels do not take (channels not a multiple of 64, fewer than 64 filters)."""
+    from improved_diffusion import _native as nat
+    a = nat.ConvArgs()
+    a.N, a.Ho, a.Wo, a.C0, a.C1, a.Cout, a.ksize = 40, 16, 16, 128, 0, 128, 3
+    codes = nat._wgrad_codes(a)
+    assert codes and len(set(codes)) == len(codes)
+    nchunks = (40 * 256 + 31) // 32
+    tiles = set()
+    for c in codes:
+        t = c - 1
+        tile, stages, ms = t & 3, (t >> 2) & 3, t >> 4
+        assert tile in (1, 2) and stages in (1, 2) and 1 <= ms <= nchunks // 2
+        tiles.add(tile)
+    assert tiles == {1, 2}
+    a.Cout = 64
+    assert {(c - 1) & 3 for c in nat._wgrad_codes(a)} == {1}, "128-filter tiles need 128 filters"
+    a.C0 = 96
+    assert nat._wgrad_codes(a) == []
+    a.C0, a.Cout = 128, 32
+    assert nat._wgrad_codes(a) == []
+
