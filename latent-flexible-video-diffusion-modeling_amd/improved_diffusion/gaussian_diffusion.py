@@ -594,6 +594,8 @@ class GraphSampler:
     def run(self, i, n):
         """``n`` consecutive steps t = i, i-1, ... (the clock stops at 0): exactly ``step`` n times - the noise is keyed by
         (chain seed, t, element), the clock lives on the device - but K steps per graph launch while at least K remain."""
+        if self.inject_noise and n > 1:
+            raise ValueError("inject_noise: the caller provides the noise of every step - use step()")
         if i != self.expected_t:
             self.t_buf.fill_(i + 1)
         left = int(n)
