@@ -723,6 +723,108 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     }
 }
 
+// The same convolution on the matrix cores, for the latent / pixel models (C + 1 = 5 or 4 input channels: K = 45 / 36).
+// Per workgroup of 64 pixels the composited 3x3 patches are laid out as an im2col tile A[64][KP] in LDS (KP = K padded
+// to a multiple of 4; a thread's pixel is fixed and its k values are wave-uniform: coalesced reads of the (B,T,C,H,W)
+// tensors, scalar tap decode), the filters - OIHW rows ARE [Cout][K] - as W[Cout][KP]; each wave multiplies its 16 pixels
+// by all filters with v_mfma_f32_16x16x4_f32.  Every global load of a phase is issued before the first use (fully
+// unrolled: K is a template parameter): the scalar kernel above measures 11.5 us whatever its arithmetic costs - a first
+// matrix-core version with a rolled gather loop (twelve dependent round trips) measured the same.
+template <int NCT, int CI>      // Cout = 16 NCT; CI = C + 1
+__global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+                                                           const float* __restrict__ obs, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                           int H, int W, ConvInTick tk) {
+    constexpr int Cout = 16 * NCT, C = CI - 1, K = 9 * CI, KP = (K + 3) & ~3, KS = KP + 1;   // odd LDS row stride
+    constexpr int NKI = KP / 4;          // k values per wave (k = wave + 4 i)
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    if (tk.t != nullptr && blockIdx.x == gridDim.x - 1) {        // the clock's workgroup (see conv_in_kernel)
+        int64_t* tnew = reinterpret_cast<int64_t*>(wl);
+        if ((int)threadIdx.x < tk.B) {
+            int64_t v = tk.t[threadIdx.x] - 1;
+            v = v < 0 ? 0 : v;
+            tk.t[threadIdx.x] = v;
+            tk.model_t[threadIdx.x] = tk.table[v];
+            tnew[threadIdx.x] = v;
+        }
+        __syncthreads();
+        const int q4 = tk.row_floats >> 2;
+        for (int e = threadIdx.x; e < tk.B * q4; e += 256) {
+            const int b = e / q4, i = e - b * q4;
+            const float* src = tk.rows_all + ((size_t)tnew[b] * tk.B + b) * tk.rows_ld;
+            st4(tk.rows + (size_t)b * tk.rows_ld + 4 * i, ld4(src + 4 * i));
+        }
+        return;
+    }
+    float* As = wl;                  // [64][KS]
+    float* Ws = wl + 64 * KS;        // [Cout][KS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- all global loads first: the filters (wave w stages rows w, w + 4, ...; lane = k) and the im2col values
+    float wv[Cout / 4];
+#pragma unroll
+    for (int i = 0; i < Cout / 4; ++i) wv[i] = lane < K ? w[(size_t)(wave + 4 * i) * K + lane] : 0.f;
+    const int HW = H * W;
+    const long total = (long)N * HW;
+    const long pix = (long)blockIdx.x * 64 + lane;
+    const bool live = pix < total;
+    const long pp = live ? pix : total - 1;
+    const int n = (int)(pp / HW);
+    const int pq = (int)(pp - (long)n * HW);
+    const int oy = pq / W, ox = pq - oy * W;
+    const float ob = obs[n];
+    const float* xn = x + (size_t)n * C * HW;
+    const float* x0n = x0 + (size_t)n * C * HW;
+    float xa[NKI], xb[NKI];
+    bool inb[NKI];
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+        const int k = wave + 4 * i;              // wave-uniform
+        const int ci = k / 9, tap = k - ci * 9;
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        inb[i] = live && k < K && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int ip = inb[i] ? iy * W + ix : pq;
+        const int cc = ci < C ? ci : 0;
+        xa[i] = xn[cc * HW + ip];
+        xb[i] = x0n[cc * HW + ip];
+    }
+#pragma unroll
+    for (int i = 0; i < Cout / 4; ++i)
+        if (lane < KP) Ws[(wave + 4 * i) * KS + lane] = wv[i];
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+        const int k = wave + 4 * i;
+        const int ci = k / 9;
+        float v = ci < C ? xa[i] * (1.0f - ob) + xb[i] * ob : ob;
+        As[lane * KS + k] = inb[i] ? v : 0.f;
+    }
+    __syncthreads();
+    const int r16 = lane & 15, kq = lane >> 4;
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const float b = bias[16 * c + r16];
+        acc[c] = (f32x4){b, b, b, b};
+    }
+    const float* ar = As + (16 * wave + r16) * KS + kq;
+    const float* wr = Ws + r16 * KS + kq;
+#pragma unroll
+    for (int s4 = 0; s4 < KP; s4 += 4) {
+        const float a = ar[s4];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wr[16 * c * KS + s4], acc[c], 0, 0, 0);
+    }
+    // D: lane holds rows 4 (lane >> 4) + r, column lane & 15 of each 16x16 tile
+    const long p0 = (long)blockIdx.x * 64 + 16 * wave + 4 * kq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (p0 + r < total) {
+            float* o = out + (size_t)(p0 + r) * Cout + r16;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) o[16 * c] = acc[c][r];
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------
 // rowdot: one wave per output row o of a job; up to 8 input rows share each weight load.
 // -------------------------------------------------------------------------------------
@@ -1048,6 +1150,20 @@ static int conv_in_launch(const float* x, const float* x0, const float* obs, con
     if (lds < 64 * sizeof(int64_t)) lds = 64 * sizeof(int64_t);
     const long total = (long)N * H * W;
     const dim3 grid((unsigned)((total + 63) / 64) + (tk.t ? 1u : 0u));
+    {   // matrix-core form (see conv_in_mfma_kernel) for the latent / pixel inputs and 64 / 128 filters
+        static const bool off = getenv("LFVDM_CONV_IN_SCALAR") != nullptr;       // A/B aid
+        if (!off && (C == 4 || C == 3) && (Cout == 64 || Cout == 128)) {
+            const int KP = (9 * (C + 1) + 3) & ~3;
+            size_t l2 = (size_t)(64 + Cout) * (KP + 1) * sizeof(float);
+            if (l2 < 64 * sizeof(int64_t)) l2 = 64 * sizeof(int64_t);
+#define LFVDM_CIM(NCT, CI) hipLaunchKernelGGL((conv_in_mfma_kernel<NCT, CI>), grid, dim3(256), l2, s, x, x0, obs, w, bias, out, N, H, W, tk)
+            if (C == 4) { if (Cout == 64) LFVDM_CIM(4, 5); else LFVDM_CIM(8, 5); }
+            else { if (Cout == 64) LFVDM_CIM(4, 4); else LFVDM_CIM(8, 4); }
+#undef LFVDM_CIM
+            LFVDM_CHECK_LAUNCH();
+            return LFVDM_OK;
+        }
+    }
 #define LFVDM_CONV_IN(Q)                                                                                              \
     case Q:                                                                                                           \
         if (C == 4) hipLaunchKernelGGL((conv_in_kernel<Q, 5>), grid, dim3(256), lds, s, x, x0, obs, w, bias, out, N, C, H, W, tk);      \
