@@ -130,7 +130,20 @@ __global__ __launch_bounds__(256) void conv_out_psample_kernel(const HeadUpdate 
     extern __shared__ __attribute__((aligned(16))) float wl[];      // [CO * 9][C]
     const int tid = threadIdx.x;
     const int C = p.C;
-    for (int i = tid; i < (CO * 9 * C) >> 2; i += 256) st4(wl + 4 * i, ld4(p.Wp + 4 * (size_t)i));
+    {   // filters -> LDS, all loads in flight before the first store (C = 64 CPL: the trip count is a constant)
+        constexpr int NW4 = CO * 9 * 16 * CPL, NIT = (NW4 + 255) / 256;
+        f32x4 wv[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            wv[u] = i < NW4 ? ld4(p.Wp + 4 * (size_t)i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            if (i < NW4) st4(wl + 4 * i, wv[u]);
+        }
+    }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int WQ = p.W >> 2;

@@ -600,6 +600,38 @@ struct ConvInTick {
     int B, rows_ld, row_floats;
 };
 
+// The clock's workgroup.  Its FiLM-row fetch reads a cold corner of the chain's table: the rows are copied eight float4
+// per thread at a time with all loads issued before the first store (the one-load-per-trip loop was six dependent round
+// trips - longer than the convolution's workgroups once those run on the matrix cores).
+__device__ __forceinline__ void conv_in_clock(const ConvInTick& tk, int64_t* tnew) {
+    if ((int)threadIdx.x < tk.B) {
+        int64_t v = tk.t[threadIdx.x] - 1;
+        v = v < 0 ? 0 : v;
+        tk.t[threadIdx.x] = v;
+        tnew[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < tk.B) tk.model_t[threadIdx.x] = tk.table[tnew[threadIdx.x]];     // (off the rows' critical path)
+    const int q4 = tk.row_floats >> 2;
+    for (int b = 0; b < tk.B; ++b) {
+        const float* src = tk.rows_all + ((size_t)tnew[b] * tk.B + b) * tk.rows_ld;
+        float* dst = tk.rows + (size_t)b * tk.rows_ld;
+        for (int i0 = threadIdx.x; i0 < q4; i0 += 256 * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                v[u] = i < q4 ? ld4(src + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < q4) st4(dst + 4 * i, v[u]);
+            }
+        }
+    }
+}
+
 template <int QW, int CIT>      // QW float4 quads of output channels per thread (Cout = 16 * QW); CIT = C + 1 when it is
                                 // known at compile time (4 / 5: the input gather is then fully unrolled), else 0
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ x0,
@@ -609,21 +641,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     constexpr int Cout = 16 * QW;
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [k = ci*9+tap][Cout]
     if (tk.t != nullptr && blockIdx.x == gridDim.x - 1) {        // the clock's workgroup (workgroup-uniform branch)
-        int64_t* tnew = reinterpret_cast<int64_t*>(wl);
-        if ((int)threadIdx.x < tk.B) {
-            int64_t v = tk.t[threadIdx.x] - 1;
-            v = v < 0 ? 0 : v;
-            tk.t[threadIdx.x] = v;
-            tk.model_t[threadIdx.x] = tk.table[v];
-            tnew[threadIdx.x] = v;
-        }
-        __syncthreads();
-        const int q4 = tk.row_floats >> 2;
-        for (int e = threadIdx.x; e < tk.B * q4; e += 256) {
-            const int b = e / q4, i = e - b * q4;
-            const float* src = tk.rows_all + ((size_t)tnew[b] * tk.B + b) * tk.rows_ld;
-            st4(tk.rows + (size_t)b * tk.rows_ld + 4 * i, ld4(src + 4 * i));
-        }
+        conv_in_clock(tk, reinterpret_cast<int64_t*>(wl));
         return;
     }
     const int Ci = CIT ? CIT : C + 1;
@@ -739,21 +757,7 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(const float* __restri
     constexpr int NKI = KP / 4;          // k values per wave (k = wave + 4 i)
     extern __shared__ __attribute__((aligned(16))) float wl[];
     if (tk.t != nullptr && blockIdx.x == gridDim.x - 1) {        // the clock's workgroup (see conv_in_kernel)
-        int64_t* tnew = reinterpret_cast<int64_t*>(wl);
-        if ((int)threadIdx.x < tk.B) {
-            int64_t v = tk.t[threadIdx.x] - 1;
-            v = v < 0 ? 0 : v;
-            tk.t[threadIdx.x] = v;
-            tk.model_t[threadIdx.x] = tk.table[v];
-            tnew[threadIdx.x] = v;
-        }
-        __syncthreads();
-        const int q4 = tk.row_floats >> 2;
-        for (int e = threadIdx.x; e < tk.B * q4; e += 256) {
-            const int b = e / q4, i = e - b * q4;
-            const float* src = tk.rows_all + ((size_t)tnew[b] * tk.B + b) * tk.rows_ld;
-            st4(tk.rows + (size_t)b * tk.rows_ld + 4 * i, ld4(src + 4 * i));
-        }
+        conv_in_clock(tk, reinterpret_cast<int64_t*>(wl));
         return;
     }
     float* As = wl;                  // [64][KS]
