@@ -695,9 +695,27 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const lfvdm_pack
     // (filter, channel, tap) from a flat element index with three integer divisions per element and was instruction-bound
     // (149 us per training step for 366 MB of traffic; reciprocal divisions: 125 us).
     const int i = threadIdx.x & 31, w = threadIdx.x >> 5;
-    for (int c = w; c < nco; c += 8) {
-        const float* src = J.src + ((size_t)(co0 + c) * J.Cin + ci0) * taps;
-        for (int r = i; r < run; r += 32) tile[c * row + r] = src[r];
+    {   // (4 filters x <= 9 runs of 32 floats per thread: all loads in flight before the first LDS write)
+        float v[4][9];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = w + 8 * cc;
+            const float* src = J.src + ((size_t)(co0 + min(c, nco - 1)) * J.Cin + ci0) * taps;
+#pragma unroll
+            for (int rr = 0; rr < 9; ++rr) {
+                const int r = i + 32 * rr;
+                v[cc][rr] = (c < nco && r < run) ? src[r] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = w + 8 * cc;
+#pragma unroll
+            for (int rr = 0; rr < 9; ++rr) {
+                const int r = i + 32 * rr;
+                if (c < nco && r < run) tile[c * row + r] = v[cc][rr];
+            }
+        }
     }
     __syncthreads();
     // ld > natural width: the destination keeps zero padding channels (written once by the host, never here)
