@@ -163,16 +163,30 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float* __restri
 
     for (int kb = 0; kb < P; kb += KB) {
         __syncthreads();  // previous block fully consumed
-        for (int e = threadIdx.x; e < KB * (FP / 4); e += 256) {
-            const int key = e / (FP / 4), fq = e - key * (FP / 4);
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (kb + key < P && fq * 4 < F) {
-                const float* row = base + (size_t)(kb + key) * ld + fq * 4;
-                kv = ld4(row + C);
-                vv = ld4(row + 2 * C);
+        {   // all loads of the block in flight before the first LDS write (the trip count is a compile-time constant)
+            constexpr int NIT = (KB * (FP / 4) + 255) / 256;
+            f32x4 kv[NIT], vv[NIT];
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int e = threadIdx.x + 256 * u;
+                const int key = e / (FP / 4), fq = e - key * (FP / 4);
+                kv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                vv[u] = kv[u];
+                if (e < KB * (FP / 4) && kb + key < P && fq * 4 < F) {
+                    const float* row = base + (size_t)(kb + key) * ld + fq * 4;
+                    kv[u] = ld4(row + C);
+                    vv[u] = ld4(row + 2 * C);
+                }
             }
-            st4(Ks + key * KLD + fq * 4, kv);
-            st4(Vs + key * VLD + fq * 4, vv);
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int e = threadIdx.x + 256 * u;
+                const int key = e / (FP / 4), fq = e - key * (FP / 4);
+                if (e < KB * (FP / 4)) {
+                    st4(Ks + key * KLD + fq * 4, kv[u]);
+                    st4(Vs + key * VLD + fq * 4, vv[u]);
+                }
+            }
         }
         __syncthreads();
 
@@ -295,21 +309,35 @@ __global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const float* __re
 
     for (int yb = 0; yb < P; yb += KB) {
         __syncthreads();   // previous block fully consumed
-        for (int e = threadIdx.x; e < KB * (FP / 4); e += 256) {
-            const int y = e / (FP / 4), fq = e - y * (FP / 4);
-            f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = {0.f, 0.f, 0.f, 0.f};
-            if (yb + y < P && fq * 4 < F) {
-                const float* row = base + (size_t)(yb + y) * ld + fq * 4;
-                if (DKV) {
-                    v1 = ld4(row) * scale;
-                    v2 = ld4(dobase + (size_t)(yb + y) * C + fq * 4);
-                } else {
-                    v1 = ld4(row + C);
-                    v2 = ld4(row + 2 * C);
+        {   // all loads of the block in flight before the first LDS write
+            constexpr int NIT = (KB * (FP / 4) + 255) / 256;
+            f32x4 v1[NIT], v2[NIT];
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int e = threadIdx.x + 256 * u;
+                const int y = e / (FP / 4), fq = e - y * (FP / 4);
+                v1[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                v2[u] = v1[u];
+                if (e < KB * (FP / 4) && yb + y < P && fq * 4 < F) {
+                    const float* row = base + (size_t)(yb + y) * ld + fq * 4;
+                    if (DKV) {
+                        v1[u] = ld4(row) * scale;
+                        v2[u] = ld4(dobase + (size_t)(yb + y) * C + fq * 4);
+                    } else {
+                        v1[u] = ld4(row + C);
+                        v2[u] = ld4(row + 2 * C);
+                    }
                 }
             }
-            st4(A1s + y * LD + fq * 4, v1);
-            st4(A2s + y * LD + fq * 4, v2);
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int e = threadIdx.x + 256 * u;
+                const int y = e / (FP / 4), fq = e - y * (FP / 4);
+                if (e < KB * (FP / 4)) {
+                    st4(A1s + y * LD + fq * 4, v1[u]);
+                    st4(A2s + y * LD + fq * 4, v2[u]);
+                }
+            }
         }
         if (DKV && threadIdx.x < KB) {
             const bool in = yb + (int)threadIdx.x < P;
