@@ -41,7 +41,7 @@ for k, (nf, f, nw, w) in sorted(agg.items(), key=lambda kv: -(2 * kv[1][1] + kv[
     out[k] = {"launches": nf, "fetch_kib_raw_per_launch": round(f / nf, 2), "write_kib_per_launch": round(w / nw, 2),
               "hbm_bytes_per_launch": round((2 * f / nf + w / nw) * 1024)}
 tot_f = sum(a[1] for a in agg.values()); tot_w = sum(a[3] for a in agg.values())
-steps = max(1, sum(1 for r in fetch if "conv_in_kernel" in r["Kernel_Name"]))
+steps = max(1, sum(1 for r in fetch if "conv_in_" in r["Kernel_Name"]))
 out["_whole_step"] = {"launches": len(fetch) // steps, "fetch_kib_raw_per_launch": round(tot_f / steps, 2),
                       "write_kib_per_launch": round(tot_w / steps, 2),
                       "hbm_bytes_per_launch": round((2 * tot_f + tot_w) * 1024 / steps)}
