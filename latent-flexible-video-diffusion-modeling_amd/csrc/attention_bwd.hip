@@ -574,13 +574,19 @@ __global__ __launch_bounds__(256) void rpe_nets_bwd_kernel(const lfvdm_rpe_bwd_j
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        for (int kc = 0; kc < C; kc += 32) {                // d_act[r][c] = sum_o dR[r][o] * Wout_t[c][o]
-            f32x4 w[4];
+        // (the filter chunk of step kc + 32 is in flight while chunk kc is multiplied: see rpe_nets_kernel)
+        f32x4 w[4];
+        const float* wsrc = J.Wout_t + (size_t)(nt * 32 + (lane >> 3)) * C + (lane & 7) * 4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = ld4(J.Wout_t + (size_t)(nt * 32 + r * 8 + (lane >> 3)) * C + kc + (lane & 7) * 4);
+        for (int r = 0; r < 4; ++r) w[r] = ld4(wsrc + (size_t)r * 8 * C);
+        for (int kc = 0; kc < C; kc += 32) {                // d_act[r][c] = sum_o dR[r][o] * Wout_t[c][o]
 #pragma unroll
             for (int r = 0; r < 4; ++r) st4(Wst + r * 8 * RPB_LDR + st_off, w[r]);
             wave_lds_fence();
+            if (kc + 32 < C) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = ld4(wsrc + (size_t)r * 8 * C + kc + 32);
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 a4 = ld4(As + fra + kc + g * 8);
