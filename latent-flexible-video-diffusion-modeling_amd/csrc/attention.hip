@@ -53,16 +53,22 @@ __global__ __launch_bounds__(256) void rpe_nets_kernel(const lfvdm_rpe_job* __re
         rowf[threadIdx.x][0] = f0; rowf[threadIdx.x][1] = f1; rowf[threadIdx.x][2] = f2; rowf[threadIdx.x][3] = fb;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * C; e += 256) {
-        const int r = e / C, k = e - r * C;
-        float v = 0.f;
-        if (rowf[r][3] >= 0.f) {
-            const int b = (int)rowf[r][3];
-            const float hd = (rowf[r][0] * J.Wd[k * 3 + 0] + rowf[r][1] * J.Wd[k * 3 + 1] + rowf[r][2] * J.Wd[k * 3 + 2]) + J.bd[k];
-            v = silu_f(J.tproj[b * J.tproj_ld + k] + hd);
-            if (J.act != nullptr) J.act[(size_t)(m0 + r) * C + k] = v;
+    // thread = (row wave + 4 i, column lane + 64 j): no per-element index division, the column's three feature weights
+    // and bias loaded once for its 8 rows (same arithmetic per element as before)
+    for (int k = lane; k < C; k += 64) {
+        const float w0 = J.Wd[k * 3 + 0], w1 = J.Wd[k * 3 + 1], w2 = J.Wd[k * 3 + 2], bk = J.bd[k];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave + 4 * i;
+            float v = 0.f;
+            if (rowf[r][3] >= 0.f) {
+                const int b = (int)rowf[r][3];
+                const float hd = (rowf[r][0] * w0 + rowf[r][1] * w1 + rowf[r][2] * w2) + bk;
+                v = silu_f(J.tproj[b * J.tproj_ld + k] + hd);
+                if (J.act != nullptr) J.act[(size_t)(m0 + r) * C + k] = v;
+            }
+            As[r * ALD + k] = v;
         }
-        As[r * ALD + k] = v;
     }
     __syncthreads();
 

@@ -559,11 +559,16 @@ __global__ __launch_bounds__(256) void rpe_nets_bwd_kernel(const lfvdm_rpe_bwd_j
         }
         rowf[threadIdx.x][0] = f0; rowf[threadIdx.x][1] = f1; rowf[threadIdx.x][2] = f2; rowf[threadIdx.x][3] = fb;
     }
-    for (int e = threadIdx.x; e < 32 * (C / 4); e += 256) {
-        const int r = e / (C / 4), k = (e - r * (C / 4)) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + r < M) v = ld4(J.dR + (size_t)(m0 + r) * C + k);
-        st4(As + r * ALD + k, v);
+    // thread = (row wave + 4 i, float4 column lane + 64 j): the loads of a column's 8 rows in flight together
+    for (int k = lane * 4; k < C; k += 256) {
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave + 4 * i;
+            v[i] = (m0 + r < M) ? ld4(J.dR + (size_t)(m0 + r) * C + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st4(As + (wave + 4 * i) * ALD + k, v[i]);
     }
     __syncthreads();
     const int b_lo = m0 / TT;                               // T*T >= 32: the tile spans batch elements b_lo, b_lo + 1
