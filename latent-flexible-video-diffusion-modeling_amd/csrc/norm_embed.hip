@@ -943,19 +943,31 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const lfvdm_rowdot_bwd_
                         }
                     }
                 }
-                for (int o = o0; o < o1; ++o) {
-                    const f32x4 wv = ld4(J.W + (size_t)o * J.K + k);
-                    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                // the task's RDB_ROWS output rows: weight rows, gradient rows and dout values are all requested before the
+                // first use (one row per trip was a chain of dependent round trips: 32 us per launch)
+                f32x4 wv[RDB_ROWS], gv[RDB_ROWS];
+                float dv[RDB_ROWS][4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (i < mc) {
-                            const float d = J.dout[(size_t)(m0 + i) * J.lddout + o];
-                            g += inv[i] * d;
-                            accD[i] += wv * d;
+                for (int u = 0; u < RDB_ROWS; ++u) {
+                    const int o = min(o0 + u, o1 - 1);
+                    wv[u] = ld4(J.W + (size_t)o * J.K + k);
+                    gv[u] = ld4(J.dW + (size_t)o * J.K + k);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dv[u][i] = i < mc ? J.dout[(size_t)(m0 + i) * J.lddout + o] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < RDB_ROWS; ++u) {
+                    if (o0 + u < o1) {
+                        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (i < mc) {
+                                g += inv[i] * dv[u][i];
+                                accD[i] += wv[u] * dv[u][i];
+                            }
                         }
+                        st4(J.dW + (size_t)(o0 + u) * J.K + k, gv[u] + g);
                     }
-                    float* gw = J.dW + (size_t)o * J.K + k;
-                    st4(gw, ld4(gw) + g);
                 }
                 if (grouped) {                       // (M <= 4: a single m0 pass; `it` < RDB_KIT)
 #pragma unroll
