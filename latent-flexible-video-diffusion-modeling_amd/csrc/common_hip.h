@@ -46,6 +46,17 @@ __device__ __forceinline__ float silu_f(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
+// floor(a / d) for 0 <= a < 2^21, d >= 1, rd = v_rcp_f32(d): the truncated product is off by at most one and the
+// fix-up repairs it (a generic 32-bit division is ~30 instructions; the normalisation kernels did eight per thread to
+// find the group of a channel)
+__device__ __forceinline__ int fdiv_small(int a, int d, float rd) {
+    int q = (int)((float)a * rd);
+    const int r = a - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 

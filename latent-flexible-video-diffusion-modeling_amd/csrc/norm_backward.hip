@@ -31,6 +31,7 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_stats_kernel(
     float* __restrict__ sums) {
     const int C = C0 + C1;
     const int cg = C / 32;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int CW = GB_GPW * cg;
     const int Q = CW / 4;
     const int n = blockIdx.x;
@@ -48,10 +49,10 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_stats_kernel(
         const f32x4 A = ld4(coefA + (size_t)n * C + c), B = ld4(coefB + (size_t)n * C + c);
         f32x4 mu, rs;
         const float* st = stats + (size_t)n * 64;
-        mu.x = st[2 * ((c + 0) / cg)]; rs.x = st[2 * ((c + 0) / cg) + 1];
-        mu.y = st[2 * ((c + 1) / cg)]; rs.y = st[2 * ((c + 1) / cg) + 1];
-        mu.z = st[2 * ((c + 2) / cg)]; rs.z = st[2 * ((c + 2) / cg) + 1];
-        mu.w = st[2 * ((c + 3) / cg)]; rs.w = st[2 * ((c + 3) / cg) + 1];
+        mu.x = st[2 * (fdiv_small(c + 0, cg, rcg))]; rs.x = st[2 * (fdiv_small(c + 0, cg, rcg)) + 1];
+        mu.y = st[2 * (fdiv_small(c + 1, cg, rcg))]; rs.y = st[2 * (fdiv_small(c + 1, cg, rcg)) + 1];
+        mu.z = st[2 * (fdiv_small(c + 2, cg, rcg))]; rs.z = st[2 * (fdiv_small(c + 2, cg, rcg)) + 1];
+        mu.w = st[2 * (fdiv_small(c + 3, cg, rcg))]; rs.w = st[2 * (fdiv_small(c + 3, cg, rcg)) + 1];
         const size_t pos0 = (size_t)n * P;
         for (int p = pl; p < P; p += PL) {
             const f32x4 x = ldcat(s0, s1p, C0, C1, pos0 + p, c);
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
     GnParamGradArgs pg) {
     const int C = C0 + C1;
     const int cg = C / 32;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int CW = GB_GPW * cg;
     const int Q = CW / 4;
     const int n = blockIdx.x;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
     f32x4 mu, rs, S1, S2;
     const float* st = stats + (size_t)n * 64;
 #define LFVDM_G(k, f)                                                             \
-    { const int g = (c + k) / cg; mu.f = st[2 * g]; rs.f = st[2 * g + 1];         \
+    { const int g = fdiv_small(c + k, cg, rcg); mu.f = st[2 * g]; rs.f = st[2 * g + 1];         \
       S1.f = gS1[g - blockIdx.y * GB_GPW]; S2.f = gS2[g - blockIdx.y * GB_GPW]; }
     LFVDM_G(0, x) LFVDM_G(1, y) LFVDM_G(2, z) LFVDM_G(3, w)
 #undef LFVDM_G
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_fused_kernel(
     float* __restrict__ out0, float* __restrict__ out1, GnParamGradArgs pg) {
     const int C = C0 + C1;
     const int cg = C / 32;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int CW = GB_GPW * cg;
     const int Q = CW / 4;
     const int n = blockIdx.x;
@@ -194,10 +197,10 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_fused_kernel(
     const f32x4 A = ld4(coefA + (size_t)n * C + c), B = ld4(coefB + (size_t)n * C + c);
     f32x4 mu, rs;
     const float* st = stats + (size_t)n * 64;
-    mu.x = st[2 * ((c + 0) / cg)]; rs.x = st[2 * ((c + 0) / cg) + 1];
-    mu.y = st[2 * ((c + 1) / cg)]; rs.y = st[2 * ((c + 1) / cg) + 1];
-    mu.z = st[2 * ((c + 2) / cg)]; rs.z = st[2 * ((c + 2) / cg) + 1];
-    mu.w = st[2 * ((c + 3) / cg)]; rs.w = st[2 * ((c + 3) / cg) + 1];
+    mu.x = st[2 * (fdiv_small(c + 0, cg, rcg))]; rs.x = st[2 * (fdiv_small(c + 0, cg, rcg)) + 1];
+    mu.y = st[2 * (fdiv_small(c + 1, cg, rcg))]; rs.y = st[2 * (fdiv_small(c + 1, cg, rcg)) + 1];
+    mu.z = st[2 * (fdiv_small(c + 2, cg, rcg))]; rs.z = st[2 * (fdiv_small(c + 2, cg, rcg)) + 1];
+    mu.w = st[2 * (fdiv_small(c + 3, cg, rcg))]; rs.w = st[2 * (fdiv_small(c + 3, cg, rcg)) + 1];
     const size_t pos0 = (size_t)n * P;
     const bool silu = act == LFVDM_ACT_SILU;
     f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
@@ -259,10 +262,10 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_fused_kernel(
     __syncthreads();
     if (!active) return;
     f32x4 S1, S2;
-    S1.x = gS1[(q * 4 + 0) / cg]; S2.x = gS2[(q * 4 + 0) / cg];
-    S1.y = gS1[(q * 4 + 1) / cg]; S2.y = gS2[(q * 4 + 1) / cg];
-    S1.z = gS1[(q * 4 + 2) / cg]; S2.z = gS2[(q * 4 + 2) / cg];
-    S1.w = gS1[(q * 4 + 3) / cg]; S2.w = gS2[(q * 4 + 3) / cg];
+    S1.x = gS1[fdiv_small(q * 4 + 0, cg, rcg)]; S2.x = gS2[fdiv_small(q * 4 + 0, cg, rcg)];
+    S1.y = gS1[fdiv_small(q * 4 + 1, cg, rcg)]; S2.y = gS2[fdiv_small(q * 4 + 1, cg, rcg)];
+    S1.z = gS1[fdiv_small(q * 4 + 2, cg, rcg)]; S2.z = gS2[fdiv_small(q * 4 + 2, cg, rcg)];
+    S1.w = gS1[fdiv_small(q * 4 + 3, cg, rcg)]; S2.w = gS2[fdiv_small(q * 4 + 3, cg, rcg)];
     const bool first = c < C0;
     float* out = first ? out0 : out1;
     const int Cd = first ? C0 : C1;
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
     float* gS2 = gst_all[wave][3];
     const int b = (int)(sample / P), p = (int)(sample % P);
     const int cg = C / 32;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int Q = C / 4;
     const size_t base = ((size_t)b * T * P + p) * C;
     const size_t tstride = (size_t)P * C;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
     for (int pass = 0; pass < 2; ++pass) {
         for (int q = ql; q < Q; q += QL) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f};
-            if (pass) { mu.x = gmean[(q * 4) / cg]; mu.y = gmean[(q * 4 + 1) / cg]; mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg]; }
+            if (pass) { mu.x = gmean[fdiv_small(q * 4, cg, rcg)]; mu.y = gmean[fdiv_small(q * 4 + 1, cg, rcg)]; mu.z = gmean[fdiv_small(q * 4 + 2, cg, rcg)]; mu.w = gmean[fdiv_small(q * 4 + 3, cg, rcg)]; }
             for (int t = tl; t < T; t += TL) {
                 f32x4 v = ld4(x + base + t * tstride + q * 4);
                 if (pass) { v = v - mu; s += v * v; } else { s += v; }
@@ -348,8 +352,8 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
     // per-channel sums of dy and dy*xhat
     for (int q = ql; q < Q; q += QL) {
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, mu, rs;
-        mu.x = gmean[(q * 4) / cg]; mu.y = gmean[(q * 4 + 1) / cg]; mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg];
-        rs.x = grstd[(q * 4) / cg]; rs.y = grstd[(q * 4 + 1) / cg]; rs.z = grstd[(q * 4 + 2) / cg]; rs.w = grstd[(q * 4 + 3) / cg];
+        mu.x = gmean[fdiv_small(q * 4, cg, rcg)]; mu.y = gmean[fdiv_small(q * 4 + 1, cg, rcg)]; mu.z = gmean[fdiv_small(q * 4 + 2, cg, rcg)]; mu.w = gmean[fdiv_small(q * 4 + 3, cg, rcg)];
+        rs.x = grstd[fdiv_small(q * 4, cg, rcg)]; rs.y = grstd[fdiv_small(q * 4 + 1, cg, rcg)]; rs.z = grstd[fdiv_small(q * 4 + 2, cg, rcg)]; rs.w = grstd[fdiv_small(q * 4 + 3, cg, rcg)];
         for (int t = tl; t < T; t += TL) {
             const f32x4 xv = ld4(x + base + t * tstride + q * 4);
             const f32x4 d = ld4(dy + base + t * tstride + q * 4);
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_kernel(const float* __res
         const f32x4 ga = ld4(gamma + q * 4);
         f32x4 o;
 #define LFVDM_T(k, f)                                                                                   \
-    { const int g = (q * 4 + k) / cg; const float xh = (xv.f - gmean[g]) * grstd[g];                    \
+    { const int g = fdiv_small(q * 4 + k, cg, rcg); const float xh = (xv.f - gmean[g]) * grstd[g];                    \
       o.f = grstd[g] * (ga.f * d.f - (gS1[g] + xh * gS2[g])); }
         LFVDM_T(0, x) LFVDM_T(1, y) LFVDM_T(2, z) LFVDM_T(3, w)
 #undef LFVDM_T
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_reg_kernel(const float* _
     float* gS2 = gst_all[wave][3];
     const int b = (int)(sample / P), p = (int)(sample % P);
     const int cg = C / 32;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int Q = C / 4;                 // <= 64, divides 64
     const size_t base = ((size_t)b * T * P + p) * C;
     const size_t tstride = (size_t)P * C;
@@ -469,11 +474,11 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_reg_kernel(const float* _
         }
         wave_lds_fence();
         if (pass == 0) {
-            mu.x = gmean[(q * 4 + 0) / cg]; mu.y = gmean[(q * 4 + 1) / cg];
-            mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg];
+            mu.x = gmean[fdiv_small(q * 4 + 0, cg, rcg)]; mu.y = gmean[fdiv_small(q * 4 + 1, cg, rcg)];
+            mu.z = gmean[fdiv_small(q * 4 + 2, cg, rcg)]; mu.w = gmean[fdiv_small(q * 4 + 3, cg, rcg)];
         } else {
-            rs.x = grstd[(q * 4 + 0) / cg]; rs.y = grstd[(q * 4 + 1) / cg];
-            rs.z = grstd[(q * 4 + 2) / cg]; rs.w = grstd[(q * 4 + 3) / cg];
+            rs.x = grstd[fdiv_small(q * 4 + 0, cg, rcg)]; rs.y = grstd[fdiv_small(q * 4 + 1, cg, rcg)];
+            rs.z = grstd[fdiv_small(q * 4 + 2, cg, rcg)]; rs.w = grstd[fdiv_small(q * 4 + 3, cg, rcg)];
         }
     }
     // per-channel sums of dy and dy * xhat (xhat replaces x in the registers)
@@ -517,8 +522,8 @@ __global__ __launch_bounds__(256) void gn_temporal_bwd_reg_kernel(const float* _
     }
     if (!live) return;
     f32x4 S1, S2;
-    S1.x = gS1[(q * 4 + 0) / cg]; S1.y = gS1[(q * 4 + 1) / cg]; S1.z = gS1[(q * 4 + 2) / cg]; S1.w = gS1[(q * 4 + 3) / cg];
-    S2.x = gS2[(q * 4 + 0) / cg]; S2.y = gS2[(q * 4 + 1) / cg]; S2.z = gS2[(q * 4 + 2) / cg]; S2.w = gS2[(q * 4 + 3) / cg];
+    S1.x = gS1[fdiv_small(q * 4 + 0, cg, rcg)]; S1.y = gS1[fdiv_small(q * 4 + 1, cg, rcg)]; S1.z = gS1[fdiv_small(q * 4 + 2, cg, rcg)]; S1.w = gS1[fdiv_small(q * 4 + 3, cg, rcg)];
+    S2.x = gS2[fdiv_small(q * 4 + 0, cg, rcg)]; S2.y = gS2[fdiv_small(q * 4 + 1, cg, rcg)]; S2.z = gS2[fdiv_small(q * 4 + 2, cg, rcg)]; S2.w = gS2[fdiv_small(q * 4 + 3, cg, rcg)];
 #pragma unroll
     for (int i = 0; i < TIT; ++i) {
         const int t = tl + i * TL;

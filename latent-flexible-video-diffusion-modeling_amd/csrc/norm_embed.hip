@@ -26,6 +26,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
     float* __restrict__ act_out, int act_mode) {
     const int C = C0 + C1;
     const int cg = C / 32;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int CW = GN_GPW * cg;       // channels handled here
     const int Q = CW / 4;             // float4 quads
     const int n = blockIdx.x;
@@ -51,8 +52,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
         if (active) {
             f32x4 mu = {0.f, 0.f, 0.f, 0.f};
             if (pass) {
-                mu.x = gmean[(q * 4 + 0) / cg]; mu.y = gmean[(q * 4 + 1) / cg];
-                mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg];
+                mu.x = gmean[fdiv_small(q * 4 + 0, cg, rcg)]; mu.y = gmean[fdiv_small(q * 4 + 1, cg, rcg)];
+                mu.z = gmean[fdiv_small(q * 4 + 2, cg, rcg)]; mu.w = gmean[fdiv_small(q * 4 + 3, cg, rcg)];
             }
             if (cached) {
 #pragma unroll
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
     }
     for (int cc = tid; cc < CW; cc += GN_THREADS) {
         const int ch = cbase + cc;
-        const int g = cc / cg;
+        const int g = fdiv_small(cc, cg, rcg);
         float A = grstd[g] * gamma[ch];
         float B = beta[ch] - gmean[g] * A;
         if (film) {
@@ -296,6 +297,7 @@ __device__ __forceinline__ void gn_chunk_load(const float* s0, const float* s1, 
 __global__ __launch_bounds__(GN_THREADS) void gn_chunk_stats_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
                                                                     GnChunkGeom g, float* __restrict__ part_out) {
     const int C = g.C0 + g.C1, cg = C / 32, CW = GN_GPW * cg, Q = CW / 4, PL = g.PL;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int sidx = blockIdx.x, n = blockIdx.z, cbase = blockIdx.y * CW;
     const int tid = threadIdx.x;
     const bool active = tid < PL * Q;
@@ -313,8 +315,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_stats_kernel(const float*
         if (active) {
             f32x4 mu = {0.f, 0.f, 0.f, 0.f};
             if (pass) {
-                mu.x = gmean[(q * 4 + 0) / cg]; mu.y = gmean[(q * 4 + 1) / cg];
-                mu.z = gmean[(q * 4 + 2) / cg]; mu.w = gmean[(q * 4 + 3) / cg];
+                mu.x = gmean[fdiv_small(q * 4 + 0, cg, rcg)]; mu.y = gmean[fdiv_small(q * 4 + 1, cg, rcg)];
+                mu.z = gmean[fdiv_small(q * 4 + 2, cg, rcg)]; mu.w = gmean[fdiv_small(q * 4 + 3, cg, rcg)];
             }
 #pragma unroll
             for (int i = 0; i < GN_KEEP; ++i) {
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_apply_kernel(
     int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats,
     float* __restrict__ act_out, int act_mode) {
     const int C = g.C0 + g.C1, cg = C / 32, CW = GN_GPW * cg, Q = CW / 4, PL = g.PL;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int sidx = blockIdx.x, n = blockIdx.z, cbase = blockIdx.y * CW;
     const int tid = threadIdx.x;
     const bool active = tid < PL * Q;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_chunk_apply_kernel(
     }
     for (int cc = tid; cc < CW; cc += GN_THREADS) {
         const int ch = cbase + cc;
-        const int gi = cc / cg;
+        const int gi = fdiv_small(cc, cg, rcg);
         float A = grstd[gi] * gamma[ch];
         float B = beta[ch] - gmean[gi] * A;
         if (film) {
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
     float* gstat = gstat_all[wave];
     const int b = (int)(sample / P), p = (int)(sample % P);
     const int cg = C / 32;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int Q = C / 4;
     const size_t base = ((size_t)b * T * P + p) * C;
     const size_t tstride = (size_t)P * C;
@@ -469,8 +473,8 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
             f32x4 mu = {0.f, 0.f, 0.f, 0.f};
             if (pass) {
-                mu.x = gstat[(q * 4 + 0) / cg]; mu.y = gstat[(q * 4 + 1) / cg];
-                mu.z = gstat[(q * 4 + 2) / cg]; mu.w = gstat[(q * 4 + 3) / cg];
+                mu.x = gstat[fdiv_small(q * 4 + 0, cg, rcg)]; mu.y = gstat[fdiv_small(q * 4 + 1, cg, rcg)];
+                mu.z = gstat[fdiv_small(q * 4 + 2, cg, rcg)]; mu.w = gstat[fdiv_small(q * 4 + 3, cg, rcg)];
             }
             for (int t = tl; t < T; t += TL) {
                 f32x4 v = ld4(x + base + t * tstride + q * 4);
@@ -497,10 +501,10 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
         f32x4 v = ld4(x + base + t * tstride + q * 4);
         const f32x4 ga = ld4(gamma + q * 4), be = ld4(beta + q * 4);
         f32x4 o;
-        o.x = (v.x - gstat[(q * 4 + 0) / cg]) * gstat[32 + (q * 4 + 0) / cg] * ga.x + be.x;
-        o.y = (v.y - gstat[(q * 4 + 1) / cg]) * gstat[32 + (q * 4 + 1) / cg] * ga.y + be.y;
-        o.z = (v.z - gstat[(q * 4 + 2) / cg]) * gstat[32 + (q * 4 + 2) / cg] * ga.z + be.z;
-        o.w = (v.w - gstat[(q * 4 + 3) / cg]) * gstat[32 + (q * 4 + 3) / cg] * ga.w + be.w;
+        o.x = (v.x - gstat[fdiv_small(q * 4 + 0, cg, rcg)]) * gstat[32 + fdiv_small(q * 4 + 0, cg, rcg)] * ga.x + be.x;
+        o.y = (v.y - gstat[fdiv_small(q * 4 + 1, cg, rcg)]) * gstat[32 + fdiv_small(q * 4 + 1, cg, rcg)] * ga.y + be.y;
+        o.z = (v.z - gstat[fdiv_small(q * 4 + 2, cg, rcg)]) * gstat[32 + fdiv_small(q * 4 + 2, cg, rcg)] * ga.z + be.z;
+        o.w = (v.w - gstat[fdiv_small(q * 4 + 3, cg, rcg)]) * gstat[32 + fdiv_small(q * 4 + 3, cg, rcg)] * ga.w + be.w;
         st4(y + base + t * tstride + q * 4, o);
     }
 }
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(256) void gn_temporal_reg_kernel(const float* __res
     float* gstat = gstat_all[wave];
     const int b = (int)(sample / P), p = (int)(sample % P);
     const int cg = C / 32;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
     const int Q = C / 4;                 // <= 64, divides 64
     const size_t base = ((size_t)b * T * P + p) * C;
     const size_t tstride = (size_t)P * C;
@@ -559,11 +564,11 @@ __global__ __launch_bounds__(256) void gn_temporal_reg_kernel(const float* __res
         }
         wave_lds_fence();
         if (pass == 0) {
-            mu.x = gstat[(q * 4 + 0) / cg]; mu.y = gstat[(q * 4 + 1) / cg];
-            mu.z = gstat[(q * 4 + 2) / cg]; mu.w = gstat[(q * 4 + 3) / cg];
+            mu.x = gstat[fdiv_small(q * 4 + 0, cg, rcg)]; mu.y = gstat[fdiv_small(q * 4 + 1, cg, rcg)];
+            mu.z = gstat[fdiv_small(q * 4 + 2, cg, rcg)]; mu.w = gstat[fdiv_small(q * 4 + 3, cg, rcg)];
         } else {
-            rs.x = gstat[32 + (q * 4 + 0) / cg]; rs.y = gstat[32 + (q * 4 + 1) / cg];
-            rs.z = gstat[32 + (q * 4 + 2) / cg]; rs.w = gstat[32 + (q * 4 + 3) / cg];
+            rs.x = gstat[32 + fdiv_small(q * 4 + 0, cg, rcg)]; rs.y = gstat[32 + fdiv_small(q * 4 + 1, cg, rcg)];
+            rs.z = gstat[32 + fdiv_small(q * 4 + 2, cg, rcg)]; rs.w = gstat[32 + fdiv_small(q * 4 + 3, cg, rcg)];
         }
     }
     const f32x4 ga = ld4(gamma + q * 4), be = ld4(beta + q * 4);
