@@ -167,9 +167,12 @@ __device__ __forceinline__ void wgrad_wave_task(const lfvdm_conv_args& p, int ms
             bsum.x += __shfl_xor(bsum.x, o, 64); bsum.y += __shfl_xor(bsum.y, o, 64);
             bsum.z += __shfl_xor(bsum.z, o, 64); bsum.w += __shfl_xor(bsum.w, o, 64);
         }
-        if (lane < 8 && co0 + col < p.Cout) {
-            det_add(dsB, ms, db + co0 + col + 0, bsum.x); det_add(dsB, ms, db + co0 + col + 1, bsum.y);
-            det_add(dsB, ms, db + co0 + col + 2, bsum.z); det_add(dsB, ms, db + co0 + col + 3, bsum.w);
+        if (lane < 8) {     // every column guarded on its own: Cout need not be a multiple of 4 (pixel-space head: 3)
+            const int c = co0 + col;
+            if (c + 0 < p.Cout) det_add(dsB, ms, db + c + 0, bsum.x);
+            if (c + 1 < p.Cout) det_add(dsB, ms, db + c + 1, bsum.y);
+            if (c + 2 < p.Cout) det_add(dsB, ms, db + c + 2, bsum.z);
+            if (c + 3 < p.Cout) det_add(dsB, ms, db + c + 3, bsum.w);
         }
     }
 }

@@ -287,13 +287,38 @@ class _SkipSlot:
     and the kernel that produces the next stage's gradient of h adds it on the way out (``res`` of the data-gradient
     GEMM, ``add2`` of the fused GroupNorm backward)."""
     __slots__ = ("g",)
+    pending = []            # slots filled in the running backward pass and not yet drained
+    queued = False
 
     def __init__(self):
         self.g = None
 
+    def put(self, g):
+        """The decoder block leaves its gradient of the skip tensor.  The hand-off takes this gradient OUT of autograd, so
+        it is checked: at the end of the backward pass every filled slot must have been drained by its consumer."""
+        assert self.g is None, "skip-gradient slot filled twice in one backward pass"
+        self.g = g
+        _SkipSlot.pending.append(self)
+        if not _SkipSlot.queued:
+            _SkipSlot.queued = True
+            th.autograd.Variable._execution_engine.queue_callback(_SkipSlot.check_drained)
+
     def take(self):
         g, self.g = self.g, None
         return g
+
+    @staticmethod
+    def check_drained():
+        """End-of-backward callback: a slot that is still full means its consumer never ran or did not compute an input
+        gradient (a partial ``torch.autograd.grad(..., inputs=subset)``, a first layer without an input gradient): the
+        decoder's contribution would be dropped silently.  LFVDM_NO_SKIP_SLOTS=1 gives the plain autograd sums."""
+        left = [s for s in _SkipSlot.pending if s.g is not None]
+        _SkipSlot.pending, _SkipSlot.queued = [], False
+        for s in left:
+            s.g = None
+        if left:
+            raise RuntimeError(f"{len(left)} skip-connection gradient(s) were handed to a consumer that never ran in this "
+                               "backward pass (partial backward?) - set LFVDM_NO_SKIP_SLOTS=1 for such calls")
 
 
 # ----------------------------------------------------------------------------- plain conv (in / down / up)
@@ -333,6 +358,8 @@ class ConvFn(th.autograd.Function):
         else:
             dw, db = _wgrad_into(tuple(w.shape), x, **wkw)
         dx = None
+        if ctx.x_slot is not None and ctx.x_slot.g is not None and not ctx.needs_input_grad[0]:
+            raise RuntimeError("a skip-connection gradient was handed to a convolution that computes no input gradient")
         if ctx.needs_input_grad[0]:
             wt = _pack_t(w)
             if stride == 2:   # transposed conv: zero-insertion gather of dout on the (2Ho x 2Wo) grid
@@ -576,7 +603,8 @@ class ResBlockFn(th.autograd.Function):
         dxa, dxb, dg1, dbe1, _ = _gn_backward(da1, a, b, C0, C1, N, P, cA1, cB1, st1, nat.ACT_SILU, g1, be1, None, T,
                                               inplace=inplace, add=skip_grad, add2=extra)
         if ctx.b_slot is not None:
-            ctx.b_slot.g, dxb = dxb, None
+            ctx.b_slot.put(dxb)
+            dxb = None
         return (dxa, dxb, dfilm, dg1, dbe1, dw1, db1, dg2, dbe2, dw2, db2, dws, dbs, None, None, None, None, None, None,
                 None, None)
 

@@ -111,6 +111,7 @@ class GradExchange:
         self.micro_steps = 0               # every micro-step (eager or replayed) bumps every early counter once
         self.wait_timeout_s = float(os.environ.get("LFVDM_FLAG_TIMEOUT_S", "20"))
         self.overlap_probe = None
+        self.timeouts_seen = 0
         self._late = []                    # (pinned word, event): the timed-out word of earlier steps, read one step late
         if self.overlap:
             from . import _native as nat
@@ -156,9 +157,12 @@ class GradExchange:
 
     def poll_timeout(self, sync=False):
         """Once per optimizer step, after the optimizer launch: raises if a bucket's wait on the backward graph timed out
-        in an EARLIER step (sync=True: in any step so far).  The optimizer launch of such a step has skipped its update,
-        so parameters, moments and EMA are those of the last good step.  No host stall: the word travels through pinned
-        memory behind the step's work and is read when its event has completed - normally one step late."""
+        on ANY rank in the PREVIOUS step (sync=True: in any step so far).  The decision is collective: ``launch`` ends
+        with a MAX all-reduce of the timed-out word behind the bucket collectives, so the word the optimizer launch reads
+        (``skip_flag``) is the same on every rank - either every replica applies the step or none does - and the word of
+        step s is examined by every rank at exactly step s + 1 (fixed lag: its event is normally long complete when the
+        host gets here, the host runs at most one step ahead of the GPU anyway), so all ranks raise in the same step and
+        nobody is left alone in a collective.  Parameters, moments and EMA are then those of the last good step."""
         if self.flags is None:
             return
         if sync:
@@ -170,14 +174,26 @@ class GradExchange:
             ev.record()
             self._late.append((host, ev))
             bad = False
-            while self._late and (self._late[0][1].query() or len(self._late) > 2):
+            while len(self._late) > 1:              # everything but the word just enqueued: fixed one-step lag
                 h, e = self._late.pop(0)
                 e.synchronize()
                 bad = bad or bool(h.item())
         if bad:
-            self.overlap = False            # whoever catches this and carries on gets the exchange behind the graph's end
-            raise RuntimeError("gradient exchange: a bucket's wait on the backward graph timed out (lfvdm_flag_wait); the "
-                               "optimizer skipped that step - parameters are those of the last good step")
+            self.reset_timeout()
+            raise RuntimeError("gradient exchange: a bucket's wait on the backward graph timed out (lfvdm_flag_wait) on "
+                               "at least one rank; every rank's optimizer skipped that step - parameters are those of "
+                               "the last good step")
+
+    def reset_timeout(self):
+        """After a timeout has been reported: whoever catches the error and carries on gets the exchange behind the
+        graph's end (no device-side waits any more), with a CLEARED word - otherwise every later optimizer launch would
+        skip as well.  Collective by construction: every rank gets here in the same step (poll_timeout)."""
+        self.overlap = False
+        self.timeouts_seen += 1
+        self._late = []
+        if self.flags is not None:
+            th.cuda.current_stream().wait_stream(self.comm)
+            self.flags.buf[self.flags.n].zero_()
 
     # ------------------------------------------------------------------ construction-time sync
     def broadcast(self, *flats):
@@ -235,6 +251,11 @@ class GradExchange:
                         tail_started = True
                     self.stats["buckets_behind_graph_end"] += 1
                 self._works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            if self.flags is not None:
+                # collective skip decision: a wait that gave up on ONE rank has let a half-written bucket into the sums
+                # every rank received - MAX over ranks of the timed-out word, behind the buckets, before the optimizer
+                # launch (which is ordered behind this stream by wait()) reads it as skip_flag
+                self._works.append(dist.all_reduce(self.flags.buf[self.flags.n, :1], op=dist.ReduceOp.MAX, async_op=True))
     def micro_step_done(self):
         """Called by TrainLoop after every micro-step it has enqueued (eager or graph replay)."""
         self.micro_steps += 1

@@ -383,15 +383,59 @@ def _tuned_wgrad_code(a, out_floats):
     outputs - the real launch accumulates.  The weight-gradient kernels are a quarter of a training step and how their
     (filter tile, channel tile, M slice) workgroups divide the 256 CUs differs per layer."""
     cache = tune_cache()
-    key = (-1,) + tune_key(a)
-    code = cache.get(key)
+    # the bias reduction and a strided dout (ldr != Cout: the head's padded rows) change the kernel's work: own entries
+    key = (-1,) + tune_key(a) + (int(bool(a.bias)), int(a.ldr != a.Cout and a.ldr != 0))
+    code = _wgrad_agreed.get(key)
     if code is not None:
         return code
-    if os.environ.get("LFVDM_AUTOTUNE", "1") == "0" or torch.cuda.is_current_stream_capturing() or deterministic():
-        return 0
+    store = _rank_store()
+    if store is not None and store[1] != 0:
+        # data-parallel job: ranks must run the SAME kernels (bitwise-equal replicas in deterministic mode, no skew from
+        # one rank tuning while its peers sit in a bucket all-reduce): rank 0 decides, the others read its choice from
+        # the rendezvous store (a blocking get per shape, once per process; no collective that could mismatch)
+        if torch.cuda.is_current_stream_capturing():
+            return cache.get(key, 0)
+        code = int(store[0].get("lfvdm/wgrad/" + json.dumps([int(x) for x in key])).decode())
+        _wgrad_agreed[key] = code
+        return code
+    code = cache.get(key)
+    if code is None:
+        if torch.cuda.is_current_stream_capturing():
+            return 0                    # nothing may be measured (or published) from inside a capture
+        if os.environ.get("LFVDM_AUTOTUNE", "1") == "0" or deterministic():
+            code = 0                    # the heuristic; still published below so that the other ranks do not wait
+        else:
+            code = _measure_wgrad_code(a, out_floats)
+            cache[key] = code
+    _wgrad_agreed[key] = code
+    if store is not None:
+        store[0].set("lfvdm/wgrad/" + json.dumps([int(x) for x in key]), str(int(code)))
+    return code
+
+
+_wgrad_agreed = {}
+_store_memo = []
+
+
+def _rank_store():
+    """(c10d store, rank) of an initialised multi-rank job, else None."""
+    if not _store_memo:
+        import torch.distributed as dist
+        st = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            try:
+                st = (dist.distributed_c10d._get_default_store(), dist.get_rank())
+            except Exception:
+                st = None
+        if not (dist.is_available() and dist.is_initialized()):
+            return None                 # not memoised: the process group may still be created later
+        _store_memo.append(st)
+    return _store_memo[0]
+
+
+def _measure_wgrad_code(a, out_floats):
     codes = _wgrad_codes(a)
     if not codes:
-        cache[key] = 0
         return 0
     L, s = lib(), stream()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -417,7 +461,6 @@ def _tuned_wgrad_code(a, out_floats):
         if t_min < best_t * 0.98:
             best, best_t = code, t_min
     a.out, a.bias, a.tune = real_out, real_bias, 0
-    cache[key] = best
     return best
 
 

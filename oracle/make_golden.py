@@ -37,6 +37,8 @@ CONFIGS = {
     "micro_rb2": (dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(2,), num_res_blocks=2,
                        num_heads=2), 1, 3, 8, 0),
     "cfgA": (dict(model_channels=32, channel_mult=(1, 2, 2, 2), attention_resolutions=(2, 4)), 1, 5, 32, 0),
+    # pixel-like micro model: 3 input / 3 output channels (the head's Cout is not a multiple of 4)
+    "micro_px": (dict(in_channels=3, model_channels=64, channel_mult=(1, 2), attention_resolutions=(2,)), 1, 3, 16, 0),
     "cfgB": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 20, 16, 3),
     "cfgB_T14": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 14, 16, 0),
     # BASELINE.json configs[2]: the per-GPU training workload (ch128, 4 levels, 20 frames of which 3 are padding, batch 2)
@@ -394,6 +396,58 @@ def gen_sampler_cfgB():
     print("[sampler cfgB] ok", np.stack(traj).shape)
 
 
+def gen_sampler_cfgD_window():
+    """The long-video path (BASELINE.json configs[3]): batch 1, the configs[1] network, 250-step respacing, windows of the
+    reference's hierarchy-2 schedule for T=1000 / 36 observed / K=20 / step 10 (tests/golden/schemes.json, itself generated
+    from the reference's sampling_schemes): window 2 (20 frames: 10 conditioning frames incl. far-away anchors + 10 new) and
+    the schedule's single 14-frame window.  Per window: three ancestral steps of the reference's SpacedDiffusion.p_sample
+    from the top of the respaced chain (i = 249, 248, 247 -> model timesteps 999, 995, 991 through _WrappedModel) and the
+    last two steps (i = 1, 0: the t == 0 step adds no noise), with recorded recipe noise (gaussian_diffusion.py:369-401,
+    respace.py:110-124)."""
+    import json
+    kw, _, _, H, _ = CONFIGS["cfgB"]
+    cfg = uo.make_cfg(**kw)
+    model, sd = build_reference_model(cfg)
+    with open(os.path.join(OUT, "schemes.json")) as f:
+        case = next(c for c in json.load(f) if (c["scheme"], c["video_length"], c["n_obs"], c["max_frames"], c["step_size"])
+                    == ("hierarchy-2", 1000, 36, 20, 10))
+    wins = {20: 2, 14: next(i for i, w in enumerate(case["windows"]) if len(w[0]) + len(w[1]) == 14)}
+    pixel = {"diffusion_space": "pixel", "pre_encoded": False, "pre_encoded_stats_dict": None}
+    diff = rsu.create_gaussian_diffusion(steps=1000, timestep_respacing="250", rescale_timesteps=True, rescale_learned_sigmas=True,
+                                         diffusion_space_kwargs=dict(pixel))
+    assert diff.num_timesteps == 250
+    out = {}
+    real_randn_like = torch.randn_like
+    for K, wi in wins.items():
+        obs_idx, lat_idx = case["windows"][wi]
+        assert len(obs_idx) + len(lat_idx) == K
+        tag = f"cfgD_w{K}"
+        inp = tt(recipe.make_inputs(tag, 1, K, cfg["in_channels"], H, H))
+        fi = torch.tensor([list(obs_idx) + list(lat_idx)], dtype=torch.long)      # observed first (video_sample.py:56-61)
+        obs = torch.zeros(1, K, 1, 1, 1)
+        obs[:, :len(obs_idx)] = 1.0
+        mk = dict(frame_indices=fi, obs_mask=obs, latent_mask=1 - obs, x0=inp["x0"])
+        shape = inp["x"].shape
+        for leg, steps, x in (("top", (249, 248, 247), inp["x"].clone()),
+                              ("bottom", (1, 0), (0.5 * inp["x"] + 0.5 * inp["x0"]).clone())):
+            traj = []
+            for j, i in enumerate(steps):
+                noise = torch.from_numpy(recipe.gaussianish(f"{tag}/{leg}/noise{j}", x.numel()).reshape(shape).astype(np.float32))
+                torch.randn_like = lambda x_, _n=noise: _n
+                try:
+                    with torch.no_grad():
+                        x = diff.p_sample(model, x, torch.tensor([i]), clip_denoised=True, model_kwargs=mk)["sample"]
+                finally:
+                    torch.randn_like = real_randn_like
+                traj.append(x.numpy())
+            out[f"w{K}_{leg}"] = np.stack(traj)
+        out[f"w{K}_frame_indices"] = fi.numpy()
+        out[f"w{K}_n_obs"] = np.int64(len(obs_idx))
+        out[f"w{K}_window"] = np.int64(wi)
+    np.savez_compressed(os.path.join(OUT, "sampler_cfgD_window.npz"), **out)
+    print("[sampler cfgD window] ok", {k: v.shape for k, v in out.items()})
+
+
 def gen_train_step_cfgC():
     """One optimizer step of the reference's TrainLoop arithmetic at BASELINE.json configs[2] (ch128, batch 2, 20 frames):
     training_losses (MSE branch, gaussian_diffusion.py:722-796) -> (losses["loss"] * weights).mean().backward()
@@ -481,6 +535,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ops":
         gen_ops()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round4":       # the fixtures added in round 4 only
+        gen_forward(only=["micro_px"])
+        gen_backward(names=["micro_px", "cfgE_T2"])
+        gen_sampler_cfgD_window()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfgD_window":
+        gen_sampler_cfgD_window()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "round3":       # the fixtures added in round 3 only
         gen_sampler_cfgB()
         gen_train_step_cfgC()
@@ -495,4 +557,5 @@ if __name__ == "__main__":
     gen_sampler_cfgB()
     gen_train_step_cfgC()
     gen_forward_cfgE_T20()
+    gen_sampler_cfgD_window()
     print("golden vectors written to", OUT)

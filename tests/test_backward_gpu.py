@@ -14,12 +14,28 @@ from test_forward_gpu import build_native
 pytestmark = pytest.mark.gpu
 
 
+_oracle_grads = {}
+
+
+def oracle_gradients(name, cfg, sd, inp, probe):
+    """CPU autograd of the oracle (minutes for the 119 M-parameter pixel model: computed once per case)."""
+    if name not in _oracle_grads:
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        o, _ = uo.unet_forward(sdo, cfg, inp["x"], inp["x0"], inp["t"].float(), inp["frame_indices"], inp["obs_mask"], inp["latent_mask"])
+        (o * probe).sum().backward()
+        _oracle_grads[name] = {k: v.grad for k, v in sdo.items()}
+    return _oracle_grads[name]
+
+
 @pytest.mark.parametrize("inplace", [False, True], ids=["autograd", "inplace"])
-@pytest.mark.parametrize("name", ["micro", "micro_rb2", "cfgC"])
+@pytest.mark.parametrize("name", ["micro", "micro_rb2", "micro_px", "cfgC", "cfgE_T2"])
 def test_parameter_gradients_match_oracle(name, inplace):
     """Both gradient delivery modes (_backward._GradMode): returned to autograd (default), or accumulated into p.grad
     by the kernels (what TrainLoop switches on).  cfgC is the BASELINE.json configs[2] training shape (ch128, 4 levels,
-    20 frames of which 3 are padding, batch 2): there the in-place mode also takes the grouped RPE path."""
+    20 frames of which 3 are padding, batch 2): there the in-place mode also takes the grouped RPE path.  cfgE_T2 is the
+    pixel-space model of configs[4] (the reference's published training recipe, README.md:54-57: 128x128x3, ch128, rb2,
+    5 levels, head dims 96 / 128, 119 M parameters) on 2 frames: large-map GroupNorm backward, weight gradients over
+    M = 32768 rows, head Cout = 3.  micro_px: the same 3-channel head on a small model."""
     g = np.load(os.path.join(GOLDEN, f"backward_{name}.npz"))
     cfg, sd, inp = load_case(name)
     model = build_native(cfg, sd).train()
@@ -38,15 +54,13 @@ def test_parameter_gradients_match_oracle(name, inplace):
         from improved_diffusion import _backward as bw
         assert bw._rpe_group.state is not None and bw._embed.state is not None, "grouped embedding / RPE path expected"
     # oracle gradients (CPU autograd)
-    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    o, _ = uo.unet_forward(sdo, cfg, inp["x"], inp["x0"], inp["t"].float(), inp["frame_indices"], inp["obs_mask"], inp["latent_mask"])
-    (o * probe).sum().backward()
+    ograds = oracle_gradients(name, cfg, sd, inp, probe)
     gmax = float(g["gmax"])
     keys = [str(k) for k in g["keys"]]
     worst, worst_key = 0.0, None
     for i, (k, p) in enumerate(model.named_parameters()):
         assert k == keys[i]
-        ref = sdo[k].grad
+        ref = ograds[k]
         assert p.grad is not None, k
         err = float((p.grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-3 * gmax)
         if err > worst:
@@ -211,3 +225,88 @@ def test_attention_maps_in_grad_mode_match_no_grad_engine():
             assert torch.allclose(a, b, atol=1e-4), (kind, float((a - b).abs().max()))     # other tile shapes than the tuned plan
     out.sum().backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+
+
+@pytest.mark.parametrize("deterministic", ["0", "1"], ids=["atomics", "deterministic"])
+def test_three_channel_head_gradients_in_both_reduction_modes(deterministic, monkeypatch):
+    """Head with Cout = 3 (pixel space): the narrow weight-gradient kernel's bias epilogue handles four columns per lane
+    and must guard each on its own - with LFVDM_DETERMINISTIC=1 an unguarded fourth column lands in the NEXT slice's slab
+    row (a wrong, racing bias gradient), with atomics one float past the gradient arena.  In-place delivery (what
+    TrainLoop uses), gradients vs the oracle, and the float after the last gradient must stay untouched."""
+    monkeypatch.setenv("LFVDM_DETERMINISTIC", deterministic)
+    name = "micro_px"
+    g = np.load(os.path.join(GOLDEN, f"backward_{name}.npz"))
+    cfg, sd, inp = load_case(name)
+    model = build_native(cfg, sd).train()
+    model.native_grad_accumulation = True
+    # gradients in ONE flat buffer with a canary behind the last one (out.2.bias is the last parameter)
+    params = list(model.parameters())
+    flat = torch.zeros(sum(p.numel() for p in params) + 64, device="cuda")
+    flat[-64:] = 12345.0
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    d = {k: v.cuda() for k, v in inp.items()}
+    probe = torch.from_numpy(recipe.gaussianish(name + "/probe", inp["x"].numel()).reshape(inp["x"].shape).astype(np.float32))
+    runs = []
+    for _ in range(2):
+        flat[:-64].zero_()
+        out, _ = model(d["x"], x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"],
+                       obs_mask=d["obs_mask"], latent_mask=d["latent_mask"])
+        (out * probe.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        runs.append(flat.clone())
+    assert bool((flat[-64:] == 12345.0).all()), "write past the last gradient"
+    if deterministic == "1":
+        assert torch.equal(runs[0], runs[1]), "deterministic mode must be bitwise reproducible"
+    ograds = oracle_gradients(name, cfg, sd, inp, probe)
+    gmax = float(g["gmax"])
+    for k, p in model.named_parameters():
+        ref = ograds[k]
+        err = float((p.grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-3 * gmax)
+        assert err < 2e-3, (k, err)
+    ob = dict(model.named_parameters())["out.2.bias"].grad.cpu()
+    np.testing.assert_allclose(ob.numpy(), ograds["out.2.bias"].numpy(), rtol=2e-4, atol=2e-4 * float(ograds["out.2.bias"].abs().max()))
+
+
+def test_skip_slot_handoff_equals_autograd_sums_and_detects_undrained_slots(monkeypatch):
+    """The skip-connection gradient hand-off (_backward._SkipSlot) against plain autograd sums (LFVDM_NO_SKIP_SLOTS), and
+    its safety net: a filled slot that nobody drained by the end of the backward pass raises instead of dropping the
+    decoder's contribution."""
+    from improved_diffusion import _backward as bw
+    cfg, sd, inp = load_case("micro")
+    d = {k: v.cuda() for k, v in inp.items()}
+    kw = dict(x0=d["x0"], timesteps=d["t"].float(), frame_indices=d["frame_indices"], obs_mask=d["obs_mask"],
+              latent_mask=d["latent_mask"])
+    probe = torch.from_numpy(recipe.gaussianish("micro/probe", inp["x"].numel()).reshape(inp["x"].shape).astype(np.float32)).cuda()
+    grads = {}
+    for slots in (True, False):
+        monkeypatch.setattr(bw, "_SKIP_SLOTS", slots)
+        model = build_native(cfg, sd).train()
+        model.native_grad_accumulation = True
+        out, _ = model(d["x"], **kw)
+        (out * probe).sum().backward()
+        torch.cuda.synchronize()
+        assert bw._SkipSlot.pending == [] and not bw._SkipSlot.queued
+        grads[slots] = {k: p.grad.clone() for k, p in model.named_parameters()}
+    gmax = max(float(v.abs().max()) for v in grads[False].values())
+    for k in grads[False]:
+        a, b = grads[True][k], grads[False][k]
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()) + 1e-4 * gmax), (k, float((a - b).abs().max()))
+    # a slot left full at the end of a backward pass is an error, and it is cleared for the next pass
+    slot = bw._SkipSlot()
+    leaf = torch.ones(4, device="cuda", requires_grad=True)
+
+    class Fill(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, gr):
+            slot.put(gr.clone())
+            return gr * 2
+    with pytest.raises(RuntimeError, match="never ran"):
+        Fill.apply(leaf).sum().backward()
+    assert slot.g is None and bw._SkipSlot.pending == []

@@ -254,7 +254,8 @@ def _timeout_worker(port, q):
                 raised_next = "timed out" in str(e)
         torch.cuda.synchronize()
         still = all(torch.equal(a, b) for a, b in zip(before, [loop.arena.p, loop.exp_avg, loop.exp_avg_sq, loop.ema_flat[0]]))
-        q.put(("ok" if (unchanged and still and (raised_now or raised_next) and ex.flags.timed_out() and not ex.overlap) else "bad",
+        q.put(("ok" if (unchanged and still and (raised_now or raised_next) and ex.timeouts_seen == 1 and not ex.flags.timed_out()
+                       and not ex.overlap) else "bad",
                dict(unchanged=unchanged, still=still, raised_now=raised_now, raised_next=raised_next, probe=ex.overlap_probe)))
         dist.destroy_process_group()
     except Exception:
@@ -272,3 +273,95 @@ def test_timed_out_bucket_wait_skips_the_optimizer_and_raises():
     p.join(60)
     print(res)
     assert res[0] == "ok", res
+
+
+def _one_rank_times_out_worker(rank, world, port, q):
+    """World 2 (gloo, shared card): after the micro-step has become a replayed graph ONLY RANK 1's bucket waits are made
+    to give up.  Rank 1 then all-reduces a bucket its backward may not have finished; the skip decision must be
+    collective (MAX all-reduce of the timed-out word): BOTH ranks leave parameters / moments / EMA untouched, BOTH raise
+    in the same later step, and after catching the error both carry on (exchange behind the graph's end, word cleared)
+    with replicas that stay identical."""
+    try:
+        for p in (PKG, ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), LFVDM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                          LFVDM_FLAG_TIMEOUT_S="0.3")
+        import torch.distributed as dist
+        from improved_diffusion import dist_util, script_util as su
+        from improved_diffusion.train_util import TrainLoop
+        from test_oracle_golden import load_case
+        from test_forward_gpu import build_native
+        dist_util.setup_dist()
+        cfg, sd, _ = load_case("micro")
+        model = build_native(cfg, sd).train()
+        diffusion = su.create_gaussian_diffusion(steps=1000, rescale_timesteps=True, rescale_learned_sigmas=True)
+        loop = TrainLoop(model=model, diffusion=diffusion, data=_data(2, 12, 4, 16, 50 + rank), batch_size=2, microbatch=-1,
+                         lr=1e-3, ema_rate="0.9", log_interval=1000, save_interval=10 ** 9, resume_checkpoint="", use_fp16=False,
+                         diffusion_space_kwargs={}, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.01,
+                         lr_anneal_steps=0, sample_interval=None, pad_with_random_frames=True, max_frames=4,
+                         enc_dec_chunk_size=20, args=argparse.Namespace(resume_id=""))
+        ex = loop.exchange
+        assert ex.overlap and ex.flags is not None, ex.overlap_probe
+        torch.manual_seed(100 + rank); np.random.seed(100 + rank)
+        for _ in range(4):
+            loop.run_step()
+            loop.step += 1
+        torch.cuda.synchronize()
+        assert loop._graph_state.get("graph") is not None and not ex.flags.timed_out()
+        state = lambda: [loop.arena.p, loop.exp_avg, loop.exp_avg_sq, loop.ema_flat[0]]
+        before = [t.clone() for t in state()]
+        if rank == 1:
+            ex.micro_steps += 1             # rank 1 only: its waits expect a signal the graph never sends
+        raised_at = None
+        for i in range(3):                  # the step with the timeout, then the step that must report it
+            try:
+                loop.run_step()
+                loop.step += 1
+            except RuntimeError as e:
+                assert "timed out" in str(e)
+                raised_at = i
+                break
+        torch.cuda.synchronize()
+        unchanged = all(torch.equal(a, b) for a, b in zip(before, state()))
+        if rank == 1:
+            ex.micro_steps -= 1
+        # carry on after the error: no device-side waits any more, the word is cleared, the optimizer applies again
+        cleared = not ex.flags.timed_out() and not ex.overlap
+        for _ in range(2):
+            loop.run_step()
+            loop.step += 1
+        torch.cuda.synchronize()
+        moved = not torch.equal(before[0], loop.arena.p)
+        both = [torch.empty_like(loop.arena.p) for _ in range(world)]
+        dist.all_gather(both, loop.arena.p.detach())
+        same = torch.equal(both[0], both[1])
+        at = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(at, torch.tensor([-1 if raised_at is None else raised_at], dtype=torch.int64, device="cuda"))
+        same_step = int(at[0]) == int(at[1]) and int(at[0]) >= 0
+        ok = unchanged and cleared and moved and same and same_step and ex.timeouts_seen == 1
+        dist.barrier()
+        q.put((rank, "ok" if ok else "bad", dict(unchanged=unchanged, cleared=cleared, moved=moved, same=same,
+                                                  raised_at=[int(a) for a in at], seen=ex.timeouts_seen)))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+        raise
+
+
+def test_one_rank_timing_out_makes_every_rank_skip_and_raise_together():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_one_rank_times_out_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=420) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for r in sorted(res):
+        print(r)
+    assert all(r[1] == "ok" for r in res), res

@@ -15,6 +15,8 @@ CONFIGS = {
     "micro_rb2": (dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(2,), num_res_blocks=2,
                        num_heads=2), 1, 3, 8, 0),
     "cfgA": (dict(model_channels=32, channel_mult=(1, 2, 2, 2), attention_resolutions=(2, 4)), 1, 5, 32, 0),
+    # pixel-like micro model: 3 input / 3 output channels (the head's Cout is not a multiple of 4)
+    "micro_px": (dict(in_channels=3, model_channels=64, channel_mult=(1, 2), attention_resolutions=(2,)), 1, 3, 16, 0),
     "cfgB": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 20, 16, 3),
     "cfgB_T14": (dict(model_channels=64, channel_mult=(1, 2, 2, 2), attention_resolutions=(1, 2)), 2, 14, 16, 0),
     # BASELINE.json configs[2]: per-GPU training workload (ch128, 4 levels, 20 frames incl. 3 padding frames, batch 2)
@@ -52,7 +54,7 @@ def test_forward_matches_reference(name):
     np.testing.assert_allclose(attn["spatial"][0].numpy()[:1, :32, :32], g["attn_s0"], atol=5e-5)
 
 
-@pytest.mark.parametrize("name", ["micro", "micro_rb2", "cfgC"])
+@pytest.mark.parametrize("name", ["micro", "micro_rb2", "micro_px", "cfgC", "cfgE_T2"])
 def test_backward_matches_reference(name):
     g = np.load(os.path.join(GOLDEN, f"backward_{name}.npz"))
     cfg, sd, inp = load_case(name)
@@ -142,3 +144,26 @@ def test_diffusion_tables_and_steps():
             ti = torch.zeros(shape[0], dtype=torch.long)
             x_last, _ = do.p_sample(tab, model_fn(inp["x"], do.model_timesteps(tab, ti)), inp["x"], ti, noise[0])
             np.testing.assert_allclose(x_last.numpy(), g[f"{tag}/p_sample_t0"], atol=1e-4)
+
+
+@pytest.mark.parametrize("K", [20, 14])
+def test_long_video_window_trajectory(K):
+    """The oracle's respaced p_sample at the long-video shapes (batch 1, hierarchy-2 window frame indices, 250 steps)
+    against the reference's trajectory (tests/golden/sampler_cfgD_window.npz)."""
+    g = np.load(os.path.join(GOLDEN, "sampler_cfgD_window.npz"))
+    cfg, sd, _ = load_case("cfgB")
+    tag = f"cfgD_w{K}"
+    inp = tt(recipe.make_inputs(tag, 1, K, cfg["in_channels"], 16, 16))
+    fi = torch.from_numpy(g[f"w{K}_frame_indices"])
+    obs = torch.zeros(1, K, 1, 1, 1)
+    obs[:, :int(g[f"w{K}_n_obs"])] = 1.0
+    tab = do.Tables(do.linear_betas(1000), do.space_timesteps(1000, "250"))
+    shape = inp["x"].shape
+    with torch.no_grad():
+        for leg, steps, x in (("top", (249, 248, 247), inp["x"].clone()), ("bottom", (1, 0), 0.5 * inp["x"] + 0.5 * inp["x0"])):
+            for j, i in enumerate(steps):
+                noise = torch.from_numpy(recipe.gaussianish(f"{tag}/{leg}/noise{j}", x.numel()).reshape(shape).astype(np.float32))
+                ti = torch.tensor([i])
+                eps = uo.unet_forward(sd, cfg, x, inp["x0"], do.model_timesteps(tab, ti), fi, obs, 1 - obs)[0]
+                x, _ = do.p_sample(tab, eps, x, ti, noise)
+                np.testing.assert_allclose(x.numpy(), g[f"w{K}_{leg}"][j], atol=1e-4 * (j + 1))

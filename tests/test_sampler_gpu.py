@@ -294,3 +294,39 @@ def test_fused_head_chain_equals_the_two_launch_chain(monkeypatch):
     assert float((outs[0][1] - outs[1][1]).abs().max()) < 5e-3
     assert outs[1][3] - outs[0][3] == 1, "one launch less per step"
 
+
+
+@pytest.mark.parametrize("K", [20, 14])
+def test_replayed_long_video_window_follows_the_reference_trajectory(K):
+    """The long-video path of BASELINE.json configs[3] against the REFERENCE: batch 1, 250-step respacing, the frame
+    indices of a hierarchy-2 window of the T=1000 schedule (window 2: 20 frames with far-away anchor frames; the
+    schedule's only 14-frame window) - the batch-1 tune codes, per-window timestep tables, respaced clock and the
+    hipGraph replay, vs ``SpacedDiffusion.p_sample`` (gaussian_diffusion.py:369-401 through respace.py:110-124) with
+    recorded noise: three steps from the top of the chain and the last two (t = 0 adds no noise).  Fixture
+    tests/golden/sampler_cfgD_window.npz (oracle/make_golden.py::gen_sampler_cfgD_window).  2e-4 per step taken."""
+    from improved_diffusion.gaussian_diffusion import GraphSampler
+    g = np.load(os.path.join(GOLDEN, "sampler_cfgD_window.npz"))
+    cfg, sd, _ = load_case("cfgB")
+    model = build_native(cfg, sd)
+    diff = make_diffusion(1000, "250")
+    assert diff.num_timesteps == 250
+    tag = f"cfgD_w{K}"
+    inp = {k: torch.from_numpy(v) for k, v in recipe.make_inputs(tag, 1, K, cfg["in_channels"], 16, 16).items()}
+    fi = torch.from_numpy(g[f"w{K}_frame_indices"])
+    n_obs = int(g[f"w{K}_n_obs"])
+    obs = torch.zeros(1, K, 1, 1, 1)
+    obs[:, :n_obs] = 1.0
+    mk = dict(frame_indices=fi.cuda(), obs_mask=obs.cuda(), latent_mask=(1 - obs).cuda(), x0=inp["x0"].cuda())
+    shape = tuple(inp["x"].shape)
+    s = GraphSampler(diff, model, shape, True, inject_noise=True)
+    for leg, steps, x in (("top", (249, 248, 247), inp["x"].clone()), ("bottom", (1, 0), 0.5 * inp["x"] + 0.5 * inp["x0"])):
+        s.begin(x.cuda(), mk)
+        assert s.plan.time_steps == 250, s.plan.time_table_fallback     # per-window timestep tables on
+        assert getattr(s.plan, "tuned", False) and s.graph is not None
+        for j, i in enumerate(steps):
+            noise = torch.from_numpy(recipe.gaussianish(f"{tag}/{leg}/noise{j}", inp["x"].numel()).reshape(shape).astype(np.float32))
+            s.noise.copy_(noise.cuda())
+            out = s.step(i)["sample"]
+            err = float((out.cpu() - torch.from_numpy(g[f"w{K}_{leg}"][j])).abs().max())
+            print(f"[cfgD window K={K}] {leg} step {j} (i={i}): max|d| vs reference trajectory {err:.2e}")
+            assert err < 2e-4 * (j + 1), (leg, j, err)

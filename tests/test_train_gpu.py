@@ -271,13 +271,20 @@ def test_cfgC_training_step_matches_the_reference_arithmetic():
     torch.cuda.synchronize()
     gmax = float(g["grad_absmax"].max())
     worst = dict(grad=0.0, delta=0.0, new=0.0, ema=0.0)
+    zero_tensors = []
     for i, (k, p, e, o, gr) in enumerate(zip(keys, model.parameters(), loop.ema_params[0], old, grads)):
         gn, dn = float(gr.double().norm()), float((p.detach() - o).double().norm())
         tol = 2e-3 * float(g["grad_norm"][i]) + 1e-5 * gmax * gr.numel() ** 0.5
         assert abs(gn - float(g["grad_norm"][i])) <= tol, (k, gn, float(g["grad_norm"][i]))
         assert abs(dn - float(g["delta_norm"][i])) <= 2e-3 * float(g["delta_norm"][i]) + 2.2e-4 * (0.02 * gr.numel()) ** 0.5, (k, dn, float(g["delta_norm"][i]))
-        worst["grad"] = max(worst["grad"], abs(gn - float(g["grad_norm"][i])) / (float(g["grad_norm"][i]) + 1e-12))
-        worst["delta"] = max(worst["delta"], abs(dn - float(g["delta_norm"][i])) / (float(g["delta_norm"][i]) + 1e-12))
+        # analytically-zero gradients (rpe_k's output bias shifts all logits of a query alike; biases in front of a
+        # GroupNorm): the reference's norm is rounding noise (4e-10 ... 2e-9 against gmax ~ 1e-1) and a RELATIVE deviation
+        # of it means nothing - counted, not ranked
+        if float(g["grad_norm"][i]) < 1e-6 * gmax * gr.numel() ** 0.5:
+            zero_tensors.append(k)
+        else:
+            worst["grad"] = max(worst["grad"], abs(gn - float(g["grad_norm"][i])) / float(g["grad_norm"][i]))
+            worst["delta"] = max(worst["delta"], abs(dn - float(g["delta_norm"][i])) / float(g["delta_norm"][i]))
         n = min(16, p.numel())
         new_h, ema_h = p.detach().flatten()[:n].cpu().numpy(), e.detach().flatten()[:n].cpu().numpy()
         ref_new, ref_ema, ref_g = g["new_head"][i][:n], g["ema_head"][i][:n], g["grad_head"][i][:n]
@@ -287,7 +294,14 @@ def test_cfgC_training_step_matches_the_reference_arithmetic():
         assert np.all(np.abs(new_h - ref_new) <= bound), (k, np.abs(new_h - ref_new).max())
         assert np.all(np.abs(ema_h - ref_ema) <= np.where(noisy, 2.2e-8, 1e-4 * np.abs(ref_ema) + 2e-6)), k
         worst["new"] = max(worst["new"], float(np.abs(new_h - ref_new)[~noisy].max()) if (~noisy).any() else 0.0)
-    print("[cfgC step] worst relative gradient-norm / update-norm deviation, worst |d| of a new parameter:", worst)
+        worst["ema"] = max(worst["ema"], float(np.abs(ema_h - ref_ema)[~noisy].max()) if (~noisy).any() else 0.0)
+    print(f"[cfgC step] worst relative gradient-norm / update-norm deviation over the {len(keys) - len(zero_tensors)} tensors "
+          f"with a non-zero gradient, worst |d| of a new parameter / EMA element: {worst}; {len(zero_tensors)} tensors with an "
+          f"analytically-zero gradient (reference norm < 1e-6 * gmax * sqrt(n)) excluded from the relative figures: "
+          f"{sorted(set(z.split('.')[-3] + '.' + z.split('.')[-2] + '.' + z.split('.')[-1] for z in zero_tensors))}")
+    # "gradient and update norms rtol 2e-3" - what the non-noise maxima must satisfy
+    assert worst["grad"] <= 2e-3 and worst["delta"] <= 2e-3, worst
+    assert len(zero_tensors) <= 16, zero_tensors
 
 
 def _five_steps(lr=1e-3, steps=5):
