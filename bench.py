@@ -224,11 +224,15 @@ def train_step_flops(model, B, T, H, W):
     conv = sum(conv_flops(a[0]._obj) for fn, a in pl.steps if fn is L.lfvdm_conv_igemm)
     att = 0.0
     for fn, a in pl.steps:
-        if fn is L.lfvdm_attn_temporal:
+        if fn is L.lfvdm_attn_temporal or fn is L.lfvdm_attn_temporal_sel:
             Bv, Tv, P, C = a[7], a[8], a[9], a[10]
             att += 10.0 * Bv * P * Tv * Tv * C
         elif fn is L.lfvdm_attn_spatial:
             N, P, C = a[4], a[5], a[6]
+            att += 4.0 * N * P * P * C
+        elif fn is L.lfvdm_attn_spatial_fused:     # qkv projection + core in one launch: count both
+            N, P, C = a[4], a[5], a[6]
+            conv += 2.0 * N * P * 3 * C * C
             att += 4.0 * N * P * P * C
     return {"forward_conv_gemm": conv, "forward_attention": att, "step": 3.0 * (conv + att)}
 
@@ -436,6 +440,82 @@ def bench_pixel(dev, steps):
             "params": sum(p.numel() for p in model.parameters()), "conv_gemm_gflop_per_step": round(fl / 1e9, 1),
             "conv_gemm_tflops": round(fl / (ms * 1e-3) / 1e12, 1), "conv_gemm_frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 3),
             "whole_step_tflops": round(fl / (el / steps) / 1e12, 1), "finite": bool(th.isfinite(sampler.plan.x_in).all())}
+
+
+def make_pixel_model(dev, num_res_blocks=2):
+    """BASELINE.json configs[4] network: pixel space 128x128x3, num_channels=128, reference defaults channel_mult
+    (1,1,2,3,4), attention at 16x16 and 8x8; random-init every parameter (see make_model_and_diffusion)."""
+    from improved_diffusion import script_util as su
+    kw = su.model_and_diffusion_defaults()
+    kw.update(image_size=128, in_channels=3, num_channels=128, num_res_blocks=num_res_blocks, num_heads=4,
+              attention_resolutions="16,8", diffusion_steps=1000, timestep_respacing="",
+              diffusion_space_kwargs={"diffusion_space": "pixel", "pre_encoded": False, "pre_encoded_stats_dict": None})
+    model, diffusion = su.create_model_and_diffusion(**kw)
+    g = th.Generator().manual_seed(7)
+    with th.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 1:
+                p.copy_((1.0 if name.endswith("weight") else 0.0) + 0.1 * th.randn(p.shape, generator=g))
+            else:
+                p.copy_(th.randn(p.shape, generator=g) / math.sqrt(p[0].numel()))
+    return model.to(dev), diffusion
+
+
+def _repeat_batch(batch):
+    while True:
+        yield (batch, {})
+
+
+def bench_pixel_train(dev, steps, batch=1, num_res_blocks=1, warmup=4):
+    """Pixel-space TRAINING, the reference's published recipe (README.md:54-57: video_train.py --batch_size=2 --max_frames 20
+    --dataset=carla_no_traffic --num_res_blocks=1, i.e. 128x128x3 frames, num_channels=128; BASELINE.json configs[4] in
+    video_train.py flags): one TrainLoop optimizer step = batch preparation + q_sample + U-Net forward + masked MSE +
+    backward + fused AdamW/EMA (train_util.py:277-357).  FLOPs = 3 x forward, against the fp32 MFMA peak over the WHOLE
+    step (wall clock)."""
+    import argparse as ap
+    from improved_diffusion.train_util import TrainLoop
+    model, diffusion = make_pixel_model(dev, num_res_blocks)
+    model.train()
+    T = 20
+    g = th.Generator().manual_seed(4321)
+    video = th.randn(batch, 24, 3, 128, 128, generator=g).clamp(-1, 1)
+    loop = TrainLoop(model=model, diffusion=diffusion, data=_repeat_batch(video), batch_size=batch, microbatch=-1, lr=1e-4,
+                     ema_rate="0.9999", log_interval=10 ** 9, save_interval=10 ** 9, resume_checkpoint="", use_fp16=False,
+                     diffusion_space_kwargs={}, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.0,
+                     lr_anneal_steps=0, sample_interval=None, pad_with_random_frames=True, max_frames=T,
+                     enc_dec_chunk_size=20, args=ap.Namespace(resume_id=""))
+    th.manual_seed(99)
+    np.random.seed(99)
+    for _ in range(warmup):
+        loop.run_step()
+        loop.step += 1
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loop.run_step()
+        loop.step += 1
+    th.cuda.synchronize()
+    el = time.perf_counter() - t0
+    from improved_diffusion.logger import logger
+    loop._flush_loss_log()
+    loss = float(logger.name2val.get("loss", float("nan")))
+    logger.dumpkvs()
+    fl = train_step_flops(model, batch, T, 128, 128)
+    tfl = fl["step"] / (el / steps) / 1e12
+    P = sum(p.numel() for p in model.parameters())
+    peak_gb = th.cuda.max_memory_allocated(dev) / 2 ** 30
+    out = {"workload": f"pixel-space training: 128x128x3, 20 frames, batch {batch}, num_channels=128, num_res_blocks={num_res_blocks} "
+                       "(reference README.md:54-57 recipe / BASELINE.json configs[4])",
+           "steps": steps, "ms_per_step": round(1000.0 * el / steps, 2), "optimizer_steps_per_s": round(steps / el, 3),
+           "frames_per_s": round(batch * T * steps / el, 1), "params": P, "last_loss": loss,
+           "graph_replay": loop._graph_state.get("graph") is not None, "hbm_allocated_peak_gib": round(peak_gb, 2),
+           "roofline": {"bound": "mfma", "flops_per_step": fl["step"], "forward_conv_gemm_flops": fl["forward_conv_gemm"],
+                        "forward_attention_flops": fl["forward_attention"], "achieved": round(tfl, 2),
+                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
+                        "note": "whole optimizer step (wall clock, all launches) against the fp32 MFMA peak; FLOPs = 3 x forward"}}
+    del loop, model
+    th.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic(kernel_name):

@@ -277,6 +277,20 @@ int lfvdm_gn_bwd_fused(const float* da, const float* src0, const float* src1, in
                        const float* gamma, const float* beta, const float* film, int film_ld, int T, float* dgamma,
                        float* dbeta, float* dfilm, int dfilm_ld, const float* add, int add_ld, const float* add2,
                        int add2_ld, void* stream);
+/* Large-map form of the GroupNorm backward (what lfvdm_gn_apply_ws is to the forward; reference nn.py:17-19 through
+ * unet.py:194-207,399-403 at pixel-space map sizes): a workgroup owns a chunk of positions of a (sample, 8 groups) slice,
+ * chunk sums -> fixed-order combination in every consumer workgroup -> dx: two launches of thousands of workgroups instead
+ * of N*4 workgroups whatever P is.  ws: lfvdm_gn_bwd_ws_floats(C0 + C1, N, P) floats of scratch; 0 means the slice is small
+ * and the single-workgroup kernels (lfvdm_gn_bwd_fused / _stats + _apply) are the ones to call.  dx is written (not
+ * accumulated) to out0 / out1 with add / add2 folded in.  The per-(sample, channel) sums go to sums_out[N][C][2] when it is
+ * not NULL (fixed order: deterministic mode, autograd delivery) and / or - dgamma, dbeta not NULL - into the parameter /
+ * FiLM gradients with float atomics exactly as lfvdm_gn_bwd_fused does.  dx itself is deterministic either way. */
+long lfvdm_gn_bwd_ws_floats(int C, int N, int P);
+int lfvdm_gn_bwd_ws(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                    const float* coefA, const float* coefB, const float* stats, int act, float* out0, float* out1,
+                    const float* gamma, const float* beta, const float* film, int film_ld, int T, float* dgamma,
+                    float* dbeta, float* dfilm, int dfilm_ld, const float* add, int add_ld, const float* add2, int add2_ld,
+                    float* sums_out, float* ws, long ws_floats, void* stream);
 /* GroupNorm(+FiLM) parameter gradients from the sums of lfvdm_gn_bwd_stats: dgamma / dbeta [C] are ACCUMULATED
  * (+=, fixed order), dfilm [N/T][2C] (d scale | d shift of unet.py:199-203; row strides film_ld / dfilm_ld) is
  * written when film != NULL. */

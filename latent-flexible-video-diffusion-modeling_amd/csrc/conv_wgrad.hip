@@ -760,7 +760,11 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
     const int Cin = a->C0 + a->C1;
     if (a->N <= 0 || a->Cout <= 0 || Cin <= 0 || Cin % 32 || a->C0 % 32) return LFVDM_E_SHAPE;
     if (a->ksize != 1 && a->ksize != 3) return LFVDM_E_SHAPE;
-    if (!a->res || !a->out || a->ldr < a->Cout || a->ldr % 4 || a->Cout % 4) return LFVDM_E_SHAPE;
+    // Cout that is not a multiple of 4 (the 3-channel head of a pixel-space model): narrow layers only (the wave-private
+    // kernel guards every filter row and bias column on its own); the dout rows are read as float4, so they must be
+    // padded to a multiple of 4 columns
+    if (!a->res || !a->out || a->ldr < (a->Cout + 3) / 4 * 4 || a->ldr % 4) return LFVDM_E_SHAPE;
+    if (a->Cout % 4 && a->Cout >= 64) return LFVDM_E_SHAPE;
     if (a->C1 > 0 && !a->src1) return LFVDM_E_SHAPE;
     if ((a->coefA == nullptr) != (a->coefB == nullptr)) return LFVDM_E_SHAPE;
     const long M = (long)a->N * a->Ho * a->Wo;

@@ -294,6 +294,206 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_fused_kernel(
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Large maps (pixel space, 32x32 latents, wide concats): the (sample, 8 groups) decomposition above gives N*4 workgroups
+// whatever P is - 80 workgroups streaming ~1 GB per GroupNorm at 20 x 128 x 128 x 128.  Chunked form, the decomposition
+// of the forward's gn_chunk_* kernels (norm_embed.hip): a workgroup owns a CHUNK of 8*PL positions of a (sample, 8 groups)
+// slice and keeps x and dz of the chunk in registers.
+//   pass 1 (gn_bwd_chunk_stats_kernel): per-channel partial sums s1, s2 of the chunk -> part[n][chunk][C][2]
+//   pass 2 (gn_bwd_chunk_apply_kernel): every workgroup sums the S partials of its channels IN CHUNK ORDER (its chunk's
+//     loads are already in flight), forms the group sums and writes dx of its chunk; the chunk-0 workgroup of a slice
+//     also delivers the per-(n, c) sums: float atomics into dgamma / dbeta / dfilm (training path) and / or plain stores
+//     to sums_out[n][C][2] (deterministic mode and the autograd delivery mode, which reduce them in a fixed order).
+// Thousands of workgroups, x and da read twice, dx written once; everything except the optional atomics is deterministic.
+// -------------------------------------------------------------------------------------
+constexpr int GBC_KEEP = 8;
+
+struct GnBwdChunkGeom { int C0, C1, P, S, PL; };
+
+struct GnBwdChunkRegs {
+    f32x4 x[GBC_KEEP], dz[GBC_KEEP];
+};
+
+// loads of the chunk (clamped positions: lanes past the end re-read the last row and are masked by the caller), then
+// dz = da * act'(z) in place
+__device__ __forceinline__ void gn_bwd_chunk_load(const float* da, const float* s0, const float* s1p, const GnBwdChunkGeom& g,
+                                                  size_t pos0, int npos, int pl, int c, GnBwdChunkRegs& r) {
+    const int C = g.C0 + g.C1;
+#pragma unroll
+    for (int i = 0; i < GBC_KEEP; ++i) {
+        const int p = min(pl + i * g.PL, npos - 1);
+        r.x[i] = ldcat(s0, s1p, g.C0, g.C1, pos0 + p, c);
+        r.dz[i] = ld4(da + (pos0 + p) * C + c);
+    }
+}
+
+__global__ __launch_bounds__(GB_THREADS) void gn_bwd_chunk_stats_kernel(
+    const float* __restrict__ da, const float* __restrict__ s0, const float* __restrict__ s1p, GnBwdChunkGeom g,
+    const float* __restrict__ coefA, const float* __restrict__ coefB, const float* __restrict__ stats, int act,
+    float* __restrict__ part_out) {
+    const int C = g.C0 + g.C1, cg = C / 32, CW = GB_GPW * cg, Q = CW / 4, PL = g.PL;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
+    const int sidx = blockIdx.x, n = blockIdx.z, cbase = blockIdx.y * CW;
+    const int tid = threadIdx.x;
+    const bool active = tid < PL * Q;
+    const int q = active ? tid % Q : 0, pl = active ? tid / Q : 0;
+    const int c = cbase + q * 4;
+    const int p_first = sidx * (GBC_KEEP * PL);
+    const int npos = min(GBC_KEEP * PL, g.P - p_first);
+    __shared__ float part[2][GB_THREADS * 4];
+    GnBwdChunkRegs r;
+    gn_bwd_chunk_load(da, s0, s1p, g, (size_t)n * g.P + p_first, npos, pl, c, r);
+    const f32x4 A = ld4(coefA + (size_t)n * C + c), B = ld4(coefB + (size_t)n * C + c);
+    f32x4 mu, rs;
+    const float* st = stats + (size_t)n * 64;
+    mu.x = st[2 * (fdiv_small(c + 0, cg, rcg))]; rs.x = st[2 * (fdiv_small(c + 0, cg, rcg)) + 1];
+    mu.y = st[2 * (fdiv_small(c + 1, cg, rcg))]; rs.y = st[2 * (fdiv_small(c + 1, cg, rcg)) + 1];
+    mu.z = st[2 * (fdiv_small(c + 2, cg, rcg))]; rs.z = st[2 * (fdiv_small(c + 2, cg, rcg)) + 1];
+    mu.w = st[2 * (fdiv_small(c + 3, cg, rcg))]; rs.w = st[2 * (fdiv_small(c + 3, cg, rcg)) + 1];
+    const bool silu = act == LFVDM_ACT_SILU;
+    if (active) {
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < GBC_KEEP; ++i) {
+            if (pl + i * PL < npos) {
+                f32x4 dz = r.dz[i];
+                if (silu) {
+                    const f32x4 z = r.x[i] * A + B;
+                    dz.x *= dsilu(z.x); dz.y *= dsilu(z.y); dz.z *= dsilu(z.z); dz.w *= dsilu(z.w);
+                }
+                a1 += dz;
+                a2 += dz * ((r.x[i] - mu) * rs);
+            }
+        }
+        st4(part[0] + (pl * Q + q) * 4, a1);
+        st4(part[1] + (pl * Q + q) * 4, a2);
+    }
+    __syncthreads();
+    for (int cc = tid; cc < CW; cc += GB_THREADS) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int i = 0; i < PL; ++i) { t1 += part[0][i * CW + cc]; t2 += part[1][i * CW + cc]; }
+        float* o = part_out + (((size_t)n * g.S + sidx) * C + cbase + cc) * 2;
+        o[0] = t1;
+        o[1] = t2;
+    }
+}
+
+__global__ __launch_bounds__(GB_THREADS) void gn_bwd_chunk_apply_kernel(
+    const float* __restrict__ da, const float* __restrict__ s0, const float* __restrict__ s1p, GnBwdChunkGeom g,
+    const float* __restrict__ coefA, const float* __restrict__ coefB, const float* __restrict__ stats, int act,
+    const float* __restrict__ part_in, float* __restrict__ out0, float* __restrict__ out1, GnParamGradArgs pg,
+    float* __restrict__ sums_out) {
+    const int C = g.C0 + g.C1, cg = C / 32, CW = GB_GPW * cg, Q = CW / 4, PL = g.PL;
+    const float rcg = __builtin_amdgcn_rcpf((float)cg);
+    const int sidx = blockIdx.x, n = blockIdx.z, cbase = blockIdx.y * CW;
+    const int tid = threadIdx.x;
+    const bool active = tid < PL * Q;
+    const int q = active ? tid % Q : 0, pl = active ? tid / Q : 0;
+    const int c = cbase + q * 4;
+    const int p_first = sidx * (GBC_KEEP * PL);
+    const int npos = min(GBC_KEEP * PL, g.P - p_first);
+    const size_t pos0 = (size_t)n * g.P + p_first;
+    __shared__ float comb[2][GB_THREADS];
+    __shared__ float chS[2][GB_GPW * 32];
+    __shared__ float gS1[GB_GPW], gS2[GB_GPW];
+    GnBwdChunkRegs r;
+    gn_bwd_chunk_load(da, s0, s1p, g, pos0, npos, pl, c, r);         // in flight during the combination
+    {   // partial sums of this slice's channels, chunk order: thread (channel cc, lane sl) takes chunks sl, sl + SL, ...
+        const int SL = GB_THREADS / CW;
+        const int cc = tid % CW, sl = tid / CW;
+        float t1 = 0.f, t2 = 0.f;
+        if (sl < SL) {
+            const float* pp = part_in + ((size_t)n * g.S * C + cbase + cc) * 2;
+            for (int s = sl; s < g.S; s += SL) {
+                const float2 v = *reinterpret_cast<const float2*>(pp + (size_t)s * C * 2);
+                t1 += v.x;
+                t2 += v.y;
+            }
+            comb[0][sl * CW + cc] = t1;
+            comb[1][sl * CW + cc] = t2;
+        }
+        __syncthreads();
+        if (tid < CW) {
+            t1 = 0.f; t2 = 0.f;
+            for (int i = 0; i < SL; ++i) { t1 += comb[0][i * CW + tid]; t2 += comb[1][i * CW + tid]; }
+            chS[0][tid] = t1;
+            chS[1][tid] = t2;
+            if (sidx == 0) {        // one workgroup per (sample, slice) delivers the per-channel sums
+                const int ch = cbase + tid;
+                if (sums_out != nullptr) {
+                    sums_out[((size_t)n * C + ch) * 2 + 0] = t1;
+                    sums_out[((size_t)n * C + ch) * 2 + 1] = t2;
+                }
+                if (pg.dgamma != nullptr) {
+                    float sc1 = 1.0f;
+                    if (pg.film != nullptr) {
+                        const int b = n / pg.T;
+                        sc1 += pg.film[(size_t)b * pg.film_ld + ch];
+                        atomicAdd(pg.dfilm + (size_t)b * pg.dfilm_ld + ch, t2 * pg.gamma[ch] + t1 * pg.beta[ch]);
+                        atomicAdd(pg.dfilm + (size_t)b * pg.dfilm_ld + C + ch, t1);
+                    }
+                    atomicAdd(pg.dgamma + ch, t2 * sc1);
+                    atomicAdd(pg.dbeta + ch, t1 * sc1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < GB_GPW) {
+        const int gi = blockIdx.y * GB_GPW + tid;
+        const float rstd = stats[((size_t)n * 32 + gi) * 2 + 1];
+        float S1 = 0.f, S2 = 0.f;
+        for (int i = 0; i < cg; ++i) {
+            const float gp = coefA[(size_t)n * C + gi * cg + i] / rstd;   // g' = A / rstd (rstd > 0)
+            S1 += gp * chS[0][tid * cg + i];
+            S2 += gp * chS[1][tid * cg + i];
+        }
+        const float inv = 1.0f / ((float)cg * (float)g.P);
+        gS1[tid] = S1 * inv;
+        gS2[tid] = S2 * inv;
+    }
+    __syncthreads();
+    if (!active) return;
+    const f32x4 A = ld4(coefA + (size_t)n * C + c), B = ld4(coefB + (size_t)n * C + c);
+    f32x4 mu, rs, S1, S2;
+    const float* st = stats + (size_t)n * 64;
+#define LFVDM_G(k, f)                                                                                \
+    { const int gq = fdiv_small(q * 4 + k, cg, rcg); const int gg = blockIdx.y * GB_GPW + gq;        \
+      mu.f = st[2 * gg]; rs.f = st[2 * gg + 1]; S1.f = gS1[gq]; S2.f = gS2[gq]; }
+    LFVDM_G(0, x) LFVDM_G(1, y) LFVDM_G(2, z) LFVDM_G(3, w)
+#undef LFVDM_G
+    const bool silu = act == LFVDM_ACT_SILU;
+    const bool first = c < g.C0;
+    float* out = first ? out0 : out1;
+    const int Cd = first ? g.C0 : g.C1;
+    const int cd = first ? c : c - g.C0;
+#pragma unroll
+    for (int i = 0; i < GBC_KEEP; ++i) {
+        const int p = pl + i * PL;
+        if (p < npos) {
+            f32x4 dz = r.dz[i];
+            if (silu) {
+                const f32x4 z = r.x[i] * A + B;
+                dz.x *= dsilu(z.x); dz.y *= dsilu(z.y); dz.z *= dsilu(z.z); dz.w *= dsilu(z.w);
+            }
+            const f32x4 xh = (r.x[i] - mu) * rs;
+            f32x4 dx = A * dz - rs * (S1 + xh * S2);
+            if (pg.add != nullptr) dx += ld4(pg.add + (pos0 + p) * pg.add_ld + c);
+            if (pg.add2 != nullptr) dx += ld4(pg.add2 + (pos0 + p) * pg.add2_ld + c);
+            st4(out + (pos0 + p) * Cd + cd, dx);
+        }
+    }
+}
+
+// chunks per (sample, 8 groups) slice; 0 = the slice is small enough for the single-workgroup kernels
+inline int gn_bwd_chunks(int C, int P, int* pl_out) {
+    const int Q = GB_GPW * (C / 32) / 4;
+    const int PL = GB_THREADS / Q;
+    if (pl_out) *pl_out = PL;
+    if (P <= 2 * GBC_KEEP * PL) return 0;
+    return (P + GBC_KEEP * PL - 1) / (GBC_KEEP * PL);
+}
+
 // temporal GroupNorm backward (rpe.py:135-137): sample = (b, pixel), elements [T][C/32-group]; one wave per sample.
 // y = (x-mean)*rstd*gamma + beta.  Writes dx and accumulates dgamma/dbeta with atomics.
 constexpr int GTB_MAXC = 512;
@@ -659,6 +859,44 @@ extern "C" int lfvdm_gn_bwd_fused(const float* da, const float* src0, const floa
     const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1, add, add_ld, add2, add2_ld};
     hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
                        C0, C1, P, coefA, coefB, stats, act, out0, out1, pg);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" long lfvdm_gn_bwd_ws_floats(int C, int N, int P) {
+    if (C <= 0 || C % 32 || C > 1024 || N <= 0 || P <= 0) return 0;
+    static const bool off = getenv("LFVDM_GN_BWD_NO_CHUNKS") != nullptr;       // A/B aid
+    if (off) return 0;
+    const int S = gn_bwd_chunks(C, P, nullptr);
+    return (long)N * S * C * 2;
+}
+
+extern "C" int lfvdm_gn_bwd_ws(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                               const float* coefA, const float* coefB, const float* stats, int act, float* out0,
+                               float* out1, const float* gamma, const float* beta, const float* film, int film_ld, int T,
+                               float* dgamma, float* dbeta, float* dfilm, int dfilm_ld, const float* add, int add_ld,
+                               const float* add2, int add2_ld, float* sums_out, float* ws, long ws_floats, void* stream) {
+    const int C = C0 + C1;
+    if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024 || N > 65535) return LFVDM_E_SHAPE;
+    if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
+    if (!da || !src0 || !out0 || !coefA || !coefB || !stats) return LFVDM_E_SHAPE;
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return LFVDM_E_SHAPE;
+    if (!dgamma && !sums_out) return LFVDM_E_SHAPE;          // the per-channel sums must go somewhere
+    if (add && (add_ld < C || add_ld % 4)) return LFVDM_E_SHAPE;
+    if (add2 && (add2_ld < C || add2_ld % 4)) return LFVDM_E_SHAPE;
+    if (dgamma && film && (!gamma || !beta || !dfilm || T <= 0 || N % T || film_ld < 2 * C || dfilm_ld < 2 * C)) return LFVDM_E_SHAPE;
+    int PL = 0;
+    const int S = gn_bwd_chunks(C, P, &PL);
+    if (S == 0 || !ws || ws_floats < (long)N * S * C * 2) return LFVDM_E_SHAPE;
+    const GnBwdChunkGeom g = {C0, C1, P, S, PL};
+    const GnParamGradArgs pg = {gamma, beta, dgamma ? film : nullptr, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1,
+                                add, add_ld, add2, add2_ld};
+    const dim3 grid(S, 32 / GB_GPW, N);
+    hipLaunchKernelGGL(gn_bwd_chunk_stats_kernel, grid, dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1, g, coefA, coefB,
+                       stats, act, ws);
+    LFVDM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_bwd_chunk_apply_kernel, grid, dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1, g, coefA, coefB,
+                       stats, act, (const float*)ws, out0, out1, pg, sums_out);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -450,10 +450,15 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
     [N*P][C] rows (further gradients of the same input) folded into dx by the in-place kernel."""
     C = C0 + C1
     if add2 is not None and not (inplace and not nat.deterministic()):
-        add = add2 if add is None else add + add2
+        add, add2 = (add2 if add is None else add + add2), None
     L = nat.lib()
     dxa = _new(N * P, C0, like=da)
     dxb = _new(N * P, C1, like=da) if C1 else None
+    need = int(L.lfvdm_gn_bwd_ws_floats(C, N, P))
+    if need:
+        # large map (pixel space, wide concats at 32x32): chunked two-launch form, thousands of workgroups
+        return _gn_backward_chunked(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, T, dfilm_out, inplace, add,
+                                    add2, dxa, dxb, need)
     if inplace and nat.deterministic():
         # fixed summation order: per-(sample, channel) sums (lfvdm_gn_bwd_stats), dx (lfvdm_gn_bwd_apply), then the
         # parameter / FiLM gradients by lfvdm_gn_param_grads, which walks the samples in order - no float atomics
@@ -496,19 +501,54 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
         dxa = dxa + add[:, :C0]
         if dxb is not None:
             dxb = dxb + add[:, C0:]
-    s1, s2 = sums[..., 0], sums[..., 1]              # [N][C]: sum dz, sum dz*xhat
     assert dfilm_out is None, "gradient slots belong to the in-place mode"
-    if film is not None:
-        B = N // T
-        sc1 = 1.0 + film[:, :C].repeat_interleave(T, dim=0)   # (1 + scale) per (n, c)
-        dgamma = (s2 * sc1).sum(0)
-        dbeta = (s1 * sc1).sum(0)
-        dscale = (s2 * gamma + s1 * beta).view(B, T, C).sum(1)
-        dshift = s1.view(B, T, C).sum(1)
-        dfilm = th.cat([dscale, dshift], dim=1)
-    else:
-        dgamma, dbeta, dfilm = s2.sum(0), s1.sum(0), None
+    dgamma, dbeta, dfilm = _gn_param_grads_torch(sums, gamma, beta, film, T, N, C)
     return dxa, dxb, dgamma, dbeta, dfilm
+
+
+def _gn_backward_chunked(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, T, dfilm_out, inplace, add, add2,
+                         dxa, dxb, need):
+    """lfvdm_gn_bwd_ws for all three delivery modes: in place with float atomics (the training default), in place with a
+    fixed summation order (LFVDM_DETERMINISTIC: per-(sample, channel) sums -> lfvdm_gn_param_grads), autograd (sums ->
+    torch reductions).  (add2 has already been folded into add by the caller unless the kernel takes both.)"""
+    C = C0 + C1
+    L = nat.lib()
+    ws = _new(need, like=da)
+    atomics = inplace and not nat.deterministic()
+    sums = None if atomics else _new(N, C, 2, like=da)
+    dfilm = None
+    if film is not None and inplace:
+        dfilm = dfilm_out if dfilm_out is not None else th.zeros(N // T, 2 * C, device=da.device, dtype=th.float32)
+    fptr = film.data_ptr() if film is not None else None
+    fld = film.stride(0) if film is not None else 0
+    nat.check(L.lfvdm_gn_bwd_ws(
+        nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats), act, nat.ptr(dxa),
+        nat.ptr(dxb), nat.ptr(gamma), nat.ptr(beta), fptr if atomics else None, fld, T,
+        nat.ptr(_grad_of(gamma)) if atomics else None, nat.ptr(_grad_of(beta)) if atomics else None,
+        dfilm.data_ptr() if (atomics and dfilm is not None) else None, dfilm.stride(0) if dfilm is not None else 0,
+        nat.ptr(add), add.stride(0) if add is not None else 0, nat.ptr(add2), add2.stride(0) if add2 is not None else 0,
+        nat.ptr(sums), nat.ptr(ws), need, nat.stream()), "lfvdm_gn_bwd_ws")
+    if atomics:
+        return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
+    if inplace:
+        nat.check(L.lfvdm_gn_param_grads(nat.ptr(sums), nat.ptr(gamma), nat.ptr(beta), fptr, fld, T, nat.ptr(_grad_of(gamma)),
+                                         nat.ptr(_grad_of(beta)), dfilm.data_ptr() if dfilm is not None else None,
+                                         dfilm.stride(0) if dfilm is not None else 0, N, C, nat.stream()), "lfvdm_gn_param_grads")
+        return dxa, dxb, None, None, (None if dfilm_out is not None else dfilm)
+    assert dfilm_out is None, "gradient slots belong to the in-place mode"
+    dgamma, dbeta, dfilm = _gn_param_grads_torch(sums, gamma, beta, film, T, N, C)
+    return dxa, dxb, dgamma, dbeta, dfilm
+
+
+def _gn_param_grads_torch(sums, gamma, beta, film, T, N, C):
+    s1, s2 = sums[..., 0], sums[..., 1]              # [N][C]: sum dz, sum dz*xhat
+    if film is None:
+        return s2.sum(0), s1.sum(0), None
+    B = N // T
+    sc1 = 1.0 + film[:, :C].repeat_interleave(T, dim=0)   # (1 + scale) per (n, c)
+    dscale = (s2 * gamma + s1 * beta).view(B, T, C).sum(1)
+    dshift = s1.view(B, T, C).sum(1)
+    return (s2 * sc1).sum(0), (s1 * sc1).sum(0), th.cat([dscale, dshift], dim=1)
 
 
 # ----------------------------------------------------------------------------- ResBlock

@@ -117,6 +117,9 @@ _SIGS = {
     "lfvdm_gn_bwd_apply": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_bwd_apply_params": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i,
                                    c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp], c_i),
+    "lfvdm_gn_bwd_ws_floats": ([c_i, c_i, c_i], C.c_long),
+    "lfvdm_gn_bwd_ws": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i,
+                         c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_fp, C.c_long, c_fp], c_i),
     "lfvdm_gn_bwd_fused": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i,
                             c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp], c_i),
     "lfvdm_gn_param_grads": ([c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),

@@ -1171,3 +1171,68 @@ def test_spatial_fused_refuses_what_does_not_fit(nat):
     assert L.lfvdm_attn_spatial_fused_ok(40, 256, 128, 4) != 0       # 16x16 frame at 128 channels: 128 KB of tokens alone
     assert L.lfvdm_attn_spatial_fused_ok(40, 256, 96, 4) != 0        # head dim 24
     assert L.lfvdm_attn_spatial_fused_ok(40, 64, 128, 4) == 0
+
+
+# ------------------------------------------------------------------------------------------- round-4 additions
+@pytest.mark.parametrize("mode", ["atomics", "deterministic", "autograd"])
+@pytest.mark.parametrize("N,P,C0,C1,film,act,adds", [(2, 2500, 96, 32, True, 1, 2), (4, 1061, 64, 0, False, 1, 0),
+                                                     (2, 4096, 128, 128, True, 1, 1), (2, 16384, 128, 0, False, 1, 2),
+                                                     (2, 300, 512, 256, False, 0, 1), (4, 1024, 256, 0, True, 1, 0),
+                                                     (2, 256, 384, 0, False, 1, 1), (4, 256, 64, 0, False, 1, 1)])
+def test_gn_backward_large_maps(nat, N, P, C0, C1, film, act, adds, mode, monkeypatch):
+    """lfvdm_gn_bwd_ws: the chunked two-launch GroupNorm(+FiLM)(+SiLU) backward for maps whose (sample, 8 groups) slice
+    exceeds one workgroup's registers (pixel space, wide concats) - ragged last chunks, concat split, one / two extra
+    gradients folded into dx - in the three gradient delivery modes, against fp64 autograd of
+    silu(group_norm(x) * (1 + scale) + shift) (reference nn.py:17-19, unet.py:199-203).  The last case fits one
+    workgroup and must take the single-launch kernels (workspace size 0)."""
+    from improved_diffusion import _backward as bw
+    monkeypatch.setenv("LFVDM_DETERMINISTIC", "1" if mode == "deterministic" else "0")
+    C, T = C0 + C1, 2
+    need = int(nat.lib().lfvdm_gn_bwd_ws_floats(C, N, P))
+    assert (need == 0) == (P == 256 and C == 64)
+    a = (rnd("gbl/a", N * P, C0) * 1.3 + 0.7)
+    b = rnd("gbl/b", N * P, C1) if C1 else None
+    gamma, beta = 1 + 0.1 * rnd("gbl/g", C), 0.1 * rnd("gbl/be", C)
+    fm = 0.3 * rnd("gbl/film", N // T, 2 * C) if film else None
+    da = rnd("gbl/da", N * P, C)
+    extra = [rnd(f"gbl/add{i}", N * P, C) for i in range(adds)]
+    # fp64 reference
+    xd = torch.cat([a] + ([b] if C1 else []), dim=1).double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    fd = fm.double().requires_grad_(True) if film else None
+    y = F.group_norm(xd.view(N, P, C).permute(0, 2, 1), 32, gd, bd, eps=1e-5)
+    if film:
+        f = fd.repeat_interleave(T, dim=0)
+        y = y * (1 + f[:, :C, None]) + f[:, C:, None]
+    if act:
+        y = F.silu(y)
+    (y.permute(0, 2, 1).reshape(N * P, C) * da.double()).sum().backward()
+    dx_ref = xd.grad + sum(e.double() for e in extra) if extra else xd.grad
+    # product path
+    gpar = torch.nn.Parameter(gamma.cuda()); bpar = torch.nn.Parameter(beta.cuda())
+    ac, bc = a.cuda(), (b.cuda() if C1 else None)
+    fc = fm.cuda() if film else None
+    _, cA, cB, st = bw._gn_apply(ac, bc, C0, C1, N, P, gpar.detach(), bpar.detach(), fc, T, act)
+    ex = [e.cuda() for e in extra]
+    kw = dict(add=ex[0] if adds >= 1 else None, add2=ex[1] if adds >= 2 else None)
+    runs = []
+    for _ in range(2):
+        gpar.grad = None; bpar.grad = None
+        dxa, dxb, dg, db, dfilm = bw._gn_backward(da.cuda(), ac, bc, C0, C1, N, P, cA, cB, st, act, gpar, bpar, fc, T,
+                                                  inplace=(mode != "autograd"), **kw)
+        if mode != "autograd":
+            dg, db = gpar.grad, bpar.grad
+        torch.cuda.synchronize()
+        runs.append((dxa.clone(), None if dxb is None else dxb.clone(), dg.clone(), db.clone(), None if dfilm is None else dfilm.clone()))
+    dxa, dxb, dg, db, dfilm = runs[0]
+    dx = torch.cat([dxa] + ([dxb] if C1 else []), dim=1)
+    scale = float(dx_ref.abs().max())
+    close(dx, dx_ref.float(), 3e-5 * max(scale, 1.0))
+    close(dg, gd.grad.float(), 2e-4 * float(gd.grad.abs().max()))
+    close(db, bd.grad.float(), 2e-4 * float(bd.grad.abs().max()))
+    if film:
+        close(dfilm, fd.grad.float(), 2e-4 * float(fd.grad.abs().max()))
+    # dx is deterministic in every mode; the parameter gradients are when no float atomics are involved
+    assert torch.equal(runs[0][0], runs[1][0]) and (dxb is None or torch.equal(runs[0][1], runs[1][1]))
+    if mode != "atomics":
+        assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
