@@ -43,10 +43,10 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.
 HBM_PEAK_GBS = 8000.0
 
 
-def make_model_and_diffusion(num_channels, device, steps=1000, respacing=""):
+def make_model_and_diffusion(num_channels, device, steps=1000, respacing="", image_size=16):
     from improved_diffusion import script_util as su
     kw = su.model_and_diffusion_defaults()
-    kw.update(image_size=16, in_channels=4, num_channels=num_channels, num_res_blocks=1, num_heads=4,
+    kw.update(image_size=image_size, in_channels=4, num_channels=num_channels, num_res_blocks=1, num_heads=4,
               attention_resolutions="16,8", diffusion_steps=steps, timestep_respacing=respacing,
               diffusion_space_kwargs={"diffusion_space": "pixel", "pre_encoded": False, "pre_encoded_stats_dict": None})
     model, diffusion = su.create_model_and_diffusion(**kw)
@@ -120,6 +120,10 @@ def kernel_breakdown(plan, reps=10, inner=4):
             name = f"conv_igemm_kernel<{v // 1000},{v // 100 % 10},{v // 10 % 10},{v % 10}>"
             flops = conv_flops(a)
             nbytes = conv_bytes(a)
+        elif name in ("lfvdm_gn_apply", "lfvdm_gn_apply_ws"):      # (src0, src1, C0, C1, N, P, ...): read once, written once
+            nbytes = 2.0 * 4.0 * args[4] * args[5] * (args[2] + args[3])
+        elif name == "lfvdm_gn_temporal":                           # (x, gamma, beta, eps, y, B, T, P, C)
+            nbytes = 2.0 * 4.0 * args[5] * args[6] * args[7] * args[8]
         gsum = groups.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
         gsum["launches"] += 1
         gsum["ms"] += tot[i] / reps
@@ -144,17 +148,17 @@ def _oracle_model(model):
     return sd, cfg
 
 
-def cpu_baseline_sample(model, inputs, B, T, threads, budget_s):
+def cpu_baseline_sample(model, inputs, B, T, threads, budget_s, H=16, chain=1000, what="the same workload"):
     """CPU oracle restatement of the same denoising step (kind 'port') on `threads` host threads."""
     from oracle import unet_oracle as uo, diffusion_oracle as do
     th.set_num_threads(threads)
     sd, cfg = _oracle_model(model)
-    tab = do.Tables(do.linear_betas(1000))
+    tab = do.Tables(do.linear_betas(chain))
     ci = {k: v.cpu() for k, v in inputs.items()}
-    x = th.randn(B, T, 4, 16, 16)
+    x = th.randn(B, T, 4, H, H)
     n, t0 = 0, None
     with th.no_grad():
-        for i in range(999, -1, -1):
+        for i in list(range(chain - 1, -1, -1)) * (1 + 40 // chain):
             if n == 2:
                 t0 = time.perf_counter()
             t = th.full((B,), i, dtype=th.long)
@@ -166,32 +170,34 @@ def cpu_baseline_sample(model, inputs, B, T, threads, budget_s):
                 break
     el = time.perf_counter() - t0
     return dict(value=round((n - 2) / el, 3), unit="steps/s", cores=threads, kind="port",
-                sample=f"{n - 2} p_sample steps of the same workload (oracle/unet_oracle.py + diffusion_oracle.py, torch CPU fp32)")
+                sample=f"{n - 2} p_sample steps of {what} (oracle/unet_oracle.py + diffusion_oracle.py, torch CPU fp32)")
 
 
-def cpu_baseline_train(threads, budget_s):
-    """CPU oracle restatement of one optimizer step at BASELINE.json configs[2] (reference TrainLoop.run_step,
+def cpu_baseline_train(threads, budget_s, num_channels=128, B=2, T=20, H=16, chain=1000,
+                       what="configs[2] (ch128, batch 2, 20 frames)"):
+    """CPU oracle restatement of one optimizer step (default: BASELINE.json configs[2]; reference TrainLoop.run_step,
     train_util.py:267-275: zero grads, q_sample, U-Net forward, masked MSE, backward, AdamW, EMA) on `threads` threads."""
     from oracle import unet_oracle as uo, diffusion_oracle as do
     th.set_num_threads(threads)
-    model, _ = make_model_and_diffusion(128, th.device("cpu"))
+    model, _ = make_model_and_diffusion(num_channels, th.device("cpu"), steps=chain, image_size=H)
     sd, cfg = _oracle_model(model)
     del model
     params = {k: v.requires_grad_(True) for k, v in sd.items()}
     ema = {k: v.detach().clone() for k, v in params.items()}
     opt = th.optim.AdamW(list(params.values()), lr=1e-4, weight_decay=0.0)
-    tab = do.Tables(do.linear_betas(1000))
-    B, T = 2, 20
+    tab = do.Tables(do.linear_betas(chain))
     g = th.Generator().manual_seed(4321)
-    obs = th.zeros(B, T, 1, 1, 1); obs[:, :6] = 1.0
-    lat = 1.0 - obs; lat[:, -3:] = 0.0                      # 3 padding frames: neither observed nor latent
+    obs = th.zeros(B, T, 1, 1, 1); obs[:, :max(T // 3, 1)] = 1.0
+    lat = 1.0 - obs
+    if T >= 10:
+        lat[:, -3:] = 0.0                                   # 3 padding frames: neither observed nor latent
     n, t0 = 0, None
     while True:
         if n == 1:
             t0 = time.perf_counter()
-        x0 = th.randn(B, T, 4, 16, 16, generator=g).clamp(-1, 1)
+        x0 = th.randn(B, T, 4, H, H, generator=g).clamp(-1, 1)
         fi = th.stack([th.sort(th.randperm(40, generator=g)[:T])[0] for _ in range(B)])
-        t = th.randint(0, 1000, (B,), generator=g)
+        t = th.randint(0, chain, (B,), generator=g)
         noise = th.randn(x0.shape, generator=g)
         opt.zero_grad(set_to_none=True)
 
@@ -209,7 +215,7 @@ def cpu_baseline_train(threads, budget_s):
             break
     el = time.perf_counter() - t0
     return dict(value=round((n - 1) / el, 3), unit="optimizer steps/s", cores=threads, kind="port",
-                sample=f"{n - 1} training steps at configs[2] (ch128, batch 2, 20 frames): oracle forward + torch autograd "
+                sample=f"{n - 1} training steps at {what}: oracle forward + torch autograd "
                        "backward + torch AdamW + EMA, torch CPU fp32")
 
 
@@ -247,26 +253,54 @@ _TRAIN_FAMILIES = (
 )
 
 
-def train_family_split():
+def running_code_stamp():
+    """What identifies the code that is running: the library's ABI version and the digest of csrc/* + headers recorded by
+    the build next to the library (lib/build_manifest.json)."""
+    from improved_diffusion import _native as nat
+    digest = None
+    try:
+        with open(os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd", "lib", "build_manifest.json")) as f:
+            digest = json.load(f).get("source_digest")
+    except (OSError, ValueError):
+        pass
+    return {"abi": int(nat.lib().lfvdm_abi_version()), "source_digest": digest}
+
+
+def profile_stamp(path):
+    """Stamp of a committed profile: `<file>.stamp.json` written next to it by tools/refresh_profiles.sh on the box that took
+    it ({"abi", "source_digest", "git_head"}).  -> (stamp or None, stale?) where stale means it was taken with other kernels
+    than the ones running now (or carries no stamp at all)."""
+    try:
+        with open(path + ".stamp.json") as f:
+            st = json.load(f)
+    except (OSError, ValueError):
+        return None, True
+    now = running_code_stamp()
+    stale = st.get("abi") != now["abi"] or (now["source_digest"] is not None and st.get("source_digest") != now["source_digest"])
+    return st, bool(stale)
+
+
+def train_family_split(pattern="r*_train_kernel_stats.csv"):
     """Per-family GPU milliseconds of one training step from the newest committed rocprofv3 kernel summary
     (profiles/rNN_train_kernel_stats.csv: `rocprofv3 --kernel-trace --stats -- python3 tools/train_profile.py`; steps =
-    calls of the fused optimizer kernel).  None when no summary is committed."""
+    calls of the fused optimizer kernel).  None when no summary is committed.  `stale: true` when the summary's stamp
+    (library ABI + source digest of the run that took it) is not the running code's."""
     import csv
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_kernel_stats.csv")), reverse=True)
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True)
     if not paths:
         return None
     rows = []
     with open(paths[0]) as f:
         for r in csv.DictReader(f):
-            rows.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"])))
-    steps = sum(c for n, c, _ in rows if "adamw_ema" in n)
+            rows.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"])))
+    steps = sum(c for n, c, _, _ in rows if "adamw_ema" in n)
     if steps <= 0:
         return None
     fam = {k: 0.0 for k, _ in _TRAIN_FAMILIES}
     fam["other kernels"] = 0.0
     launches = 0
-    for n, c, ns in rows:
+    for n, c, ns, _ in rows:
         launches += c
         for k, pats in _TRAIN_FAMILIES:
             if any(pt in n for pt in pats):
@@ -274,9 +308,13 @@ def train_family_split():
                 break
         else:
             fam["other kernels"] += ns
-    return {"source": os.path.relpath(paths[0], ROOT), "profiled_steps": steps, "launches_per_step": round(launches / steps, 1),
+    gn = [(n, avg) for n, _, _, avg in rows if "gn_" in n]
+    stamp, stale = profile_stamp(paths[0])
+    return {"source": os.path.relpath(paths[0], ROOT), "stamp": stamp, "stale": stale,
+            "profiled_steps": steps, "launches_per_step": round(launches / steps, 1),
             "ms_per_step": {k: round(v / steps / 1e6, 3) for k, v in fam.items()},
-            "gpu_ms_per_step": round(sum(fam.values()) / steps / 1e6, 3)}
+            "gpu_ms_per_step": round(sum(fam.values()) / steps / 1e6, 3),
+            "slowest_groupnorm_kernel_avg_us": round(max((a for _, a in gn), default=0.0) / 1e3, 1)}
 
 
 def synthetic_video_stream(B, T_video, seed):
@@ -285,7 +323,79 @@ def synthetic_video_stream(B, T_video, seed):
         yield (th.randn(B, T_video, 4, 16, 16, generator=g).clamp(-1, 1), {})
 
 
-def bench_train(rank, world, dev, steps, warmup):
+def _event_time_us(fn, reps=20, warm=3):
+    """Average HIP-event time of `fn` (which enqueues on torch's current stream = the stream the C-ABI launches use)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    th.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return 1000.0 * e0.elapsed_time(e1) / reps
+
+
+def _hbm_record(nbytes, us, what):
+    gbs = nbytes / (us * 1e-6) / 1e9
+    return {"bytes": int(nbytes), "us": round(us, 2), "gb_per_s": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "what": what}
+
+
+def hbm_phases_latent(diffusion, dev):
+    """The memory-bound phases of the path against the HBM peak, live HIP-event timing of the same entry
+    points the training step uses, at the configs[2] shapes (B=2, T=20, 4x16x16): q_sample (3 tensors) and masked MSE
+    (eps, eps_hat read; per-sample sums written).  These tensors are 164 KB: the launches are latency-bound and the
+    fraction says so."""
+    from improved_diffusion._autograd import masked_mse
+    B, T = 2, 20
+    g = th.Generator(device="cpu").manual_seed(5)
+    x0, noise = th.randn(B, T, 4, 16, 16, generator=g).to(dev), th.randn(B, T, 4, 16, 16, generator=g).to(dev)
+    t = th.tensor([17, 801], device=dev)
+    mask = th.ones(B, T, 1, 1, 1, device=dev)
+    n = x0.numel()
+    with th.no_grad():
+        q = _event_time_us(lambda: diffusion.q_sample(x0, t, noise))
+        m = _event_time_us(lambda: masked_mse(noise, x0, mask))
+    return {"q_sample": _hbm_record(12.0 * n, q, "x0, eps read + x_t written, 40960 elements (incl. the output allocation)"),
+            "masked_mse": _hbm_record(8.0 * n, m, "eps, eps_hat read, 40960 elements")}
+
+
+def hbm_phases_pixel(dev):
+    """Large-map GroupNorm forward / backward (the chunked two-launch forms) on one pixel-space activation,
+    20 x 128 x 128 x 128 fp32 = 168 MB: forward reads x twice and writes act once (3 tensors), backward reads x and da
+    twice and writes dx once (5 tensors)."""
+    from improved_diffusion import _backward as bw, _native as nat
+    N, P, C = 20, 128 * 128, 128
+    g = th.Generator(device="cpu").manual_seed(6)
+    x = th.randn(N * P // 64, C, generator=g).to(dev).repeat(64, 1)
+    da = th.randn(N * P // 64, C, generator=g).to(dev).repeat(64, 1)
+    gamma, beta = th.nn.Parameter(th.ones(C, device=dev)), th.nn.Parameter(th.zeros(C, device=dev))
+    res = {}
+    with th.no_grad():
+        _, cA, cB, st = bw._gn_apply(x, None, C, 0, N, P, gamma, beta, None, 1, nat.ACT_SILU)
+        f = _event_time_us(lambda: bw._gn_apply(x, None, C, 0, N, P, gamma, beta, None, 1, nat.ACT_SILU), reps=10)
+        b = _event_time_us(lambda: bw._gn_backward(da, x, None, C, 0, N, P, cA, cB, st, nat.ACT_SILU, gamma, beta, None, 1,
+                                                   inplace=True), reps=10)
+    nb = 4.0 * N * P * C
+    res["gn_apply_large_map"] = _hbm_record(3 * nb, f, "lfvdm_gn_apply_ws (2 launches) on 20x128x128x128: x read twice, act written")
+    res["gn_backward_large_map"] = _hbm_record(5 * nb, b, "lfvdm_gn_bwd_ws (2 launches) on 20x128x128x128: x, da read twice, dx written")
+    return res
+
+
+def exchange_machinery_probe(dev, steps=12):
+    """What the bucketed exchange costs BEFORE any byte crosses xGMI, on today's code: the cfg-C training step once more
+    at world size 1 with LFVDM_FORCE_EXCHANGE=1 - marker nodes, per-bucket folds, counter kernels, one SUM all-reduce per
+    bucket over ONE rank on RCCL's stream behind the polling kernel, the collective skip word, the optimizer behind them."""
+    os.environ["LFVDM_FORCE_EXCHANGE"] = "1"
+    try:
+        return bench_train(0, 1, dev, steps, 4, probe_only=True)
+    finally:
+        os.environ.pop("LFVDM_FORCE_EXCHANGE", None)
+
+
+def bench_train(rank, world, dev, steps, warmup, probe_only=False):
     """DDP-style training at BASELINE.json configs[2]: latent U-Net num_channels=128, max_frames=20, batch 2 per
     GPU (global 2*N), one optimizer step = mask sampling + q_sample + U-Net forward/backward + ONE RCCL all-reduce
     of the gradient arena + fused AdamW/EMA (reference TrainLoop.run_step, train_util.py:267-275)."""
@@ -331,7 +441,20 @@ def bench_train(rank, world, dev, steps, warmup):
     P = sum(p.numel() for p in model.parameters())
     xch = loop.exchange
     th.cuda.synchronize()
+    if probe_only:
+        xch.collect_timing()
+        return {"ms_per_step": round(1000.0 * el / steps, 3), "steps": steps, "overlap_probe": xch.overlap_probe,
+                "overlap_with_backward": bool(xch.overlap), "buckets": len(xch.ranges),
+                "buckets_started_inside_the_backward": xch.stats["buckets_behind_event"],
+                "buckets_started_after_the_backward": xch.stats["buckets_behind_graph_end"],
+                "exposed_ms_per_step": round(sum(xch.exposed_ms[-steps:]) / max(1, len(xch.exposed_ms[-steps:])), 3),
+                "backend": dist.get_backend() if dist.is_initialized() else None}
     exposed = xch.collect_timing()[-steps:] if world > 1 else []
+    opt_us = None
+    if world == 1:          # the fused optimizer launch alone (HBM-bound: 5 arenas read, 4 written)
+        def _opt():
+            loop.optimize_normal()
+        opt_us = _event_time_us(_opt, reps=10, warm=2)
     fl = train_step_flops(model, 2, 20, 16, 16)
     tfl = fl["step"] / (el / steps) / 1e12
     roof = {"bound": "mfma", "flops_per_step": fl["step"], "forward_conv_gemm_flops": fl["forward_conv_gemm"],
@@ -348,6 +471,10 @@ def bench_train(rank, world, dev, steps, warmup):
            "allreduce_bytes_per_step": 4 * loop.arena.numel if world > 1 else 0, "last_loss": loss,
            "workload": "train: U-Net num_channels=128 num_res_blocks=1 max_frames=20 batch 2/GPU, AdamW+EMA, bucketed "
                        "all-reduce of the fp32 gradient arena overlapped with the backward graph (BASELINE.json configs[2])"}
+    if opt_us is not None:
+        out["hbm_phases"] = {"adamw_ema": _hbm_record(4.0 * P * (7 + 2 * len(loop.ema_flat)), opt_us,
+                                                      "lfvdm_adamw_ema: p, g, m, v, ema read; p, m, v, ema written = 36 B per "
+                                                      "parameter (+ the 4-byte grad-norm memset of optimize_normal)")}
     # the same record at every N (N = 1: no collective runs, the layout is what the N > 1 job will exchange)
     out["exchange"] = {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": dist.get_backend() if (dist.is_initialized() and world > 1) else "none (one rank)",
@@ -513,9 +640,21 @@ def bench_pixel_train(dev, steps, batch=1, num_res_blocks=1, warmup=4):
                         "forward_attention_flops": fl["forward_attention"], "achieved": round(tfl, 2),
                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4),
                         "note": "whole optimizer step (wall clock, all launches) against the fp32 MFMA peak; FLOPs = 3 x forward"}}
+    if batch == 1 and num_res_blocks == 1:
+        out["roofline"]["families"] = train_family_split("r*_pixel_train_kernel_stats.csv")
     del loop, model
     th.cuda.empty_cache()
     return out
+
+
+def pmc_traffic_source():
+    """(path, stamp, stale) of the newest committed PMC summary."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
+    if not paths:
+        return None
+    stamp, stale = profile_stamp(paths[0])
+    return {"source": os.path.relpath(paths[0], ROOT), "stamp": stamp, "stale": stale}
 
 
 def pmc_traffic(kernel_name):
@@ -589,6 +728,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--train-steps", type=int, default=30, help="timed optimizer steps of the training leg (0 = skip)")
+    ap.add_argument("--machinery-steps", type=int, default=12,
+                    help="N = 1 only: optimizer steps of the forced-exchange probe (LFVDM_FORCE_EXCHANGE=1; 0 = skip)")
+    ap.add_argument("--pixel-train-steps", type=int, default=5, help="timed optimizer steps of each pixel-space training leg (0 = skip)")
     ap.add_argument("--pixel-steps", type=int, default=5, help="timed steps of the pixel-space stress config, configs[4] (0 = skip)")
     ap.add_argument("--long-video-windows", type=int, default=4,
                     help="windows of the hierarchy-2 long-video leg, configs[3] (97 = the full 1000-frame video; 0 = skip)")
@@ -608,6 +750,10 @@ def main():
     th.cuda.set_device(local)
     dev = th.device("cuda", local)
     backend = None
+    # CU budget of the collectives that run beside the backward graph: LFVDM_RCCL_MAX_CHANNELS -> NCCL_MAX_NCHANNELS (each
+    # RCCL channel is one workgroup of its reduction kernels), to trade exposed exchange time against backward slowdown
+    if os.environ.get("LFVDM_RCCL_MAX_CHANNELS"):
+        os.environ["NCCL_MAX_NCHANNELS"] = os.environ["LFVDM_RCCL_MAX_CHANNELS"]
     if world > 1:
         backend = os.environ.get("LFVDM_BENCH_BACKEND") or ("gloo" if shared_cards else "nccl")   # nccl = RCCL
         os.environ["LFVDM_DIST_BACKEND"] = backend
@@ -638,14 +784,30 @@ def main():
     # Work that the sampler does once per CHAIN instead of once per step (the R tables: everything that depends on the
     # timestep and this chain's frame indices, GraphSampler.begin) is charged to every timed step at 1/chain-length of
     # its cost.  What is done once per set of WEIGHTS (graph capture, launch tuning, the FiLM tables) is reported as
-    # first_chain_setup_ms and, like capture and tuning, not charged: a whole 1000-step chain through the public
-    # p_sample_loop takes 1142 ms warm (devtests/chain_wall.py), which is what `value` reproduces.
+    # first_chain_setup_ms and, like capture and tuning, not charged.  The same chain through the PUBLIC API
+    # (diffusion.p_sample_loop) is timed below and must reproduce `value` (public_api).
     table_ms = float(getattr(sampler, "table_build_ms", 0.0))
     per_step_s = table_ms * 1e-3 / diffusion.num_timesteps
     el_steps = sum(times)
     el = el_steps + per_step_s * args.steps * regions
     finite = bool(th.isfinite(sampler.plan.x_in).all().item())
     tables_info = (sampler.plan.time_table_bytes, sampler.plan.time_table_fallback)   # fallback: why the per-step plan runs
+    # ---- the metric's own definition: one whole chain through the public p_sample_loop (reference
+    # gaussian_diffusion.py:403-522: noise draw, per-chain tables, 1000 x p_sample, final clone), wall clock
+    th.manual_seed(4321 + rank)
+    diffusion.p_sample_loop(model, shape, model_kwargs=inputs, return_decoded=False)        # (warm: same sampler object)
+    th.cuda.synchronize()
+    walls = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        pub, _ = diffusion.p_sample_loop(model, shape, model_kwargs=inputs, return_decoded=False)
+        th.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    public_wall = min(walls)
+    public_api = {"p_sample_loop_wall_ms": round(1000.0 * public_wall, 2), "chain_steps": diffusion.num_timesteps,
+                  "steps_per_s_public_api": round(diffusion.num_timesteps / public_wall, 2),
+                  "finite": bool(th.isfinite(pub).all().item()),
+                  "note": "diffusion.p_sample_loop(model, shape, model_kwargs=..., return_decoded=False), best of 2 warm chains"}
     train = None
     if args.train_steps > 0:
         del sampler
@@ -663,6 +825,9 @@ def main():
         "ms_per_step": round(1000.0 * el / total_steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "timed_regions": regions, "timed_seconds": round(el_steps, 4),
+        "p_sample_loop_wall_ms": public_api["p_sample_loop_wall_ms"],
+        "steps_per_s_public_api": public_api["steps_per_s_public_api"],
+        "public_api": public_api,
         "per_chain_setup": {"table_build_ms": round(table_ms, 3), "first_chain_table_build_ms": round(cold_setup_ms, 3),
                             "chain_steps": diffusion.num_timesteps,
                             "charged_ms_per_step": round(1000.0 * per_step_s, 5),
@@ -688,6 +853,18 @@ def main():
     out["self_check"] = checks
     if not all(checks.values()):
         raise SystemExit(f"bench.py self-check failed: {checks} (WORLD_SIZE={world}, backend={backend}, devices={n_dev})")
+    public_api["agrees_with_value_within_3pct"] = abs(public_api["steps_per_s_public_api"] * world / out["value"] - 1.0) <= 0.03
+    out["code_stamp"] = running_code_stamp()
+    if train is not None and world == 1 and rank == 0 and args.machinery_steps > 0:
+        # one GPU can report what the exchange machinery costs with today's code (before any byte crosses xGMI)
+        probe = exchange_machinery_probe(dev, args.machinery_steps)
+        train["exchange"]["machinery_ms_per_step"] = round(probe["ms_per_step"] - train["ms_per_step"], 3)
+        train["exchange"]["machinery"] = {"forced_exchange_ms_per_step": probe["ms_per_step"],
+                                          "plain_ms_per_step": train["ms_per_step"], **{k: probe[k] for k in (
+                                              "buckets", "buckets_started_inside_the_backward", "buckets_started_after_the_backward",
+                                              "overlap_with_backward", "exposed_ms_per_step", "backend", "steps")}}
+        train["exchange"]["overlap_probe"] = probe["overlap_probe"]
+        train["exchange"]["rccl_max_channels"] = os.environ.get("NCCL_MAX_NCHANNELS")
     if train is not None:
         out["train"] = train
         # the quantity that shards WITH an exchange, at top level and in the same schema at every N
@@ -695,8 +872,9 @@ def main():
         out["train_optimizer_steps_per_s"] = train["optimizer_steps_per_s"]
         out["allreduce_bytes_per_step"] = train["allreduce_bytes_per_step"]
         out["exposed_allreduce_ms_per_step"] = train["exchange"]["exposed_ms_per_step"]
-        out["exchange"] = {k: train["exchange"][k] for k in ("bucket_bytes", "exposed_ms_per_step",
-                                                                "buckets_started_inside_the_backward", "overlap_probe")}
+        out["exchange"] = {k: train["exchange"].get(k) for k in ("bucket_bytes", "exposed_ms_per_step",
+                                                                    "buckets_started_inside_the_backward", "overlap_probe",
+                                                                    "machinery_ms_per_step")}
     if rank == 0:
         # the single-GPU legs (configs[3], configs[4]) and the CPU baselines belong to the N = 1 line only
         if args.long_video_windows > 0 and world == 1:
@@ -707,6 +885,15 @@ def main():
             th.cuda.empty_cache()
             out["pixel"] = bench_pixel(dev, args.pixel_steps)
             th.cuda.empty_cache()
+            if args.pixel_train_steps > 0:
+                # the reference's published training recipe (README.md:54-57) and its rb2 / batch-1 neighbours
+                legs = [bench_pixel_train(dev, args.pixel_train_steps, batch=b, num_res_blocks=rb) for b, rb in ((1, 1), (2, 1), (1, 2))]
+                out["pixel"]["train"] = legs[0]
+                out["pixel"]["train"]["other_configs"] = [{k: lg[k] for k in ("workload", "ms_per_step", "optimizer_steps_per_s",
+                                                                               "frames_per_s", "params", "hbm_allocated_peak_gib")}
+                                                          | {"tflops": lg["roofline"]["achieved"], "frac": lg["roofline"]["frac"]}
+                                                          for lg in legs[1:]]
+                th.cuda.empty_cache()
             sampler = diffusion._graph_sampler(model, shape, True)
             sampler.begin(th.randn(*shape, device=dev), inputs)
         if not args.no_breakdown:
@@ -732,6 +919,7 @@ def main():
                                 "algorithmic_bytes": round(g["bytes"] / g["launches"]), "pmc_bytes": pmc_traffic(k)}
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "traffic_source": pmc_traffic_source(),
                                "algorithmic_bytes": round(dom["bytes"] / dom["launches"]),
                                "kernel": "conv_igemm_kernel (all tile-shape instances of the implicit GEMM)",
                                "launches_per_step": dom["launches"],
@@ -750,11 +938,38 @@ def main():
                                 "whole_step_frac_of_mfma_peak": round(dom["flops"] * out["value"] / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                 "kernels": {k: {"n": g["launches"], "us": round(1000 * g["ms"], 1)} for k, g in
                                             sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}}
+        if world == 1:
+            hp = dict(train.get("hbm_phases", {})) if train is not None else {}
+            if not args.no_breakdown:
+                for key, name in (("gn_apply", "lfvdm_gn_apply"), ("gn_temporal", "lfvdm_gn_temporal")):
+                    g = groups.get(name)
+                    if g:
+                        rec = _hbm_record(g["bytes"] / g["launches"], 1000.0 * g["ms"] / g["launches"],
+                                          f"{name}: {g['launches']} launches per cfg-B denoising step, mean bytes (x read, act written) and "
+                                          "HIP-event time per launch; 0.16-2.6 MB tensors, L2-resident: launch-latency bound")
+                        hp[key] = rec
+            hp.update(hbm_phases_latent(diffusion, dev))
+            if args.pixel_train_steps > 0 and args.pixel_steps > 0:
+                hp.update(hbm_phases_pixel(dev))
+                th.cuda.empty_cache()
+            out["hbm_phases"] = hp
         if not args.no_cpu and world == 1:
             cores = _host_cores()
             out["cpu_baseline"] = cpu_baseline_sample(model, inputs, B, T, cores, 8.0)
             out["cpu_baseline"]["one_thread"] = cpu_baseline_sample(model, inputs, B, T, 1, 5.0)
             out["cpu_baseline"]["train"] = cpu_baseline_train(cores, 8.0)
+            # "sample and train at cfgs A/B/C" (>= 10 timed steps each)
+            ma, _ = make_model_and_diffusion(32, th.device("cpu"), steps=32, image_size=32)
+            ia = {k: v.cpu() for k, v in synthetic_inputs(1, 5, 0, th.device("cpu")).items()}
+            ia["x0"] = th.randn(1, 5, 4, 32, 32, generator=th.Generator().manual_seed(9))
+            out["cpu_baseline"]["cfgA_sample"] = cpu_baseline_sample(ma, ia, 1, 5, cores, 4.0, H=32, chain=32,
+                                                                     what="configs[0] (32x32, ch32, batch 1, 5 frames, 32-step chain)")
+            out["cpu_baseline"]["cfgA_train"] = cpu_baseline_train(cores, 4.0, num_channels=32, B=1, T=5, H=32, chain=32,
+                                                                   what="configs[0] (32x32, ch32, batch 1, 5 frames)")
+            mc, _ = make_model_and_diffusion(128, th.device("cpu"))
+            out["cpu_baseline"]["cfgC_sample"] = cpu_baseline_sample(mc, inputs, B, T, cores, 6.0,
+                                                                     what="the configs[2] network (ch128, batch 2, 20 frames)")
+            del ma, mc
         print(json.dumps(out), flush=True)
     if dist.is_initialized():            # (the training leg initialises a world-1 group too)
         if world > 1:

@@ -48,6 +48,11 @@ def setup_dist():
     # "nccl" is RCCL on ROCm.  LFVDM_DIST_BACKEND=gloo is for rehearsing several ranks on ONE card (RCCL refuses two
     # ranks on the same device): tests/test_dist_gpu.py and `bench.py --gpus N` on a box with fewer than N GPUs.
     backend = os.environ.get("LFVDM_DIST_BACKEND") or ("nccl" if th.cuda.is_available() else "gloo")
+    # CU budget of the gradient collectives, which run BESIDE the replayed backward graph (_exchange.py): every RCCL channel
+    # is one workgroup of its reduction kernels.  LFVDM_RCCL_MAX_CHANNELS -> NCCL_MAX_NCHANNELS (must be set before the
+    # communicator exists) trades exposed exchange time against the slowdown of the backward pass it overlaps.
+    if os.environ.get("LFVDM_RCCL_MAX_CHANNELS"):
+        os.environ["NCCL_MAX_NCHANNELS"] = os.environ["LFVDM_RCCL_MAX_CHANNELS"]
     comm = _mpi_comm()
     if comm is not None and "RANK" not in os.environ:
         hostname = "127.0.0.1" if backend == "gloo" else socket.gethostbyname(socket.getfqdn())

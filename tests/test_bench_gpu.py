@@ -48,9 +48,26 @@ def test_two_rank_rehearsal_line_is_self_checking():
 
 
 def test_one_rank_line_has_the_same_schema():
-    d = _run(["--steps", "50", "--train-steps", "4", "--no-cpu", "--pixel-steps", "0", "--long-video-windows", "0", "--no-breakdown"])
+    d = _run(["--steps", "50", "--train-steps", "6", "--machinery-steps", "6", "--no-cpu", "--pixel-steps", "0",
+              "--long-video-windows", "0", "--no-breakdown"])
     for k in CONTRACT + MULTI:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["collective_world_size"] == 1 and d["allreduce_bytes_per_step"] == 0
     assert d["exposed_allreduce_ms_per_step"] == 0.0 and all(d["self_check"].values())
     assert d["per_chain_setup"]["fallback"] is None and d["per_chain_setup"]["timestep_table_bytes"] > 0
+    # the headline through the public API: one whole 1000-step chain of diffusion.p_sample_loop
+    assert d["p_sample_loop_wall_ms"] > 0 and d["steps_per_s_public_api"] > 0 and d["public_api"]["finite"]
+    assert abs(d["steps_per_s_public_api"] / d["value"] - 1.0) < 0.06, (d["steps_per_s_public_api"], d["value"])   # (50-step regions are noisy)
+    # what one GPU can report about the exchange with today's code: the machinery forced on at world size 1 (RCCL)
+    ex = d["train"]["exchange"]
+    assert isinstance(ex["machinery_ms_per_step"], float) and -1.0 < ex["machinery_ms_per_step"] < 5.0, ex
+    assert ex["overlap_probe"] is not None and "ok" in ex["overlap_probe"], ex
+    assert ex["machinery"]["buckets"] >= 2 and ex["machinery"]["backend"] == "nccl"
+    assert ex["machinery"]["buckets_started_inside_the_backward"] > 0 or not ex["overlap_probe"]["ok"]
+    assert d["exchange"]["machinery_ms_per_step"] == ex["machinery_ms_per_step"] and d["exchange"]["overlap_probe"] == ex["overlap_probe"]
+    # memory-bound phases against the HBM peak
+    hp = d["hbm_phases"]
+    for k in ("adamw_ema", "q_sample", "masked_mse"):
+        assert hp[k]["bytes"] > 0 and hp[k]["us"] > 0 and 0 < hp[k]["frac"] < 1, (k, hp[k])
+    assert hp["adamw_ema"]["frac"] > 0.4, hp["adamw_ema"]
+    assert d["code_stamp"]["abi"] > 0
