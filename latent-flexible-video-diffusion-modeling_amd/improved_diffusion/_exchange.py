@@ -79,6 +79,11 @@ def plan_buckets(named_params, n_buckets=4):
     return groups, marks
 
 
+def _comm_priority():
+    """Priority of the communication stream (LFVDM_COMM_STREAM_PRIORITY, default 0 = normal)."""
+    return int(os.environ.get("LFVDM_COMM_STREAM_PRIORITY", "0"))
+
+
 class _Mark(th.autograd.Function):
     """Identity; its backward tells the exchange that every gradient kernel of a bucket has been issued."""
 
@@ -115,7 +120,7 @@ class GradExchange:
         self._late = []                    # (pinned word, event): the timed-out word of earlier steps, read one step late
         if self.overlap:
             from . import _native as nat
-            self.comm = th.cuda.Stream(priority=-1)     # a wait parked here must not sit behind bulk work of other streams
+            self.comm = th.cuda.Stream(priority=_comm_priority())
             self.overlap_probe = self._probe_overlap()
             if self.overlap_probe["ok"]:
                 self.flags = nat.StreamFlags(self.n_early, arena.g.device)
@@ -232,7 +237,7 @@ class GradExchange:
                     dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
             return
         if self.comm is None:
-            self.comm = th.cuda.Stream(priority=-1)
+            self.comm = th.cuda.Stream(priority=_comm_priority())
         main = th.cuda.current_stream()
         end = th.cuda.Event()
         end.record(main)
