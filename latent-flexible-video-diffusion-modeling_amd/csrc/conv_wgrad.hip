@@ -780,10 +780,13 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
         const int t_cot = tcode & 3, t_ns = (tcode >> 2) & 3;
         const long t_ms = tcode >> 4;
         if (t_cot == 1 && a->Cout >= 64) cot = 2;
-        if (t_cot == 2 && a->Cout >= 128) cot = 4;
+        if ((t_cot == 2 || t_cot == 3) && a->Cout >= 128) cot = 4;
         int kt = 0;
         for (int k : {2})
             if (kt == 0 && Cin % (32 * k) == 0 && a->C0 % (32 * k) == 0) kt = k;
+        // tile code 3: 128 filters x 128 channels per workgroup (four 32x32 tiles per wave: twice the MFMAs per staged chunk
+        // and per barrier, 32 instead of 21 FLOP per staged byte); LDS-DMA kernel only
+        const bool wide_k = t_cot == 3 && cot == 4 && Cin % 128 == 0 && a->C0 % 128 == 0;
         if (const char* f = getenv("LFVDM_WGRAD_TILE")) {   // tuning aid: "<cot><kt>", e.g. 22
             const int v = atoi(f);
             if (cot >= v / 10) cot = v / 10;
@@ -795,7 +798,8 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
                 int ns = getenv("LFVDM_WGRAD_STAGES") ? atoi(getenv("LFVDM_WGRAD_STAGES")) : 3;
                 if (t_ns) ns = t_ns == 1 ? 2 : 3;
                 int rc;
-                if (cot == 4) rc = ns == 2 ? launch_wgrad_dma<4, 2, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<4, 2, 3>(a, s, nchunks, t_ms);
+                if (wide_k) rc = ns == 2 ? launch_wgrad_dma<4, 4, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<4, 4, 3>(a, s, nchunks, t_ms);
+                else if (cot == 4) rc = ns == 2 ? launch_wgrad_dma<4, 2, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<4, 2, 3>(a, s, nchunks, t_ms);
                 else rc = ns == 2 ? launch_wgrad_dma<2, 2, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<2, 2, 3>(a, s, nchunks, t_ms);
                 if (rc != LFVDM_OK) return rc;
                 LFVDM_CHECK_LAUNCH();

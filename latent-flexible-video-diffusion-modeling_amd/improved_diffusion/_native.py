@@ -368,10 +368,13 @@ def _wgrad_codes(a):
         return []
     nchunks = (M + 31) // 32
     codes = []
-    for tile, cot in ((1, 2), (2, 4)):
+    for tile, cot in ((1, 2), (2, 4), (3, 4)):
         if cot == 4 and a.Cout < 128:
             continue
-        tiles = a.ksize * a.ksize * (Cin // 64) * ((a.Cout + 32 * cot - 1) // (32 * cot))
+        kt = 4 if tile == 3 else 2
+        if tile == 3 and (Cin % 128 or a.C0 % 128):
+            continue
+        tiles = a.ksize * a.ksize * (Cin // (32 * kt)) * ((a.Cout + 32 * cot - 1) // (32 * cot))
         for stages in (2, 1):
             for target in (256, 320, 384, 448, 512, 640, 768, 1024):
                 ms = max(1, min((target + tiles - 1) // tiles, nchunks // 2))

@@ -1236,3 +1236,36 @@ def test_gn_backward_large_maps(nat, N, P, C0, C1, film, act, adds, mode, monkey
     assert torch.equal(runs[0][0], runs[1][0]) and (dxb is None or torch.equal(runs[0][1], runs[1][1]))
     if mode != "atomics":
         assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,H,k", [(10, 128, 0, 128, 16, 3), (3, 128, 128, 256, 8, 3), (4, 256, 0, 128, 8, 1),
+                                              (2, 128, 0, 160, 12, 3)])
+def test_conv_wgrad_every_tune_code(nat, N, C0, C1, Cout, H, k):
+    """Every launch code the weight-gradient tuner may pick for a layer shape (_native._wgrad_codes: 64- / 128-filter tiles,
+    the 128 x 128 tile of code 3, two / three LDS-DMA stages, M slices) gives the same dW and db as torch autograd."""
+    import ctypes as C
+    Cin = C0 + C1
+    x = rnd("wgc/x", N, Cin, H, H)
+    w = (rnd("wgc/w", Cout, Cin, k, k, scale=0.05)).requires_grad_(True)
+    b = rnd("wgc/b", Cout).requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1 if k == 3 else 0)
+    dout = rnd("wgc/d", N, Cout, H, H)
+    y.backward(dout)
+    gp = torch.zeros(Cout, k * k, Cin, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    keep = dict(src0=cl(x[:, :C0]), res=cl(dout))
+    if C1:
+        keep["src1"] = cl(x[:, C0:])
+    a = nat.fill_conv_args(C0=C0, C1=C1, N=N, Hs=H, Ws=H, Ho=H, Wo=H, ksize=k, ldr=Cout, out=gp, bias=db, Cout=Cout, **keep)
+    codes = nat._wgrad_codes(a)
+    tiles = {(c - 1) & 3 for c in codes}
+    assert {1, 2, 3} <= tiles, tiles
+    scale = max(1.0, float(w.grad.abs().max()))
+    for code in [0] + codes:
+        a.tune = code
+        gp.zero_(); db.zero_()
+        nat.check(nat.lib().lfvdm_conv_wgrad(C.byref(a), nat.stream()), "lfvdm_conv_wgrad")
+        got_w = gp.view(Cout, k, k, Cin).permute(0, 3, 1, 2).cpu()
+        err = float((got_w - w.grad).abs().max())
+        assert err < 2e-5 * scale, f"tune code {code}: dW max|d| = {err:.3e}"
+        assert float((db.cpu() - b.grad).abs().max()) < 2e-5 * max(1.0, float(b.grad.abs().max())), f"tune code {code}: db"
