@@ -392,14 +392,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_coop_kernel(const lfvdm_conv_a
 // are COLUMN reads (32 consecutive floats of one row per half wave), conflict-free without padding or swizzle.
 // NS stages, chunk c+NS-1 in flight while chunk c is multiplied, one barrier per chunk: counted vmcnt (this
 // wave's pieces of the chunk have landed) + lgkmcnt(0) (its reads of the buffer that is restaged next have returned).
-template <int COT, int KT, int NS>
+// CR = rows of M per staged chunk (32 or 64: twice the MFMAs per barrier and per round of address arithmetic - what the
+// narrow tiles of the 16x16 / 8x8 latent levels are short of: 16 MFMAs per wave and chunk at COT = KT = 2, CR = 32).
+template <int COT, int KT, int NS, int CR = 32>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_args p_in, int msplit) {
     const lfvdm_conv_args p = p_in;
     constexpr int DLD = COT * 32, ALD = KT * 32;
     constexpr int DQ = COT * 8, AQ = KT * 8;          // float4 per tile row
-    constexpr int ND = COT, NA = KT;                  // pieces per thread per chunk
+    constexpr int ND = COT * CR / 32, NA = KT * CR / 32;   // pieces per thread per chunk
     constexpr int TC = COT / 2, TK = KT / 2;          // tiles per wave along co / k
-    constexpr int STAGE = 32 * DLD + 32 * ALD;        // floats
+    constexpr int STAGE = CR * DLD + CR * ALD;        // floats
     constexpr unsigned kOOB = 0x40000000u;            // >= num_records of both descriptors (checked by the launcher)
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float* bias_red = wsm + NS * STAGE;               // [8][COT * 32]
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
     const int NCG = (p.Cout + 32 * COT - 1) / (32 * COT);
     const int HoWo = p.Ho * p.Wo;
     const int M = p.N * HoWo;
-    const int nchunks = (M + 31) / 32;
+    const int nchunks = (M + CR - 1) / CR;
 
     const int task = blockIdx.x;                       // (k group, co group, m slice)
     const int t1 = qdiv(task, msplit);
@@ -456,10 +458,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
     const bool want_bias = kg == 0 && p.bias != nullptr;    // workgroup-uniform
 
     auto issue = [&](int c, int stage) {
-        const int m0 = c * 32;
+        const int m0 = c * CR;
         const bool live = c < c_end;
         float* Ds = wsm + stage * STAGE + wave * 256;          // this wave's first piece
-        float* As = wsm + stage * STAGE + 32 * DLD + wave * 256;
+        float* As = wsm + stage * STAGE + CR * DLD + wave * 256;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int m = m0 + drow0 + i * DRS;
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
         nxt = nxt >= NS ? nxt - NS : nxt;
         issue(c + NS - 1, nxt);
         const float* Dst = wsm + stage * STAGE;
-        const float* Ast = Dst + 32 * DLD;
+        const float* Ast = Dst + CR * DLD;
         if (want_bias) {        // column sums of this slice's dout rows (each thread re-reads the slots of its own pieces)
 #pragma unroll
             for (int i = 0; i < ND; ++i) bsum += ld4(Dst + (drow0 + i * DRS) * DLD + dcol);
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
         const float* dcolp = Dst + wc * TC * 32 + (lane & 31);
         const float* acolp = Ast + wk * TK * 32 + (lane & 31);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < CR / 8; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int mrow = 8 * g + 4 * (lane >> 5) + e;
@@ -558,6 +560,178 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const lfvdm_conv_ar
     }
 }
 
+// --------------------------------------------------------------------------------------------------------
+// Tap-fused form for 3x3 / stride 1 layers on raw operands: a workgroup owns a 64-filter x 64-channel tile of dW for
+// THREE taps (one filter row dy, NTY = 1) or all NINE (NTY = 3).  The kernels above stage, for every tap separately, the
+// dout tile and the operand tile shifted by that tap: 16 FLOP per staged byte, and on the cfg-C layers (M = 10240) the
+// 36 (tap, channel group, filter group) tiles of a 128 -> 128 layer pull 189 MB through L2 for 10 MB of tensors - L2 ->
+// LDS bandwidth, not MFMA issue, bounds them (52 TFLOP/s).  Here a chunk of 32 consecutive output pixels (R = 32 / WSEG
+// image rows of WSEG pixels; WSEG = 32 for maps at least 32 wide) is staged ONCE with its halo - dout [32][64] plus the
+// operand window [(R | R + 2) x (WSEG + 2) pixels][64] - and every tap reads its operand fragment from the window at a
+// compile-time offset: 2.8x (NTY = 1) / 5.5x (NTY = 3) fewer staged bytes per FLOP, 48 / 144 MFMAs per wave between
+// barriers instead of 16.  Price: 3 / 9 accumulator tiles per wave (48 / 144 VGPRs) and 3x / 9x the atomics per M slice,
+// which is why the tuner picks NTY per layer shape (NTY = 3: pixel-space maps, NTY = 1: the 16x16 / 8x8 latent levels).
+// LDS-DMA staging (zero fill outside the image / past M by out-of-range offsets), two stages, one barrier per chunk.
+template <int NTY, int WSEG>
+__global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(const lfvdm_conv_args p_in, int msplit) {
+    const lfvdm_conv_args p = p_in;
+    constexpr int R = 32 / WSEG;                       // image rows per chunk
+    constexpr int WC = WSEG + 2;                       // window columns (halo of one pixel either side)
+    constexpr int WR = NTY == 3 ? R + 2 : R;           // window rows
+    constexpr int WP = WR * WC;                        // window pixels
+    constexpr int NA = (WP + 15) / 16;                 // rounds of 16 pixels (4 waves x 4 pixels of 64 channels)
+    constexpr int ND = 2;                              // dout [32][64]: 16 rows per round
+    constexpr int NTAP = 3 * NTY;
+    constexpr int STAGE = 32 * 64 + NA * 16 * 64;      // floats
+    constexpr unsigned kOOB = 0x40000000u;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float* bias_red = wsm + 2 * STAGE;                 // [8][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave & 1, wk = wave >> 1;
+
+    const int Cin = p.C0 + p.C1;
+    const int cpg = Cin / 64;
+    const int NCG = (p.Cout + 63) / 64;
+    const int HoWo = p.Ho * p.Wo;
+    const int M = p.N * HoWo;
+    const int nchunks = M / 32;                        // (HoWo % 32 == 0: checked by the launcher)
+    const int segs = p.Wo / WSEG;                      // chunks per image row (1 when the map is narrower than 32)
+
+    const int task = blockIdx.x;                       // ((dy row, channel group), filter group, m slice)
+    const int t1 = qdiv(task, msplit);
+    const int ms = task - t1 * msplit;
+    const int kg = qdiv(t1, NCG);
+    const int cg = t1 - kg * NCG;
+    const int ty0 = NTY == 3 ? 0 : qdiv(kg, cpg);      // first filter row of this workgroup
+    const int cc = (kg - (NTY == 3 ? 0 : ty0 * cpg)) * 64;
+    const bool second = cc >= p.C0;
+    const float* src = selv(second, p.src1, p.src0);
+    const int Csrc = selv(second, p.C1, p.C0);
+    const int cl = second ? cc - p.C0 : cc;
+    int c_beg, c_end;
+    slice_of(nchunks, msplit, ms, c_beg, c_end);
+    const int co0 = cg * 64;
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)((unsigned)M * p.ldr * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)src, 0, (int)((unsigned)p.N * p.Hs * p.Ws * Csrc * 4u), 0x00020000);
+
+    const int q16 = (tid & 15) * 4;                    // channel / filter quad of this thread's pieces
+    const int prow = tid >> 4;                         // 0..15: dout row / window pixel inside a round
+    const unsigned dbase = (co0 + q16 < p.Cout) ? (unsigned)(co0 + q16) * 4u : kOOB;
+    const unsigned abase = (unsigned)(cl + q16) * 4u;
+    // window pixel -> (wy, wx) of this thread's NA pieces: compile-time divisor
+    int wy[NA], wx[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int w = prow + 16 * i;
+        wy[i] = w / WC;
+        wx[i] = w - wy[i] * WC;
+    }
+    const int dy_first = NTY == 3 ? -1 : ty0 - 1;      // image-row offset of window row 0
+    const float rHoWo = __builtin_amdgcn_rcpf((float)HoWo);
+
+    f32x16 acc[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bias = kg == 0 && p.bias != nullptr;    // workgroup-uniform
+
+    auto issue = [&](int c, int stage) {
+        const bool live = c < c_end;
+        const int m0 = c * 32;
+        // chunk -> (sample, first image row, first column): scalar arithmetic (c is wave-uniform)
+        const int n = fdiv(m0, HoWo, rHoWo);
+        const int rem = m0 - n * HoWo;
+        int oy0, ox0;
+        if (WSEG == 32) { const int rowi = qdiv(rem, p.Wo); oy0 = rowi; ox0 = rem - rowi * p.Wo; (void)segs; }
+        else { oy0 = rem / WSEG; ox0 = 0; }
+        float* Ds = wsm + stage * STAGE + wave * 256;
+        float* Ws = wsm + stage * STAGE + 32 * 64 + wave * 256;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int m = m0 + prow + 16 * i;
+            const unsigned off = live ? dbase + (unsigned)m * p.ldr * 4u : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(Ds + i * 1024), 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int iy = oy0 + wy[i] + dy_first, ix = ox0 + wx[i] - 1;
+            const bool inb = live && (prow + 16 * i < WP) && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+            const unsigned off = inb ? abase + (unsigned)((n * p.Hs + iy) * p.Ws + ix) * Csrc * 4u : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(Ws + i * 1024), 16, (int)off, 0, 0, 0);
+        }
+    };
+
+    issue(c_beg, 0);
+    int stage = 0;
+    const int h4 = 4 * (lane >> 5);
+    for (int c = c_beg; c < c_end; ++c) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(c + 1, stage ^ 1);
+        const float* Dst = wsm + stage * STAGE;
+        const float* Wst = Dst + 32 * 64;
+        if (want_bias) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) bsum += ld4(Dst + (prow + 16 * i) * 64 + q16);
+        }
+        // lane base: output pixel 8g + 4h + e of the chunk, h = lane >> 5.  WSEG is a multiple of 8, so (8g + 4h + e) and
+        // (8g + e) lie in the same image row: the h term is +4 window pixels; everything else is a compile-time offset
+        const float* dcolp = Dst + h4 * 64 + wc * 32 + (lane & 31);
+        const float* wcolp = Wst + h4 * 64 + wk * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 8 * g + e;                       // (compile-time after unrolling)
+                const int jr = j / WSEG, jc = j - jr * WSEG;
+                const float a = dcolp[j * 64];
+                float b[NTAP];
+#pragma unroll
+                for (int ty = 0; ty < NTY; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx) b[ty * 3 + tx] = wcolp[((jr + ty) * WC + jc + tx) * 64];
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+            }
+        stage ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero-filled look-ahead pieces
+    // ---- accumulate the partial tiles (float atomics, or slab row ms in deterministic mode)
+    const int Ktot = 9 * Cin;
+    float* dW = p.out;
+    const DetSlab dsW = {p.splitk_ws, p.out, (long)p.Cout * Ktot};
+    const DetSlab dsB = {p.splitk_ws ? p.splitk_ws + (size_t)msplit * dsW.n : nullptr, p.bias, (long)p.Cout};
+    const int ci = cc + wk * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        const int tap = (NTY == 3 ? 0 : ty0 * 3) + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < p.Cout) det_add(dsW, ms, dW + (size_t)co * Ktot + (size_t)tap * Cin + ci, acc[t][r]);
+        }
+    }
+    if (want_bias) {
+        __syncthreads();
+        float* br = bias_red + (prow & 7) * 64;
+        if (prow < 8) { br[q16 + 0] = bsum.x; br[q16 + 1] = bsum.y; br[q16 + 2] = bsum.z; br[q16 + 3] = bsum.w; }
+        __syncthreads();
+        if (prow >= 8) { br[q16 + 0] += bsum.x; br[q16 + 1] += bsum.y; br[q16 + 2] += bsum.z; br[q16 + 3] += bsum.w; }
+        __syncthreads();
+        if (tid < 64 && co0 + tid < p.Cout) {
+            float t = 0.f;
+            for (int r = 0; r < 8; ++r) t += bias_red[r * 64 + tid];
+            det_add(dsB, ms, const_cast<float*>(p.bias) + co0 + tid, t);
+        }
+    }
+}
+
 // raw operands whose tensors are addressable with 32-bit byte offsets below 2^30: LDS-DMA kernel
 static bool wgrad_dma_ok(const lfvdm_conv_args* a, long M) {
     const bool off = getenv("LFVDM_WGRAD_NO_DMA") != nullptr;             // A/B aid (read per launch: tests toggle it)
@@ -584,8 +758,9 @@ static int det_finish(const lfvdm_conv_args* a, long msplit, hipStream_t s) {
     return LFVDM_OK;
 }
 
-template <int COT, int KT, int NS>
-static int launch_wgrad_dma(const lfvdm_conv_args* a, hipStream_t s, int nchunks, long msplit_req) {
+template <int COT, int KT, int NS, int CR = 32>
+static int launch_wgrad_dma(const lfvdm_conv_args* a, hipStream_t s, int nchunks32, long msplit_req) {
+    const int nchunks = (nchunks32 * 32 + CR - 1) / CR;
     const int Cin = a->C0 + a->C1;
     const int NKG = a->ksize * a->ksize * (Cin / (32 * KT));
     const int NCG = (a->Cout + 32 * COT - 1) / (32 * COT);
@@ -594,11 +769,42 @@ static int launch_wgrad_dma(const lfvdm_conv_args* a, hipStream_t s, int nchunks
     long msplit = msplit_req > 0 ? msplit_req : (target + tiles - 1) / tiles;      // (tuned per layer shape, or 1.5 per CU)
     if (msplit > nchunks / 2) msplit = nchunks / 2;
     if (msplit < 1) msplit = 1;
-    constexpr size_t lds = (size_t)(NS * (32 * COT * 32 + 32 * KT * 32) + 8 * COT * 32) * sizeof(float);
+    constexpr size_t lds = (size_t)(NS * (CR * COT * 32 + CR * KT * 32) + 8 * COT * 32) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "stages must fit the CU's LDS");
     static DynLdsLimit limit;
-    if (int rc = limit.ensure(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT, KT, NS>), lds)) return rc;
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<COT, KT, NS, CR>), lds)) return rc;
     if (int rc = det_fit(a, msplit)) return rc;
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT, KT, NS>), dim3((unsigned)(tiles * msplit)), dim3(256), lds, s, *a, (int)msplit);
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<COT, KT, NS, CR>), dim3((unsigned)(tiles * msplit)), dim3(256), lds, s, *a, (int)msplit);
+    return det_finish(a, msplit, s);
+}
+
+// which map widths the tap-fused kernel is instantiated for (0: not eligible)
+static int wgrad_taps_wseg(const lfvdm_conv_args* a, long M) {
+    static const bool off = getenv("LFVDM_WGRAD_NO_TAPS") != nullptr;          // A/B aid
+    const int Cin = a->C0 + a->C1;
+    if (off || a->ksize != 3 || a->stride != 1 || a->up != 0 || a->coefA || a->act != LFVDM_ACT_NONE) return 0;
+    if (Cin % 64 || a->C0 % 64 || a->Cout < 64 || a->Hs != a->Ho || a->Ws != a->Wo || (a->Ho * a->Wo) % 32) return 0;
+    if (!wgrad_dma_ok(a, M)) return 0;
+    if (a->Wo % 32 == 0) return 32;
+    if (a->Wo == 16 || a->Wo == 8) return a->Wo;
+    return 0;
+}
+
+template <int NTY, int WSEG>
+static int launch_wgrad_taps(const lfvdm_conv_args* a, hipStream_t s, long M, long msplit_req) {
+    const int Cin = a->C0 + a->C1;
+    const int nchunks = (int)(M / 32);
+    const long tiles = (long)(NTY == 3 ? 1 : 3) * (Cin / 64) * ((a->Cout + 63) / 64);
+    long msplit = msplit_req > 0 ? msplit_req : (256 + tiles - 1) / tiles;
+    if (msplit > nchunks / 2) msplit = nchunks / 2;
+    if (msplit < 1) msplit = 1;
+    constexpr int WPv = (NTY == 3 ? 32 / WSEG + 2 : 32 / WSEG) * (WSEG + 2);
+    constexpr int NAv = (WPv + 15) / 16;
+    constexpr size_t lds = (size_t)(2 * (32 * 64 + NAv * 16 * 64) + 8 * 64) * sizeof(float);
+    static DynLdsLimit limit;
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<NTY, WSEG>), lds)) return rc;
+    if (int rc = det_fit(a, msplit)) return rc;
+    hipLaunchKernelGGL((conv_wgrad_taps_kernel<NTY, WSEG>), dim3((unsigned)(tiles * msplit)), dim3(256), lds, s, *a, (int)msplit);
     return det_finish(a, msplit, s);
 }
 
@@ -775,7 +981,9 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
         const bool big3 = a->ksize == 3 && M >= 2560;
         int cot = (a->Cout >= 128 && big3) ? 4 : a->Cout >= 64 ? 2 : 0;
         // tune code (lfvdm_conv_args::tune, measured per layer shape by the caller): 1 + tile + 4 * stages + 16 * M slices;
-        // tile 1 / 2 = 64 / 128 filters per workgroup, stages 1 / 2 = two / three LDS-DMA stages, 0 = this heuristic
+        // tile 1 / 2 / 3 = 64 x 64 / 128 x 64 / 128 x 128 (filters x channels) per workgroup, stages 1 / 2 / 3 = two / three
+        // LDS-DMA stages / two stages of 64-row chunks; stage field 0 with tile 1 / 2 = the tap-fused kernels (three / nine
+        // taps per workgroup) where the layer is eligible (wgrad_taps_wseg); tune 0 = this heuristic
         const int tcode = a->tune > 0 ? a->tune - 1 : 0;
         const int t_cot = tcode & 3, t_ns = (tcode >> 2) & 3;
         const long t_ms = tcode >> 4;
@@ -794,11 +1002,27 @@ extern "C" int lfvdm_conv_wgrad(const lfvdm_conv_args* a, void* stream) {
         }
         if (cot && kt && !getenv("LFVDM_WGRAD_WAVE")) {
             hipStream_t s = (hipStream_t)stream;
+            // tune codes with stage field 0: tile 1 = three taps (one filter row) per workgroup, tile 2 = all nine
+            const int wseg = (t_ns == 0 && (t_cot == 1 || t_cot == 2)) ? wgrad_taps_wseg(a, M) : 0;
+            if (wseg) {
+                int rc;
+                if (t_cot == 1) rc = wseg == 32 ? launch_wgrad_taps<1, 32>(a, s, M, t_ms) : wseg == 16 ? launch_wgrad_taps<1, 16>(a, s, M, t_ms)
+                                                                                                      : launch_wgrad_taps<1, 8>(a, s, M, t_ms);
+                else rc = wseg == 32 ? launch_wgrad_taps<3, 32>(a, s, M, t_ms) : wseg == 16 ? launch_wgrad_taps<3, 16>(a, s, M, t_ms)
+                                                                                            : launch_wgrad_taps<3, 8>(a, s, M, t_ms);
+                if (rc != LFVDM_OK) return rc;
+                LFVDM_CHECK_LAUNCH();
+                return LFVDM_OK;
+            }
             if (wgrad_dma_ok(a, M) && kt == 2) {
                 int ns = getenv("LFVDM_WGRAD_STAGES") ? atoi(getenv("LFVDM_WGRAD_STAGES")) : 3;
-                if (t_ns) ns = t_ns == 1 ? 2 : 3;
+                if (t_ns) ns = t_ns == 2 ? 3 : 2;
+                const bool rows64 = t_ns == 3 && nchunks >= 4;         // stage code 3: two stages of 64-row chunks
                 int rc;
-                if (wide_k) rc = ns == 2 ? launch_wgrad_dma<4, 4, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<4, 4, 3>(a, s, nchunks, t_ms);
+                if (rows64 && wide_k) rc = launch_wgrad_dma<4, 4, 2, 64>(a, s, nchunks, t_ms);
+                else if (rows64 && cot == 4) rc = launch_wgrad_dma<4, 2, 2, 64>(a, s, nchunks, t_ms);
+                else if (rows64) rc = launch_wgrad_dma<2, 2, 2, 64>(a, s, nchunks, t_ms);
+                else if (wide_k) rc = ns == 2 ? launch_wgrad_dma<4, 4, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<4, 4, 3>(a, s, nchunks, t_ms);
                 else if (cot == 4) rc = ns == 2 ? launch_wgrad_dma<4, 2, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<4, 2, 3>(a, s, nchunks, t_ms);
                 else rc = ns == 2 ? launch_wgrad_dma<2, 2, 2>(a, s, nchunks, t_ms) : launch_wgrad_dma<2, 2, 3>(a, s, nchunks, t_ms);
                 if (rc != LFVDM_OK) return rc;

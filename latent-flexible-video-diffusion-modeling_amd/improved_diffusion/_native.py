@@ -362,7 +362,8 @@ def det_workspace(device):
 
 
 def _wgrad_codes(a):
-    """Candidate launch codes of lfvdm_conv_wgrad for this layer shape (1 + tile + 4 * stages + 16 * M slices)."""
+    """Candidate launch codes of lfvdm_conv_wgrad for this layer shape (1 + tile + 4 * stages + 16 * M slices; tile 1 / 2 / 3 =
+    64 x 64 / 128 x 64 / 128 x 128 filters x channels, stages 1 / 2 / 3 = two / three stages / two stages of 64-row chunks)."""
     Cin, M = a.C0 + a.C1, a.N * a.Ho * a.Wo
     if Cin % 64 or a.C0 % 64 or a.Cout < 64 or a.coefA:
         return []
@@ -375,10 +376,21 @@ def _wgrad_codes(a):
         if tile == 3 and (Cin % 128 or a.C0 % 128):
             continue
         tiles = a.ksize * a.ksize * (Cin // (32 * kt)) * ((a.Cout + 32 * cot - 1) // (32 * cot))
-        for stages in (2, 1):
+        for stages in (2, 1, 3):          # 3 LDS-DMA stages, 2 stages, 2 stages of 64-row chunks
             for target in (256, 320, 384, 448, 512, 640, 768, 1024):
-                ms = max(1, min((target + tiles - 1) // tiles, nchunks // 2))
+                ms = max(1, min((target + tiles - 1) // tiles, (nchunks // 2 if stages == 3 else nchunks) // 2))
                 code = 1 + tile + 4 * stages + 16 * ms
+                if code not in codes:
+                    codes.append(code)
+    # tap-fused kernels (stage field 0): tile 1 = one filter row (three taps) per workgroup, tile 2 = all nine taps
+    HW = a.Ho * a.Wo
+    if (a.ksize == 3 and a.stride == 1 and a.up == 0 and HW % 32 == 0 and (a.Wo % 32 == 0 or a.Wo in (8, 16))
+            and a.Hs == a.Ho and a.Ws == a.Wo):
+        for tile, rows in ((1, 3), (2, 1)):
+            tiles = rows * (Cin // 64) * ((a.Cout + 63) // 64)
+            for target in (128, 192, 256, 320, 384, 512):
+                ms = max(1, min((target + tiles - 1) // tiles, (M // 32) // 2))
+                code = 1 + tile + 16 * ms
                 if code not in codes:
                     codes.append(code)
     return codes

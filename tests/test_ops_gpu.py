@@ -1239,10 +1239,12 @@ def test_gn_backward_large_maps(nat, N, P, C0, C1, film, act, adds, mode, monkey
 
 
 @pytest.mark.parametrize("N,C0,C1,Cout,H,k", [(10, 128, 0, 128, 16, 3), (3, 128, 128, 256, 8, 3), (4, 256, 0, 128, 8, 1),
-                                              (2, 128, 0, 160, 12, 3)])
+                                              (2, 128, 0, 160, 12, 3), (1, 64, 64, 96, 32, 3), (2, 128, 0, 128, 64, 3)])
 def test_conv_wgrad_every_tune_code(nat, N, C0, C1, Cout, H, k):
     """Every launch code the weight-gradient tuner may pick for a layer shape (_native._wgrad_codes: 64- / 128-filter tiles,
-    the 128 x 128 tile of code 3, two / three LDS-DMA stages, M slices) gives the same dW and db as torch autograd."""
+    the 128 x 128 tile of code 3, two / three LDS-DMA stages, 64-row chunks, M slices, and - 3x3 layers on maps of 8, 16 or a
+    multiple of 32 pixels per row - the tap-fused kernels with three / nine taps per workgroup) gives the same dW and db as
+    torch autograd; the tap-fused kernels also through the deterministic slabs, bitwise reproducibly."""
     import ctypes as C
     Cin = C0 + C1
     x = rnd("wgc/x", N, Cin, H, H)
@@ -1258,8 +1260,11 @@ def test_conv_wgrad_every_tune_code(nat, N, C0, C1, Cout, H, k):
         keep["src1"] = cl(x[:, C0:])
     a = nat.fill_conv_args(C0=C0, C1=C1, N=N, Hs=H, Ws=H, Ho=H, Wo=H, ksize=k, ldr=Cout, out=gp, bias=db, Cout=Cout, **keep)
     codes = nat._wgrad_codes(a)
-    tiles = {(c - 1) & 3 for c in codes}
-    assert {1, 2, 3} <= tiles, tiles
+    tiles = {(c - 1) & 3 for c in codes if ((c - 1) >> 2) & 3}
+    assert ({1, 2, 3} if Cin % 128 == 0 and C0 % 128 == 0 and Cout >= 128 else {1}) <= tiles, tiles
+    taps_codes = [c for c in codes if ((c - 1) >> 2) & 3 == 0]
+    eligible = k == 3 and (H * H) % 32 == 0 and (H % 32 == 0 or H in (8, 16))
+    assert bool(taps_codes) == eligible and (not eligible or {(c - 1) & 3 for c in taps_codes} == {1, 2})
     scale = max(1.0, float(w.grad.abs().max()))
     for code in [0] + codes:
         a.tune = code
@@ -1269,3 +1274,17 @@ def test_conv_wgrad_every_tune_code(nat, N, C0, C1, Cout, H, k):
         err = float((got_w - w.grad).abs().max())
         assert err < 2e-5 * scale, f"tune code {code}: dW max|d| = {err:.3e}"
         assert float((db.cpu() - b.grad).abs().max()) < 2e-5 * max(1.0, float(b.grad.abs().max())), f"tune code {code}: db"
+    # deterministic mode (partial tiles stored to slab rows, summed in slice order) for the tap-fused kernels
+    ws = torch.empty(64 << 20, device="cuda")
+    a.splitk_ws, a.splitk_ws_floats = ws.data_ptr(), ws.numel()
+    for code in taps_codes[:2] + taps_codes[-2:]:
+        a.tune = code
+        runs = []
+        for _ in range(2):
+            gp.zero_(); db.zero_()
+            nat.check(nat.lib().lfvdm_conv_wgrad(C.byref(a), nat.stream()), "lfvdm_conv_wgrad")
+            runs.append((gp.clone(), db.clone()))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), f"tune code {code}: not reproducible"
+        got_w = gp.view(Cout, k, k, Cin).permute(0, 3, 1, 2).cpu()
+        assert float((got_w - w.grad).abs().max()) < 2e-5 * scale, f"tune code {code} (deterministic)"
+        assert float((db.cpu() - b.grad).abs().max()) < 2e-5 * max(1.0, float(b.grad.abs().max())), f"tune code {code}: db (deterministic)"
