@@ -230,7 +230,7 @@ def train_step_flops(model, B, T, H, W):
     conv = sum(conv_flops(a[0]._obj) for fn, a in pl.steps if fn is L.lfvdm_conv_igemm)
     att = 0.0
     for fn, a in pl.steps:
-        if fn is L.lfvdm_attn_temporal or fn is L.lfvdm_attn_temporal_sel:
+        if fn is L.lfvdm_attn_temporal or fn is L.lfvdm_attn_temporal_sel or fn is L.lfvdm_attn_temporal_ring:
             Bv, Tv, P, C = a[7], a[8], a[9], a[10]
             att += 10.0 * Bv * P * Tv * Tv * C
         elif fn is L.lfvdm_attn_spatial:
@@ -689,19 +689,24 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def timed_sampling(sampler, steps, world, dev, min_seconds, start_i):
+def timed_sampling(sampler, steps, world, dev, min_seconds, n_t):
     """Regions of EXACTLY `steps` denoising steps, each bracketed by barrier + synchronize on both sides and reduced with
     MAX over the ranks; repeated until at least `min_seconds` have been timed (a 20-step region is 26 ms: too short to
-    quote a rate from).  -> (list of region times, next timestep)."""
-    i, times = start_i, []
+    quote a rate from).  Every region walks the chain from its top (t = n_t - 1 downwards, restarting if `steps` exceeds the
+    chain), so that the in-stream refills of the rolling R-table window are inside the timed region in the proportion a real
+    chain has them.  -> list of region times."""
+    times = []
     while True:
         th.cuda.synchronize()
         if world > 1:
             dist.barrier()
         th.cuda.synchronize()
         t0 = time.perf_counter()
-        sampler.run(i, steps)            # = `steps` x sampler.step, 8 steps per graph launch (GraphSampler.run)
-        i = max(i - steps, 0)
+        left = steps
+        while left > 0:
+            n = min(left, n_t)
+            sampler.run(n_t - 1, n)      # = n x sampler.step, 8 steps per graph launch (GraphSampler.run)
+            left -= n
         th.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -713,7 +718,7 @@ def timed_sampling(sampler, steps, world, dev, min_seconds, start_i):
             el = float(tt.item())
         times.append(el)
         if sum(times) >= min_seconds or len(times) >= 200:
-            return times, i
+            return times
 
 
 def main():
@@ -779,14 +784,18 @@ def main():
     k = int(getattr(sampler, "K", 1))
     sampler.run(i, k)                                        # captures the K-steps-per-launch graph outside the timed region
     i = max(i - k, 0)
-    times, i = timed_sampling(sampler, args.steps, world, dev, args.min_seconds, i)
+    times = timed_sampling(sampler, args.steps, world, dev, args.min_seconds, diffusion.num_timesteps)
     regions = len(times)
     # Work that the sampler does once per CHAIN instead of once per step (the R tables: everything that depends on the
     # timestep and this chain's frame indices, GraphSampler.begin) is charged to every timed step at 1/chain-length of
     # its cost.  What is done once per set of WEIGHTS (graph capture, launch tuning, the FiLM tables) is reported as
     # first_chain_setup_ms and, like capture and tuning, not charged.  The same chain through the PUBLIC API
     # (diffusion.p_sample_loop) is timed below and must reproduce `value` (public_api).
-    table_ms = float(getattr(sampler, "table_build_ms", 0.0))
+    # per-chain work outside the steps (GraphSampler.begin: index tables, the first block of the rolling R window) is
+    # charged to every timed step at 1/chain-length; the window's refills run in-stream inside the timed regions
+    sampler.begin(th.randn(*shape, device=dev), inputs)
+    table_ms = float(sampler.table_build_ms)
+    chain_table_ms = float(sampler.chain_table_ms())       # (for the record: every R block of a chain once)
     per_step_s = table_ms * 1e-3 / diffusion.num_timesteps
     el_steps = sum(times)
     el = el_steps + per_step_s * args.steps * regions
@@ -828,11 +837,14 @@ def main():
         "p_sample_loop_wall_ms": public_api["p_sample_loop_wall_ms"],
         "steps_per_s_public_api": public_api["steps_per_s_public_api"],
         "public_api": public_api,
-        "per_chain_setup": {"table_build_ms": round(table_ms, 3), "first_chain_table_build_ms": round(cold_setup_ms, 3),
+        "per_chain_setup": {"begin_table_build_ms": round(table_ms, 3), "table_build_ms": round(table_ms, 3), "first_chain_table_build_ms": round(cold_setup_ms, 3),
                             "chain_steps": diffusion.num_timesteps,
                             "charged_ms_per_step": round(1000.0 * per_step_s, 5),
                             "timestep_table_bytes": int(tables_info[0]), "fallback": tables_info[1],
-                            "note": "value and ms_per_step include this amortised share; timed_seconds is the raw replay time"},
+                            "r_table_ring_steps": int(getattr(sampler.plan, "time_ring", 0)),
+                            "r_table_build_ms_per_chain_in_stream": round(chain_table_ms, 3),
+                            "note": "value and ms_per_step include the amortised share of begin(); the rolling window's refills "
+                                    "(r_table_build_ms_per_chain_in_stream) run inside the timed regions; timed_seconds is the raw time"},
         "region_ms_per_step_min_max": [round(1000.0 * min(times) / args.steps, 4), round(1000.0 * max(times) / args.steps, 4)],
         "config": {"workload": "sample: p_sample loop, latent U-Net num_channels=64 num_res_blocks=1 max_frames=20 "
                                "batch=2 1000-step DDPM on synthetic 4x16x16 latents (BASELINE.json configs[1])",

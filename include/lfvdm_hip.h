@@ -454,6 +454,12 @@ int lfvdm_attn_temporal(const float* qkv, const float* Rq, const float* Rk, cons
 int lfvdm_attn_temporal_sel(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,
                             float* o, float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel,
                             void* stream);
+/* The same with the tables held as a ROLLING WINDOW of `ring` timesteps ([ring][B][T][T][C]): batch row b reads slice
+ * rsel[b] % ring (ring = 0: lfvdm_attn_temporal_sel).  The sampler refills half a ring at a time between graph launches
+ * (Plan.ensure_R): 1/8 of the whole-chain tables' memory at ring = 128 for a 1000-step chain, same values. */
+int lfvdm_attn_temporal_ring(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,
+                             float* o, float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel,
+                             int ring, void* stream);
 
 /* Backward of the temporal core: from qkv, d_o (gradient of the core output), the three R tensors and the mask
  * writes dqkv [M][3C] and dRq / dRk / dRv [B][T][T][C] (every element written, no atomics).

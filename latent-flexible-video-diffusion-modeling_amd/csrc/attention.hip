@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256)
 void attn_temporal_kernel(const float* __restrict__ qkv, const float* __restrict__ Rq, const float* __restrict__ Rk,
                           const float* __restrict__ Rv, const float* __restrict__ mask, float* __restrict__ o,
                           float* __restrict__ attn_out, int T, int P, int C, int heads, int PPW,
-                          const int64_t* __restrict__ rsel) {
+                          RSel rsel) {
     using ST = TAStage<TMAX, FC>;
     constexpr int NQ = ST::NQ, RB = ST::RB;
     extern __shared__ __attribute__((aligned(16))) float ta_smem[];
@@ -513,7 +513,7 @@ void attn_temporal_kernel(const float* __restrict__ qkv, const float* __restrict
     const size_t ld = (size_t)3 * C;
     const float* qrow = qkv + ((size_t)(b * T + t) * P + p) * ld + h * F;   // dereferenced only if active
     // rsel: the R tensors are tables over the sampler's timesteps ([n_t][B][T][T][C]); rsel[b] picks the slice
-    const size_t rb = rsel ? (size_t)rsel[b] * gridDim.z + b : (size_t)b;
+    const size_t rb = rsel.slice(b, (int)gridDim.z);
     const float* Rbase[3] = {Rk + rb * T * T * C + h * F, Rq + rb * T * T * C + h * F, Rv + rb * T * T * C + h * F};
 
     // per-thread staging slots: global offsets (without the chunk offset) and LDS offsets, computed once.
@@ -688,7 +688,7 @@ void attn_temporal_kernel(const float* __restrict__ qkv, const float* __restrict
 
 template <int TMAX, int FC>
 int launch_temporal(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
-                    float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
+                    float* attn_out, int B, int T, int P, int C, int heads, RSel rsel, hipStream_t s) {
     const int PPW = 64 / T;                                  // pixels per wave
     const int RST = T * FC + 4;
     const size_t lds = (size_t)(2 * T + 4 * PPW) * RST * sizeof(float);
@@ -704,7 +704,7 @@ int launch_temporal(const float* qkv, const float* Rq, const float* Rk, const fl
 
 template <int FC>
 int launch_temporal_t(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
-                      float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
+                      float* attn_out, int B, int T, int P, int C, int heads, RSel rsel, hipStream_t s) {
     if (T <= 8) return launch_temporal<8, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (T <= 16) return launch_temporal<16, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (T <= 24) return launch_temporal<24, FC>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
@@ -800,13 +800,14 @@ extern "C" int lfvdm_attn_spatial_bwd(const float* qkv, const float* o, const fl
 }
 
 int lfvdm_attn_temporal2_try(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
-                             float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s);
+                             float* attn_out, int B, int T, int P, int C, int heads, RSel rsel, hipStream_t s);
 
-extern "C" int lfvdm_attn_temporal_sel(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,
-                                       float* o, float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel,
-                                       void* stream) {
+extern "C" int lfvdm_attn_temporal_ring(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,
+                                        float* o, float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel_p,
+                                        int ring, void* stream) {
     if (B <= 0 || T <= 0 || T > TA_MAXT || P <= 0 || heads <= 0 || C % heads) return LFVDM_E_SHAPE;
-    if (!Rq || !Rk || !Rv) return LFVDM_E_SHAPE;
+    if (!Rq || !Rk || !Rv || ring < 0 || (ring > 0 && !rsel_p)) return LFVDM_E_SHAPE;
+    const RSel rsel = {rsel_p, ring};
     const int F = C / heads;
     hipStream_t s = (hipStream_t)stream;
     // second-generation kernel (attention_temporal2.hip) for head dims 16 / 32 / 64 and launches that do not fill the chip
@@ -824,6 +825,12 @@ extern "C" int lfvdm_attn_temporal_sel(const float* qkv, const float* Rq, const 
     if (F % 16 == 0 && T <= 24) return launch_temporal_t<16>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (F % 8 == 0) return launch_temporal_t<8>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     return LFVDM_E_UNSUPPORTED;
+}
+
+extern "C" int lfvdm_attn_temporal_sel(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,
+                                       float* o, float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel,
+                                       void* stream) {
+    return lfvdm_attn_temporal_ring(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, 0, stream);
 }
 
 extern "C" int lfvdm_attn_temporal(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask,

@@ -59,7 +59,7 @@ __device__ __forceinline__ void t2_decode(const T2Geom& g, int& b, int& h, int& 
 // LDS images of a workgroup, in slots of 4 floats: R[tq][3][RS] (R_k | R_q transposed | R_v) at Rimg, KV[pixel][2][RS] at KVimg
 template <int F, int TCAP>
 __device__ __forceinline__ void t2_stage(const float* __restrict__ qkv, const float* __restrict__ Rq, const float* __restrict__ Rk,
-                                         const float* __restrict__ Rv, const int64_t* __restrict__ rsel, const T2Geom& g, int b, int h,
+                                         const float* __restrict__ Rv, RSel rsel, const T2Geom& g, int b, int h,
                                          int tq0, int p0, int wave, int lane, float* Rimg, float* KVimg) {
     using CF = T2Cfg<F, TCAP>;
     constexpr int NQ = CF::NQ, RS = CF::RS;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void t2_stage(const float* __restrict__ qkv, const fl
     // of LDS): pieces of 64 slots, dealt round-robin to the waves.  Slots nobody reads (row padding, frames past T,
     // pixels past P) are filled from a valid dummy address.
     {
-        const size_t rb = rsel ? (size_t)rsel[b] * g.B + b : (size_t)b;
+        const size_t rb = rsel.slice(b, g.B);
         const float* Rsrc[3] = {Rk + rb * T * T * C + h * F, Rq + rb * T * T * C + h * F, Rv + rb * T * T * C + h * F};
         const float* kvsrc = qkv + (size_t)b * T * P * 3 * C + C + h * F;     // k of (b, frame 0, pixel 0); v is C further
         const int vpx = min(NPX, P - p0);                              // pixel rows that exist
@@ -113,7 +113,7 @@ template <int F, int TCAP>
 __global__ __launch_bounds__(256, 3)          // three waves per SIMD (<= 168 VGPRs): the waves hide each other's LDS latency
 void attn_temporal2_kernel(const float* __restrict__ qkv, const float* __restrict__ Rq, const float* __restrict__ Rk,
                            const float* __restrict__ Rv, const float* __restrict__ mask, float* __restrict__ o,
-                           float* __restrict__ attn_out, const int64_t* __restrict__ rsel, T2Geom g) {
+                           float* __restrict__ attn_out, RSel rsel, T2Geom g) {
     using CF = T2Cfg<F, TCAP>;
     constexpr int NQ = CF::NQ, RS = CF::RS;
     extern __shared__ __attribute__((aligned(16))) float t2_smem[];
@@ -302,7 +302,7 @@ void attn_temporal2_bwd_rows_kernel(const float* __restrict__ qkv, const float* 
     const int p0 = strip * NPX;
     float* Rimg = t2_smem;
     float* KVimg = t2_smem + (size_t)((g.TGN * 3 * RS + 63) & ~63) * 4;
-    t2_stage<F, TCAP>(qkv, Rq, Rk, Rv, nullptr, g, b, h, tq0, p0, wave, lane, Rimg, KVimg);
+    t2_stage<F, TCAP>(qkv, Rq, Rk, Rv, RSel{nullptr, 0}, g, b, h, tq0, p0, wave, lane, Rimg, KVimg);
 
     const float invN = 1.0f / (float)g.TGN;
     const int sq = lane & 3, pair = lane >> 2;
@@ -507,7 +507,7 @@ inline bool t2_geometry(int B, int T, int P, int C, int heads, int F, int RS, T2
 
 template <int F, int TCAP>
 int launch_t2(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o, float* attn_out,
-              int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
+              int B, int T, int P, int C, int heads, RSel rsel, hipStream_t s) {
     T2Geom g;
     size_t lds;
     unsigned grid;
@@ -547,7 +547,7 @@ int launch_t2_bwd_rows_f(const float* qkv, const float* dO, const float* Rq, con
 
 template <int F>
 int launch_t2_f(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
-                float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
+                float* attn_out, int B, int T, int P, int C, int heads, RSel rsel, hipStream_t s) {
     if (T <= 8) return launch_t2<F, 8>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (T <= 16) return launch_t2<F, 16>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
     if (T <= 20) return launch_t2<F, 20>(qkv, Rq, Rk, Rv, mask, o, attn_out, B, T, P, C, heads, rsel, s);
@@ -559,7 +559,7 @@ int launch_t2_f(const float* qkv, const float* Rq, const float* Rk, const float*
 
 // Internal entry (attention.hip dispatches here first): LFVDM_E_UNSUPPORTED = shape not covered, use the first kernel.
 int lfvdm_attn_temporal2_try(const float* qkv, const float* Rq, const float* Rk, const float* Rv, const float* mask, float* o,
-                             float* attn_out, int B, int T, int P, int C, int heads, const int64_t* rsel, hipStream_t s) {
+                             float* attn_out, int B, int T, int P, int C, int heads, RSel rsel, hipStream_t s) {
     const int F = C / heads;
     // Large launches (e.g. 16x16 maps at 128 channels, batch 2: 25.9 us vs 30) keep every CU busy in the first kernel
     // too, which stages each R slice once per 12 pixels instead of once per 12 pixels AND frame group: use it there.

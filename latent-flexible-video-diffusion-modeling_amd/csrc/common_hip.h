@@ -84,6 +84,19 @@ __device__ __forceinline__ float wave_max(float v) {
 // normally combined with float atomics, whose order - hence the rounding - changes from run to run.  With a slab the
 // partials go to slab[part][n] by plain stores (each (part, element) at most once; the slab is zero-filled first
 // where a part does not cover every element) and ONE launch adds the parts in index order: dst[i] += sum_p slab[p][i].
+// Row selector of the temporal attention's R tables (sampler plans): slice index of batch row b =
+// (ring ? p[b] % ring : p[b]); p == nullptr: no tables, slice b.  `ring` > 0: the tables hold a rolling window of `ring`
+// timesteps, timestep t in slot t % ring (Plan.build_R_tables refills the window every `ring` steps).
+struct RSel {
+    const int64_t* p;
+    int ring;
+    __host__ __device__ size_t slice(int b, int B) const {
+        if (!p) return (size_t)b;
+        const long t = (long)p[b];
+        return (size_t)(ring ? t % ring : t) * B + b;
+    }
+};
+
 struct DetSlab {
     float* slab;           // nullptr: float atomics
     const float* base;     // first element of the destination array

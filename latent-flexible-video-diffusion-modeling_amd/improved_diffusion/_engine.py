@@ -294,9 +294,20 @@ class Plan:
         self.t_sel = None
         self.time_table_bytes = 0
         self.time_table_fallback = None          # why the plan runs the per-step embedding / RPE launches instead
+        # The R tables ([timestep][B][T][T][C] per RPE network: 6.3 GiB for the 1000 steps of the headline chain, linear in
+        # batch and chain length) are kept as a ROLLING WINDOW of `time_ring` timesteps (LFVDM_TIME_RING, default 128; 0 =
+        # the whole chain): timestep t lives in slot t % ring, the window is refilled half a ring at a time by the same
+        # grouped RPE launch (ensure_R, called by the sampler between graph launches) - same total work per chain, same
+        # values bit for bit, an eighth of the memory: batch 8 and the pixel-space plan fit the default budget.  The FiLM /
+        # time-projection rows of all timesteps (rows_all, 80 MB) stay whole.
+        self.time_ring = 0
         if self.time_steps:
+            ring = int(os.environ.get("LFVDM_TIME_RING", "128")) // 16 * 16      # two halves, each a multiple of 8 steps
+            if 0 < ring < self.time_steps:
+                self.time_ring = ring
             Bv = self.time_steps * B
-            table_bytes = 4 * Bv * (self.rows_ld + T * T * sum(r.rpe_net.channels for r in rpe_mods))
+            table_bytes = 4 * B * (self.time_steps * self.rows_ld +
+                                   (self.time_ring or self.time_steps) * T * T * sum(r.rpe_net.channels for r in rpe_mods))
             if os.environ.get("LFVDM_TIME_TABLES", "1") == "0":
                 self.time_table_fallback = "disabled (LFVDM_TIME_TABLES=0)"
             elif B > 64:
@@ -318,8 +329,11 @@ class Plan:
             self.t_sel = self.buf(B, dtype=th.int64).zero_()          # the sampler's device-side step counter
             self.rows_all = self.buf(Bv, self.rows_ld)
             for r in rpe_mods:
-                self.R[r] = self.buf(Bv, T, T, r.rpe_net.channels)     # [n_t][B][T][T][C]
+                self.R[r] = self.buf((self.time_ring or self.time_steps) * B, T, T, r.rpe_net.channels)   # [slot][B][T][T][C]
             self.tables_sig = None
+            self._fill_jobs = {}       # (t0, t1, slot0) -> job table of that refill (pointers only: reused by every chain)
+            self._loaded = {}          # ring half -> block of timesteps it holds
+            self._fi_rep = None
         else:
             (j0, j1, jg), n_g, rows_g = emb_jobs(B, self.tin, self.Bpad, e0, self.emb, self.rows)
             self.keep += [j0, j1, jg]
@@ -463,8 +477,9 @@ class Plan:
             at = self.buf(B * P, heads, T, T)
             self.attn_t.append(at)
         if self.time_steps:     # R tensors are tables over the chain's timesteps: slice t_sel[b]
-            self.add(L.lfvdm_attn_temporal_sel, _p(self.s_qkv), _p(self.R[ta.rpe_q]), _p(self.R[ta.rpe_k]), _p(self.R[ta.rpe_v]),
-                     _p(self.mask), _p(self.s_o), _p(at) if at is not None else None, B, T, P, Cc, heads, _p(self.t_sel))
+            self.add(L.lfvdm_attn_temporal_ring, _p(self.s_qkv), _p(self.R[ta.rpe_q]), _p(self.R[ta.rpe_k]), _p(self.R[ta.rpe_v]),
+                     _p(self.mask), _p(self.s_o), _p(at) if at is not None else None, B, T, P, Cc, heads, _p(self.t_sel),
+                     self.time_ring)
         else:
             self.add(L.lfvdm_attn_temporal, _p(self.s_qkv), _p(self.R[ta.rpe_q]), _p(self.R[ta.rpe_k]), _p(self.R[ta.rpe_v]),
                      _p(self.mask), _p(self.s_o), _p(at) if at is not None else None, B, T, P, Cc, heads)
@@ -538,18 +553,62 @@ class Plan:
         self.tables_sig = (self.time_signature(), tuple(ts_table.tolist()))       # (compared by GraphSampler.begin)
 
     def build_R_tables(self, frame_indices):
-        """R_q / R_k / R_v of every temporal attention for every timestep of the chain (they depend on the timestep and
-        on this window's frame indices): the grouped RPE launch on the virtual batch."""
+        """Per chain: R_q / R_k / R_v of every temporal attention depend on the timestep and on THIS window's frame indices.
+        Whole-chain tables (time_ring == 0): one grouped RPE launch on the virtual batch of n_t * B rows.  Rolling window:
+        only remember the indices; ``ensure_R`` fills the halves of the ring as the chain reaches them."""
         if not self.R:
             return
         n_t, B, T = self.time_steps, self.B, self.T
-        fi = frame_indices.to(self.dev, th.int64).reshape(B, T).repeat(n_t, 1).contiguous()
-        jr, n_r, tiles_r = self._rpe_jobs(n_t * B, self.rows_all, self.R)
-        nat.check(nat.lib().lfvdm_rpe_nets_maxc(_p(jr), n_r, tiles_r, _p(fi), n_t * B, T, max(r.rpe_net.channels for r in self.R),
-                                                nat.stream()), "lfvdm_rpe_nets")
-        # no host synchronisation: the job table and the index tensor were allocated on this stream and are released to the
-        # caching allocator in stream order, so the launch above is done with them before anything can reuse the memory -
-        # and a windowed sampler (97 chains per video) keeps the host ahead of the device across windows
+        steps = (self.time_ring // 2) if self.time_ring else n_t
+        self._fi_rep = frame_indices.to(self.dev, th.int64).reshape(B, T).repeat(steps, 1).contiguous()
+        self._loaded = {}
+        if not self.time_ring:
+            self._fill_R(0, n_t, 0)
+        # no host synchronisation: the index tensor is released to the caching allocator in stream order, and a windowed
+        # sampler (97 chains per video) keeps the host ahead of the device across windows
+
+    def _fill_R(self, t0, t1, slot0):
+        """R rows of the timesteps [t0, t1) -> slots [slot0, slot0 + t1 - t0): the grouped RPE launch of the per-step plan
+        on the virtual batch of (t1 - t0) * B rows (bitwise the per-step values: every output row depends on its own
+        input row only)."""
+        B, T = self.B, self.T
+        key = (t0, t1, slot0)
+        ent = self._fill_jobs.get(key)
+        if ent is None:
+            views = {r: buf[slot0 * B:] for r, buf in self.R.items()}
+            ent = self._rpe_jobs((t1 - t0) * B, self.rows_all[t0 * B:], views)
+            self._fill_jobs[key] = ent
+        jr, n_r, tiles_r = ent
+        nat.check(nat.lib().lfvdm_rpe_nets_maxc(_p(jr), n_r, tiles_r, _p(self._fi_rep), (t1 - t0) * B, T,
+                                                max(r.rpe_net.channels for r in self.R), nat.stream()), "lfvdm_rpe_nets")
+
+    def ensure_R(self, t_hi, t_lo=None):
+        """Rolling window: make the R rows of the timesteps t_lo..t_hi resident (at most half a ring apart: the sampler
+        calls this before every graph launch with the timesteps that launch walks).  Half h of the ring holds the block of
+        ring / 2 timesteps blk with blk % 2 == h; a refill is one launch, stream-ordered behind the steps that read the
+        half's previous content."""
+        if not self.time_ring or not self.R:
+            return
+        H = self.time_ring // 2
+        t_hi = min(max(int(t_hi), 0), self.time_steps - 1)
+        t_lo = t_hi if t_lo is None else min(max(int(t_lo), 0), t_hi)
+        assert t_hi - t_lo < H, "a graph launch walks less than half a ring of timesteps"
+        for blk in {t_hi // H, t_lo // H}:
+            if self._loaded.get(blk % 2) != blk:
+                self._fill_R(blk * H, min((blk + 1) * H, self.time_steps), (blk % 2) * H)
+                self._loaded[blk % 2] = blk
+
+    def fill_whole_chain(self):
+        """Every R block of a chain once (what a chain costs in table building; bench.py charges it per step)."""
+        if not self.R:
+            return
+        if not self.time_ring:
+            self._fill_R(0, self.time_steps, 0)
+            return
+        H = self.time_ring // 2
+        for blk in range((self.time_steps + H - 1) // H):
+            self._fill_R(blk * H, min((blk + 1) * H, self.time_steps), (blk % 2) * H)
+        self._loaded = {}
 
     def fuse_head_update(self, t_buf, tables, clip, seed, noise, pred, inject_noise):
         """Sampler only (its plan is private): replace the last launch - the output convolution - by

@@ -144,6 +144,7 @@ _SIGS = {
     "lfvdm_sampler_tick": ([c_fp, c_fp, c_fp, c_i, c_fp], c_i),
     "lfvdm_sampler_tick_fetch": ([c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp], c_i),
     "lfvdm_attn_temporal_sel": ([c_fp] * 7 + [c_i] * 5 + [c_fp, c_fp], c_i),
+    "lfvdm_attn_temporal_ring": ([c_fp] * 7 + [c_i] * 5 + [c_fp, c_i, c_fp], c_i),
     "lfvdm_attn_temporal_bwd": ([c_fp] * 12 + [c_i] * 5 + [c_fp], c_i),
     "lfvdm_attn_spatial_bwd": ([c_fp] * 6 + [c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_attn_temporal": ([c_fp] * 7 + [c_i] * 5 + [c_fp], c_i),

@@ -550,6 +550,7 @@ class GraphSampler:
                 if pl.tables_sig != (pl.time_signature(), self._ts_key):
                     pl.build_time_tables(self.ts_table)          # once per set of weights
                 pl.build_R_tables(model_kwargs["frame_indices"])  # once per chain: R depends on this window's frames
+                pl.ensure_R(self.diffusion.num_timesteps - 1)    # (rolling window: the block the chain starts in)
                 e1.record()
                 self._table_events = (e0, e1)        # read lazily (table_build_ms): no host stall between windows / chains
                 self.t_buf.fill_(self.diffusion.num_timesteps)
@@ -584,9 +585,27 @@ class GraphSampler:
             self.seed.random_()                                 # this chain's noise key (torch's generator: seedable)
         self.expected_t = self.diffusion.num_timesteps - 1
 
+    def chain_table_ms(self):
+        """GPU milliseconds of ALL table building of one chain of this sampler (every R block once; the FiLM rows are per
+        set of weights and not included): with the rolling window the refills ride between the graph launches of ``run``,
+        this measures them on their own (synchronises)."""
+        pl = self.plan
+        if not pl.time_steps:
+            return 0.0
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        th.cuda.synchronize()
+        e0.record()
+        pl.fill_whole_chain()
+        e1.record()
+        e1.synchronize()
+        if self.expected_t is not None:
+            pl.ensure_R(self.expected_t)
+        return e0.elapsed_time(e1)
+
     def step(self, i):
         if i != self.expected_t:  # arbitrary order requested: reset the device-side counter
             self.t_buf.fill_(i + 1)
+        self.plan.ensure_R(i)
         self.graph.replay()
         self.expected_t = max(i - 1, 0)
         return {"sample": self.plan.x_in, "pred_xstart": self.pred, "attn": None}
@@ -598,7 +617,7 @@ class GraphSampler:
             raise ValueError("inject_noise: the caller provides the noise of every step - use step()")
         if i != self.expected_t:
             self.t_buf.fill_(i + 1)
-        left = int(n)
+        left, t = int(n), int(i)
         if self.K > 1 and left >= self.K:
             if self.graph_k is None:
                 g = th.cuda.CUDAGraph()
@@ -608,11 +627,15 @@ class GraphSampler:
                         self._step_body()
                 self.graph_k = g
             while left >= self.K:
+                self.plan.ensure_R(t, t - self.K + 1)      # rolling R window: the timesteps this launch walks
                 self.graph_k.replay()
                 left -= self.K
+                t = max(t - self.K, 0)
         for _ in range(left):
+            self.plan.ensure_R(t)
             self.graph.replay()
-        self.expected_t = max(i - int(n), 0)
+            t = max(t - 1, 0)
+        self.expected_t = max(int(i) - int(n), 0)
         return {"sample": self.plan.x_in, "pred_xstart": self.pred, "attn": None}
 
 

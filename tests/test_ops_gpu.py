@@ -395,6 +395,13 @@ def test_attn_temporal_second_generation_kernel(nat, B, T, P, Cc, heads):
     picked = [torch.stack([(0.5 + 0.25 * int(sel[b])) * r[b] for b in range(B)]) for r in Rs]
     ref3 = _temporal_core_f64(qkv.double(), picked[0].double(), picked[1].double(), picked[2].double(), mask.double(), B, T, P, Cc, heads)
     close(o3, ref3.float(), 5e-5)
+    # the same tables as a rolling window of `ring` = 3 timesteps: timestep t lives in slot t % 3 (lfvdm_attn_temporal_ring)
+    big = torch.tensor([int(sel[b]) + 3 * (7 + b) for b in range(B)], dtype=torch.int64, device="cuda")
+    o4 = torch.full((M, Cc), float("nan"), device="cuda")
+    nat.check(nat.lib().lfvdm_attn_temporal_ring(g[0].data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(),
+                                                 g[4].data_ptr(), o4.data_ptr(), None, B, T, P, Cc, heads, big.data_ptr(), n_t,
+                                                 nat.stream()), "lfvdm_attn_temporal_ring")
+    assert torch.equal(o4, o3)
 
 
 def test_spatial_attention_block(nat):

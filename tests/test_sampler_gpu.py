@@ -330,3 +330,39 @@ def test_replayed_long_video_window_follows_the_reference_trajectory(K):
             err = float((out.cpu() - torch.from_numpy(g[f"w{K}_{leg}"][j])).abs().max())
             print(f"[cfgD window K={K}] {leg} step {j} (i={i}): max|d| vs reference trajectory {err:.2e}")
             assert err < 2e-4 * (j + 1), (leg, j, err)
+
+
+def test_rolling_R_window_is_bitwise_the_whole_chain_tables(monkeypatch):
+    """The R tables as a rolling window of `ring` timesteps (LFVDM_TIME_RING; slot t % ring, refilled half a ring at a time
+    between graph launches) against whole-chain tables (LFVDM_TIME_RING=0): a 100-step chain through the public loop (8-step
+    graph launches that straddle the half-ring boundaries: 100 is not a multiple of 16), single steps in arbitrary order,
+    and a window's memory must be the ring's share of the chain's."""
+    cfg, sd, inp = load_case("micro")
+    d = {k: v.cuda() for k, v in inp.items()}
+    mk = dict(frame_indices=d["frame_indices"], obs_mask=d["obs_mask"], latent_mask=d["latent_mask"], x0=d["x0"])
+    shape = tuple(inp["x"].shape)
+    outs = {}
+    for ring in ("0", "16", "48"):
+        monkeypatch.setenv("LFVDM_TIME_RING", ring)
+        monkeypatch.setenv("LFVDM_AUTOTUNE", "0")
+        model = build_native(cfg, sd)
+        diff = make_diffusion(1000, "100")
+        torch.manual_seed(11)
+        a, _ = diff.p_sample_loop(model, shape, clip_denoised=True, model_kwargs=mk, return_decoded=False)
+        s = diff._graph_sampler(model, shape, True)
+        assert s.plan.time_steps == 100 and s.plan.time_ring == int(ring)
+        s.begin(d["x"].clone(), mk)
+        s.seed.fill_(99)
+        singles = []
+        for i in (99, 98, 50, 7, 8, 63, 64, 0):          # arbitrary order: every access must find its block resident
+            singles.append(s.step(i)["sample"].clone())
+        s.begin(d["x"].clone(), mk)
+        s.seed.fill_(99)
+        r = s.run(99, 37)["sample"].clone()               # 4 launches of 8 + 5 single steps, across block boundaries
+        outs[ring] = (a, singles, r, s.plan.time_table_bytes, s.chain_table_ms())
+    for ring in ("16", "48"):
+        assert torch.equal(outs[ring][0], outs["0"][0]), ring
+        assert all(torch.equal(x, y) for x, y in zip(outs[ring][1], outs["0"][1])), ring
+        assert torch.equal(outs[ring][2], outs["0"][2]), ring
+        assert outs[ring][4] > 0
+    assert outs["16"][3] < 0.4 * outs["0"][3], (outs["16"][3], outs["0"][3])
