@@ -277,6 +277,12 @@ int lfvdm_gn_bwd_fused(const float* da, const float* src0, const float* src1, in
                        const float* gamma, const float* beta, const float* film, int film_ld, int T, float* dgamma,
                        float* dbeta, float* dfilm, int dfilm_ld, const float* add, int add_ld, const float* add2,
                        int add2_ld, void* stream);
+/* lfvdm_gn_bwd_fused for the deterministic mode: the same ONE launch (statistics + dx, add / add2 folded in), but the
+ * per-(sample, channel) sums are STORED to sums[N][C][2] (each pair by exactly one workgroup) instead of being added to the
+ * parameter gradients with float atomics; lfvdm_gn_param_grads then reduces them in sample order. */
+int lfvdm_gn_bwd_fused_sums(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                            const float* coefA, const float* coefB, const float* stats, int act, float* out0, float* out1,
+                            const float* add, int add_ld, const float* add2, int add2_ld, float* sums, void* stream);
 /* Large-map form of the GroupNorm backward (what lfvdm_gn_apply_ws is to the forward; reference nn.py:17-19 through
  * unet.py:194-207,399-403 at pixel-space map sizes): a workgroup owns a chunk of positions of a (sample, 8 groups) slice,
  * chunk sums -> fixed-order combination in every consumer workgroup -> dx: two launches of thousands of workgroups instead

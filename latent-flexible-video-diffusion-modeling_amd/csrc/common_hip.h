@@ -108,3 +108,4 @@ __device__ __forceinline__ void det_add(const DetSlab& d, long part, float* dst,
 }
 // dst[i] += slab[0][i] + slab[1][i] + ... (fixed order), i < n  (det_reduce.hip)
 int lfvdm_det_reduce_launch(float* dst, const float* slab, long n, long parts, hipStream_t s);
+int lfvdm_det_reduce2_launch(float* d0, const float* s0, long n0, float* d1, const float* s1, long n1, long parts, hipStream_t s);

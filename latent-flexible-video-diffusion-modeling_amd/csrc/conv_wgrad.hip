@@ -753,9 +753,10 @@ static int det_finish(const lfvdm_conv_args* a, long msplit, hipStream_t s) {
     if (!a->splitk_ws) return LFVDM_OK;
     if (hipGetLastError() != hipSuccess) return LFVDM_E_LAUNCH;
     const long n = (long)a->Cout * a->ksize * a->ksize * (a->C0 + a->C1);
-    if (int rc = lfvdm_det_reduce_launch(a->out, a->splitk_ws, n, msplit, s)) return rc;
-    if (a->bias) return lfvdm_det_reduce_launch(const_cast<float*>(a->bias), a->splitk_ws + (size_t)msplit * n, a->Cout, msplit, s);
-    return LFVDM_OK;
+    if (a->bias)        // weight and bias gradient in one launch
+        return lfvdm_det_reduce2_launch(a->out, a->splitk_ws, n, const_cast<float*>(a->bias), a->splitk_ws + (size_t)msplit * n,
+                                        a->Cout, msplit, s);
+    return lfvdm_det_reduce_launch(a->out, a->splitk_ws, n, msplit, s);
 }
 
 template <int COT, int KT, int NS, int CR = 32>

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_apply_kernel(
 __global__ __launch_bounds__(GB_THREADS) void gn_bwd_fused_kernel(
     const float* __restrict__ da, const float* __restrict__ s0, const float* __restrict__ s1p, int C0, int C1, int P,
     const float* __restrict__ coefA, const float* __restrict__ coefB, const float* __restrict__ stats, int act,
-    float* __restrict__ out0, float* __restrict__ out1, GnParamGradArgs pg) {
+    float* __restrict__ out0, float* __restrict__ out1, GnParamGradArgs pg, float* __restrict__ sums_out) {
     const int C = C0 + C1;
     const int cg = C / 32;
     const float rcg = __builtin_amdgcn_rcpf((float)cg);
@@ -235,6 +235,11 @@ __global__ __launch_bounds__(GB_THREADS) void gn_bwd_fused_kernel(
         chS[0][cc] = t1;
         chS[1][cc] = t2;
         const int ch = cbase + cc;
+        if (sums_out != nullptr) {      // deterministic mode: every (sample, channel) pair is written by exactly one
+            sums_out[((size_t)n * C + ch) * 2 + 0] = t1;      // workgroup; lfvdm_gn_param_grads adds them in sample order
+            sums_out[((size_t)n * C + ch) * 2 + 1] = t2;
+            continue;
+        }
         float sc1 = 1.0f;
         if (pg.film != nullptr) {
             const int b = n / pg.T;
@@ -858,7 +863,23 @@ extern "C" int lfvdm_gn_bwd_fused(const float* da, const float* src0, const floa
     if (film && (!gamma || !beta || !dfilm || T <= 0 || N % T || film_ld < 2 * C || dfilm_ld < 2 * C)) return LFVDM_E_SHAPE;
     const GnParamGradArgs pg = {gamma, beta, film, dgamma, dbeta, dfilm, film_ld, dfilm_ld, T > 0 ? T : 1, add, add_ld, add2, add2_ld};
     hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
-                       C0, C1, P, coefA, coefB, stats, act, out0, out1, pg);
+                       C0, C1, P, coefA, coefB, stats, act, out0, out1, pg, (float*)nullptr);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_bwd_fused_sums(const float* da, const float* src0, const float* src1, int C0, int C1, int N, int P,
+                                       const float* coefA, const float* coefB, const float* stats, int act, float* out0,
+                                       float* out1, const float* add, int add_ld, const float* add2, int add2_ld, float* sums,
+                                       void* stream) {
+    const int C = C0 + C1;
+    if (N <= 0 || P <= 0 || C <= 0 || C % 32 || C0 % 4 || C > 1024 || !sums) return LFVDM_E_SHAPE;
+    if (C1 > 0 && (!src1 || !out1)) return LFVDM_E_SHAPE;
+    if (add && (add_ld < C || add_ld % 4)) return LFVDM_E_SHAPE;
+    if (add2 && (add2_ld < C || add2_ld % 4)) return LFVDM_E_SHAPE;
+    const GnParamGradArgs pg = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, add, add_ld, add2, add2_ld};
+    hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(N, 32 / GB_GPW), dim3(GB_THREADS), 0, (hipStream_t)stream, da, src0, src1,
+                       C0, C1, P, coefA, coefB, stats, act, out0, out1, pg, sums);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }
@@ -928,8 +949,7 @@ static int gn_temporal_bwd_impl(const float* x, const float* dy, const float* ga
                            accumulate, det_ws);
     LFVDM_CHECK_LAUNCH();
     if (det_ws) {       // ordered sum of the workgroups' partial parameter gradients
-        if (int rc = lfvdm_det_reduce_launch(dgamma, det_ws, C, nwg, s)) return rc;
-        return lfvdm_det_reduce_launch(dbeta, det_ws + (size_t)nwg * C, C, nwg, s);
+        return lfvdm_det_reduce2_launch(dgamma, det_ws, C, dbeta, det_ws + (size_t)nwg * C, C, nwg, s);
     }
     return LFVDM_OK;
 }

@@ -449,7 +449,7 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
     """Returns (dx_a, dx_b, dgamma, dbeta, dfilm).  da: [N*P][C] gradient w.r.t. act(GN(x)).  add, add2: optional
     [N*P][C] rows (further gradients of the same input) folded into dx by the in-place kernel."""
     C = C0 + C1
-    if add2 is not None and not (inplace and not nat.deterministic()):
+    if add2 is not None and not inplace:
         add, add2 = (add2 if add is None else add + add2), None
     L = nat.lib()
     dxa = _new(N * P, C0, like=da)
@@ -462,15 +462,12 @@ def _gn_backward(da, a, b, C0, C1, N, P, cA, cB, stats, act, gamma, beta, film, 
     if inplace and nat.deterministic():
         # fixed summation order: per-(sample, channel) sums (lfvdm_gn_bwd_stats), dx (lfvdm_gn_bwd_apply), then the
         # parameter / FiLM gradients by lfvdm_gn_param_grads, which walks the samples in order - no float atomics
+        # (the statistics + dx launch is the training path's fused kernel, with the sums stored instead of added)
         sums = _new(N, C, 2, like=da)
-        nat.check(L.lfvdm_gn_bwd_stats(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
-                                       act, nat.ptr(sums), nat.stream()), "lfvdm_gn_bwd_stats")
-        nat.check(L.lfvdm_gn_bwd_apply(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
-                                       nat.ptr(sums), act, nat.ptr(dxa), nat.ptr(dxb), 0, 0, nat.stream()), "lfvdm_gn_bwd_apply")
-        if add is not None:
-            dxa.add_(add[:, :C0])
-            if dxb is not None:
-                dxb.add_(add[:, C0:])
+        nat.check(L.lfvdm_gn_bwd_fused_sums(nat.ptr(da), nat.ptr(a), nat.ptr(b), C0, C1, N, P, nat.ptr(cA), nat.ptr(cB), nat.ptr(stats),
+                                            act, nat.ptr(dxa), nat.ptr(dxb), nat.ptr(add), add.stride(0) if add is not None else 0,
+                                            nat.ptr(add2), add2.stride(0) if add2 is not None else 0, nat.ptr(sums), nat.stream()),
+                  "lfvdm_gn_bwd_fused_sums")
         dfilm = None
         if film is not None:
             dfilm = dfilm_out if dfilm_out is not None else th.zeros(N // T, 2 * C, device=da.device, dtype=th.float32)

@@ -117,6 +117,8 @@ _SIGS = {
     "lfvdm_gn_bwd_apply": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_bwd_apply_params": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i,
                                    c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp], c_i),
+    "lfvdm_gn_bwd_fused_sums": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_i,
+                                 c_fp, c_fp], c_i),
     "lfvdm_gn_bwd_ws_floats": ([c_i, c_i, c_i], C.c_long),
     "lfvdm_gn_bwd_ws": ([c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i,
                          c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i, c_fp, c_fp, C.c_long, c_fp], c_i),
@@ -402,8 +404,7 @@ def _tuned_wgrad_code(a, out_floats):
     outputs - the real launch accumulates.  The weight-gradient kernels are a quarter of a training step and how their
     (filter tile, channel tile, M slice) workgroups divide the 256 CUs differs per layer."""
     cache = tune_cache()
-    # the bias reduction and a strided dout (ldr != Cout: the head's padded rows) change the kernel's work: own entries
-    key = (-1,) + tune_key(a) + (int(bool(a.bias)), int(a.ldr != a.Cout and a.ldr != 0))
+    key = _wgrad_key(a)
     code = _wgrad_agreed.get(key)
     if code is not None:
         return code
@@ -434,6 +435,11 @@ def _tuned_wgrad_code(a, out_floats):
 
 _wgrad_agreed = {}
 _store_memo = []
+
+
+def _wgrad_key(a):
+    # the bias reduction and a strided dout (ldr != Cout: the head's padded rows) change the kernel's work: own entries
+    return (-1,) + tune_key(a) + (int(bool(a.bias)), int(a.ldr != a.Cout and a.ldr != 0))
 
 
 def _rank_store():
@@ -487,8 +493,12 @@ def conv_wgrad(**kw):
     """Weight/bias gradient launch; kw as conv_igemm plus res=dout rows, out=packed dW, bias=db."""
     a = fill_conv_args(**kw)
     if deterministic():
+        # tile shape / M slices: the table entry measured in the default (atomics) mode, if there is one - nothing is timed in
+        # this mode (same table on every rank: same kernels, bitwise-equal replicas); key without the slab pointer
+        key = _wgrad_key(a)
         ws = det_workspace(kw["out"].device)
         a.splitk_ws, a.splitk_ws_floats = ws.data_ptr(), ws.numel()
+        a.tune = tune_cache().get(key, 0)
     else:
         a.tune = _tuned_wgrad_code(a, kw["out"].numel())
     check(lib().lfvdm_conv_wgrad(C.byref(a), stream()), "lfvdm_conv_wgrad")
