@@ -744,6 +744,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries ONE JSON line and nothing else: libraries that print to file descriptor 1 (RCCL's version banner at
+    # communicator creation, for one) are sent to stderr for the duration of the run; the line goes out through the saved
+    # descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -982,7 +989,8 @@ def main():
             out["cpu_baseline"]["cfgC_sample"] = cpu_baseline_sample(mc, inputs, B, T, cores, 6.0,
                                                                      what="the configs[2] network (ch128, batch 2, 20 frames)")
             del ma, mc
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():            # (the training leg initialises a world-1 group too)
         if world > 1:
             dist.barrier()

@@ -4,7 +4,7 @@
 #   bash tools/refresh_profiles.sh
 # 1. rocprofv3 kernel stats, training step                 -> train_kernel_stats.csv (also placed in profiles/ on the
 #    box, so that the bench line's train.roofline.families is computed from THIS profile)
-# 2. default bench line (all legs)                         -> bench_line.json
+# 2. (moved: the default bench line is taken after the PMC passes, step 4b)
 # 3. rocprofv3 kernel stats, sampling bench                -> bench_kernel_stats.csv
 # 4. PMC passes over eager denoising steps (tools/pmc_target.py), one counter group per pass:
 #    FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE  -> pmc_traffic.json (+ raw counter CSVs)
@@ -43,8 +43,6 @@ cp $OUT/pixel_train_kernel_stats.csv $ROOT/profiles/${ROUND}_pixel_train_kernel_
 stamp $OUT/pixel_train_kernel_stats.csv; cp $OUT/pixel_train_kernel_stats.csv.stamp.json $ROOT/profiles/${ROUND}_pixel_train_kernel_stats.csv.stamp.json
 rm -rf $OUT/pxp/*trace*
 echo "pixel train profile done"
-step 500 python3 $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
-echo "bench done"
 step 300 rocprofv3 --kernel-trace --stats -d $OUT/bp -o bp --output-format csv -- python3 $ROOT/bench.py --steps 300 --warmup 20 --train-steps 0 --pixel-steps 0 --long-video-windows 0 --no-cpu > $OUT/bp.log 2>&1
 cp $OUT/bp/bp_kernel_stats.csv $OUT/bench_kernel_stats.csv
 echo "bench profile done"
@@ -57,13 +55,18 @@ echo "pmc mfma done"
 python3 $ROOT/tools/pmc_summarize.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json $OUT/pmc_mfma
 stamp $OUT/pmc_traffic.json
 stamp $OUT/bench_kernel_stats.csv
+# 4b. the default bench line LAST among the measurements it quotes: train / pixel-train family splits and PMC traffic are
+#     read from profiles/${ROUND}_*, which must be THIS run's files (stamped with the running code)
+for f in pmc_traffic.json pmc_traffic.json.stamp.json; do cp $OUT/$f $ROOT/profiles/${ROUND}_$f; done
+step 500 python3 $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
+echo "bench done"
 # 5. in-kernel phase table of the implicit-GEMM launches (diagnostic build with -DLFVDM_STAMP, if present)
 if [ -f $ROOT/devlib/liblfvdm_stamp.so ]; then
   cd $ROOT && LFVDM_TUNE_CACHE_OUT= step 200 python3 tools/conv_phase_stamps.py all > $OUT/conv_phase_stamps.txt 2>&1; cd /tmp
   echo "phase stamps done"
 fi
 # 6. the parity tests that print their deviations from the reference fixtures
-cd $ROOT && step 400 python3 -m pytest tests/test_forward_gpu.py tests/test_sampler_gpu.py tests/test_train_gpu.py -m gpu -q -s --timeout 300 -k "reference or cfgC_training or replayed or full_size or fp64" > $OUT/parity_deviations.txt 2>&1; cd /tmp
+cd $ROOT && step 500 python3 -m pytest tests/test_forward_gpu.py tests/test_backward_gpu.py tests/test_sampler_gpu.py tests/test_train_gpu.py -m gpu -q -s --timeout 400 -k "reference or cfgC_training or replayed or full_size or fp64 or parameter_gradients" > $OUT/parity_deviations.txt 2>&1; cd /tmp
 echo "parity deviations done"
 # 7. the whole 1000-frame hierarchy-2 video (BASELINE.json configs[3] at full size: 97 windows x 250 steps)
 step 400 python3 $ROOT/bench.py --steps 50 --warmup 10 --train-steps 0 --pixel-steps 0 --no-cpu --long-video-windows 97 > $OUT/long_video_line.json 2> $OUT/long_video.err
