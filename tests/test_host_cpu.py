@@ -330,24 +330,32 @@ def test_vae_boundary_matches_reference_golden():
 
 
 def test_wgrad_tune_codes_are_well_formed():
-    """Candidate launch codes of the weight-gradient tuner (_native._wgrad_codes: 1 + tile + 4 * stages + 16 * M slices):
-    unique, only legal tiles for the filter count, at most half as many M slices as 32-row chunks, none for shapes the
-    LDS-DMA kernels do not take (channels not a multiple of 64, fewer than 64 filters)."""
+    """Candidate launch codes of the weight-gradient tuner (_native._wgrad_codes: 1 + tile + 4 * stages + 16 * M slices; tile
+    1 / 2 / 3 = 64x64 / 128x64 / 128x128, stages 1 / 2 / 3 = two / three stages / 64-row chunks, stage field 0 = the tap-fused
+    kernels with three (tile 1) or nine (tile 2) taps per workgroup): unique, only legal tiles for the filter / channel
+    count, a bounded number of M slices, tap-fused codes only for 3x3 / stride-1 layers on maps of 8, 16 or a multiple of
+    32 pixels per row, none at all for shapes the LDS-DMA kernels do not take."""
     from improved_diffusion import _native as nat
     a = nat.ConvArgs()
-    a.N, a.Ho, a.Wo, a.C0, a.C1, a.Cout, a.ksize = 40, 16, 16, 128, 0, 128, 3
+    a.N, a.Hs, a.Ws, a.Ho, a.Wo, a.C0, a.C1, a.Cout, a.ksize, a.stride = 40, 16, 16, 16, 16, 128, 0, 128, 3, 1
     codes = nat._wgrad_codes(a)
     assert codes and len(set(codes)) == len(codes)
     nchunks = (40 * 256 + 31) // 32
-    tiles = set()
+    seen = set()
     for c in codes:
         t = c - 1
         tile, stages, ms = t & 3, (t >> 2) & 3, t >> 4
-        assert tile in (1, 2) and stages in (1, 2) and 1 <= ms <= nchunks // 2
-        tiles.add(tile)
-    assert tiles == {1, 2}
+        assert tile in (1, 2, 3) and 1 <= ms <= nchunks // 2
+        assert stages in (1, 2, 3) or (stages == 0 and tile in (1, 2)), (tile, stages)
+        seen.add((tile, stages > 0))
+    assert seen == {(1, True), (2, True), (3, True), (1, False), (2, False)}
+    a.stride = 2                                              # strided layer: no tap-fused kernels
+    assert all(((c - 1) >> 2) & 3 for c in nat._wgrad_codes(a))
+    a.stride, a.Ho, a.Wo, a.Hs, a.Ws = 1, 12, 12, 12, 12       # 144 pixels per frame: chunks would straddle frames
+    assert all(((c - 1) >> 2) & 3 for c in nat._wgrad_codes(a))
+    a.Ho = a.Wo = a.Hs = a.Ws = 16
     a.Cout = 64
-    assert {(c - 1) & 3 for c in nat._wgrad_codes(a)} == {1}, "128-filter tiles need 128 filters"
+    assert {(c - 1) & 3 for c in nat._wgrad_codes(a) if ((c - 1) >> 2) & 3} == {1}, "128-filter tiles need 128 filters"
     a.C0 = 96
     assert nat._wgrad_codes(a) == []
     a.C0, a.Cout = 128, 32
