@@ -120,11 +120,23 @@ class GradExchange:
         self._late = []                    # (pinned word, event): the timed-out word of earlier steps, read one step late
         if self.overlap:
             from . import _native as nat
-            self.comm = th.cuda.Stream(priority=_comm_priority())
-            self.overlap_probe = self._probe_overlap()
+            # HIP maps streams of one priority onto a few hardware queues in creation order: a fresh stream may alias the
+            # queue that replays the backward graph (a wait parked there would only start after the graph).  Probe, and on a
+            # miss try the next stream - the rejected ones are kept alive meanwhile so that the runtime moves on to another
+            # queue.  (Round 3 side-stepped this with a high-priority stream, which has its own queue - and was measured in
+            # round 4 to delay every launch of the graph while a polling kernel sits on it.)
+            rejected = []
+            for attempt in range(8):
+                self.comm = th.cuda.Stream(priority=_comm_priority())
+                self.overlap_probe = self._probe_overlap()
+                self.overlap_probe["streams_tried"] = attempt + 1
+                if self.overlap_probe["ok"]:
+                    break
+                rejected.append(self.comm)
+            del rejected
             if self.overlap_probe["ok"]:
                 self.flags = nat.StreamFlags(self.n_early, arena.g.device)
-            else:               # the two streams share a hardware queue (or the wait gave up): exchange behind the graph's end
+            else:               # every stream shares main's hardware queue (or the waits gave up): exchange behind the graph's end
                 self.overlap = False
         self._works = []
         self._timing = []              # (start, end) event pairs of the exposed waits, read lazily

@@ -1295,3 +1295,59 @@ def test_conv_wgrad_every_tune_code(nat, N, C0, C1, Cout, H, k):
         got_w = gp.view(Cout, k, k, Cin).permute(0, 3, 1, 2).cpu()
         assert float((got_w - w.grad).abs().max()) < 2e-5 * scale, f"tune code {code} (deterministic)"
         assert float((db.cpu() - b.grad).abs().max()) < 2e-5 * max(1.0, float(b.grad.abs().max())), f"tune code {code}: db (deterministic)"
+
+
+def test_tensors_above_one_gibibyte_take_the_range_paths(nat):
+    """Operands of 2^30 bytes and more (pixel space at large batch: 64 frames x 128 x 128 x 256 channels = 1 GiB): the LDS-DMA
+    kernels address with 32-bit byte offsets below 2^30, so lfvdm_conv_igemm cuts the batch into sample ranges and
+    lfvdm_conv_wgrad falls back to the register-staged kernels with 64-bit addressing.  Reference: torch's own convolution
+    and its autograd ON THE GPU (fp32) - the CPU would need minutes at this size.  Also the full pixel-space weight-gradient
+    shape of BASELINE.json configs[4] (20 x 128 x 128, 128 -> 128: M = 327680) through the tap-fused and tiled kernels."""
+    import ctypes as C
+    torch.backends.cudnn.allow_tf32 = False
+    g = torch.Generator(device="cuda").manual_seed(5)
+    # ---- forward + weight gradient above 2^30 bytes
+    N, H, Cin, Cout = 64, 128, 256, 64
+    x = torch.randn(N, H, H, Cin, device="cuda", generator=g)                   # channels-last rows: exactly 2^30 bytes
+    assert x.numel() * 4 >= 1 << 30
+    w = (0.02 * torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g)).requires_grad_(True)
+    b = torch.randn(Cout, device="cuda", generator=g).requires_grad_(True)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)                      # (N, Cout, H, W) view of channels-last data
+    out = torch.empty(N * H * H, Cout, device="cuda")
+    wp = packed(nat, w.detach().cpu())
+    nat.conv_igemm(src0=x.view(-1, Cin), C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, W=wp, bias=b.detach(), Cout=Cout, out=out, ldo=Cout)
+    got = out.view(N, H, H, Cout).permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    err = float((got - ref.detach()).abs().max())
+    assert err < 2e-4 * scale, (err, scale)
+    dout = torch.randn(N * H * H, Cout, device="cuda", generator=g)
+    ref.backward(dout.view(N, H, H, Cout).permute(0, 3, 1, 2))
+    gp = torch.zeros(Cout, 9, Cin, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    nat.conv_wgrad(src0=x.view(-1, Cin), C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, ksize=3, res=dout, ldr=Cout, out=gp, bias=db, Cout=Cout)
+    got_w = gp.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    sw = float(w.grad.abs().max())
+    assert float((got_w - w.grad).abs().max()) < 5e-4 * sw, (float((got_w - w.grad).abs().max()), sw)
+    assert float((db - b.grad).abs().max()) < 5e-4 * float(b.grad.abs().max())
+    del x, ref, out, got, dout
+    torch.cuda.empty_cache()
+    # ---- the full pixel-space weight-gradient shape, every kernel family the tuner may pick for it
+    N, Cin, Cout = 20, 128, 128
+    x = torch.randn(N, H, H, Cin, device="cuda", generator=g)
+    w = (0.02 * torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g)).requires_grad_(True)
+    dout = torch.randn(N * H * H, Cout, device="cuda", generator=g)
+    F.conv2d(x.permute(0, 3, 1, 2), w, None, padding=1).backward(dout.view(N, H, H, Cout).permute(0, 3, 1, 2))
+    sw = float(w.grad.abs().max())
+    gp = torch.zeros(Cout, 9, Cin, device="cuda")
+    a = nat.fill_conv_args(src0=x.view(-1, Cin), C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, ksize=3, res=dout, ldr=Cout, out=gp, Cout=Cout)
+    codes = nat._wgrad_codes(a)
+    pick = {}
+    for c in codes:                                     # one code per (tile, stage field): largest M-slice count of each
+        pick[((c - 1) & 3, ((c - 1) >> 2) & 3)] = c
+    assert {(1, 0), (2, 0), (3, 1)} <= set(pick), sorted(pick)
+    for key, code in sorted(pick.items()):
+        a.tune = code
+        gp.zero_()
+        nat.check(nat.lib().lfvdm_conv_wgrad(C.byref(a), nat.stream()), "lfvdm_conv_wgrad")
+        err = float((gp.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2) - w.grad).abs().max())
+        assert err < 5e-4 * sw, (key, code, err, sw)
