@@ -71,3 +71,24 @@ def test_one_rank_line_has_the_same_schema():
         assert hp[k]["bytes"] > 0 and hp[k]["us"] > 0 and 0 < hp[k]["frac"] < 1, (k, hp[k])
     assert hp["adamw_ema"]["frac"] > 0.4, hp["adamw_ema"]
     assert d["code_stamp"]["abi"] > 0
+
+
+def test_pixel_training_leg_runs_the_published_recipe():
+    """bench.bench_pixel_train: the reference's published training recipe (README.md:54-57: 128x128x3 frames, 20 frames,
+    num_channels=128, num_res_blocks=1) as a TrainLoop at batch 1 - eager steps, capture, replays; finite loss, a captured
+    micro-step, and a whole-step rate that only the large-map kernels (chunked GroupNorm backward, tiled weight gradients)
+    can give: above 40 % of the fp32 MFMA peak."""
+    import sys
+    import torch
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ.setdefault("LFVDM_TUNE_CACHE", os.path.join(ROOT, "profiles", "tune_cache_mi355x.json"))
+    import bench
+    rec = bench.bench_pixel_train(torch.device("cuda", 0), 3, batch=1, num_res_blocks=1, warmup=4)
+    assert rec["graph_replay"] and rec["last_loss"] == rec["last_loss"] and 0.0 < rec["last_loss"] < 10.0, rec
+    assert rec["params"] == 80358147
+    rf = rec["roofline"]
+    assert rf["flops_per_step"] > 5.0e12 and rf["frac"] > 0.40, rf
+    fam = rf.get("families")
+    if fam is not None and not fam["stale"]:
+        assert fam["slowest_groupnorm_kernel_avg_us"] < 100.0, fam
