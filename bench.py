@@ -257,13 +257,23 @@ def running_code_stamp():
     """What identifies the code that is running: the library's ABI version and the digest of csrc/* + headers recorded by
     the build next to the library (lib/build_manifest.json)."""
     from improved_diffusion import _native as nat
-    digest = None
+    digest, origin = None, None
+    pkg = os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd")
     try:
-        with open(os.path.join(ROOT, "latent-flexible-video-diffusion-modeling_amd", "lib", "build_manifest.json")) as f:
-            digest = json.load(f).get("source_digest")
+        with open(os.path.join(pkg, "lib", "build_manifest.json")) as f:
+            digest, origin = json.load(f).get("source_digest"), "build manifest"
     except (OSError, ValueError):
         pass
-    return {"abi": int(nat.lib().lfvdm_abi_version()), "source_digest": digest}
+    if digest is None:          # library shipped without its manifest: the digest of the sources next to it
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("lfvdm_build", os.path.join(pkg, "build.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            digest, origin = mod.source_digest(), "source tree"
+        except Exception:
+            pass
+    return {"abi": int(nat.lib().lfvdm_abi_version()), "source_digest": digest, "digest_from": origin}
 
 
 def profile_stamp(path):
