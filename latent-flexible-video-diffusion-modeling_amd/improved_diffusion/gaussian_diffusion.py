@@ -490,6 +490,8 @@ class GraphSampler:
         # it holds (1063 -> 1080 steps/s at cfg B with 8 steps per launch; 32 and more lose again); LFVDM_STEPS_PER_GRAPH=1: off
         import os
         self.K = max(1, int(os.environ.get("LFVDM_STEPS_PER_GRAPH", "8")))
+        if self.plan.time_steps and self.plan.time_ring:
+            self.K = min(self.K, self.plan.time_ring // 2)     # a graph launch must not walk more than half the R ring
         self.graph_k = None
         self.expected_t = None
 
