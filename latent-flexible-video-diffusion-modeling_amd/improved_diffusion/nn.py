@@ -10,6 +10,21 @@ import torch as th
 import torch.nn as nn
 
 
+_checkpoint_warned = [False]
+
+
+def warn_use_checkpoint(flag):
+    """``use_checkpoint=True`` (reference nn.py:126-172, used at unet.py:190-192 and rpe.py:127) is accepted for
+    constructor compatibility and has NO effect here: the native backward keeps the activations it needs (results are
+    identical to the reference's, peak memory is not reduced).  Said once per process."""
+    if flag and not _checkpoint_warned[0]:
+        _checkpoint_warned[0] = True
+        import warnings
+        warnings.warn("use_checkpoint=True is accepted but ignored by the native gfx950 path: activations are kept for "
+                      "the backward pass (same results as the reference, no memory saving)", RuntimeWarning, stacklevel=3)
+    return bool(flag)
+
+
 class SiLU(nn.Module):
     """x * sigmoid(x)  (reference nn.py:12-14).  Fused into the conv operand load natively."""
 

@@ -5,7 +5,7 @@ Compute lives in csrc/attention.hip (``lfvdm_rpe_nets``, ``lfvdm_attn_temporal``
 """
 import torch.nn as nn
 
-from .nn import normalization, zero_module
+from .nn import normalization, zero_module, warn_use_checkpoint
 
 
 class RPENet(nn.Module):
@@ -46,7 +46,7 @@ class RPEAttention(nn.Module):
         self.num_heads = num_heads
         self.channels = channels
         self.scale = (channels // num_heads) ** -0.5
-        self.use_checkpoint = use_checkpoint
+        self.use_checkpoint = warn_use_checkpoint(use_checkpoint)
         self.qkv = nn.Linear(channels, channels * 3)
         self.proj_out = zero_module(nn.Linear(channels, channels))
         self.norm = normalization(channels)

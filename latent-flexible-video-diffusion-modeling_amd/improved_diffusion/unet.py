@@ -10,7 +10,7 @@ import torch as th
 import torch.nn as nn
 
 from .fp16_util import convert_module_to_f16, convert_module_to_f32
-from .nn import SiLU, conv_nd, linear, avg_pool_nd, zero_module, normalization
+from .nn import SiLU, conv_nd, linear, avg_pool_nd, zero_module, normalization, warn_use_checkpoint
 from .rpe import RPEAttention
 
 
@@ -64,7 +64,7 @@ class ResBlock(TimestepBlock):
         self.dropout = dropout
         self.out_channels = out_channels or channels
         self.use_conv = use_conv
-        self.use_checkpoint = use_checkpoint
+        self.use_checkpoint = warn_use_checkpoint(use_checkpoint)
         self.use_scale_shift_norm = use_scale_shift_norm
         self.in_layers = nn.Sequential(normalization(channels), SiLU(),
                                        conv_nd(dims, channels, self.out_channels, 3, padding=1))
@@ -116,7 +116,7 @@ class UNetVideoModel(nn.Module):
         self.dropout = dropout
         self.channel_mult = channel_mult
         self.conv_resample = conv_resample
-        self.use_checkpoint = use_checkpoint
+        self.use_checkpoint = warn_use_checkpoint(use_checkpoint)
         self.num_heads = num_heads
         self.num_heads_upsample = num_heads_upsample
         self.use_rpe_net = use_rpe_net
