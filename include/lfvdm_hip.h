@@ -569,6 +569,78 @@ int lfvdm_compose_rows(const float* x, const float* x0, const float* obs, float*
                        void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Persistent level chain: a run of CONSECUTIVE launches of one forward pass - implicit GEMMs and small-map GroupNorms of
+ * the low-resolution levels (unet.py:194-207 ResBlocks, :91-114 / :60-88 resampling convs, the 1x1 projections of
+ * :223-243) - executed as ONE launch of <= 256 co-resident workgroups.  Every stage keeps the tile decomposition, K-slice
+ * order and epilogue of its stand-alone kernel (bitwise the same results); what replaces the launch boundaries is a
+ * point-to-point dependency per work item: an item lists the output tiles of earlier stages whose bytes it reads, polls
+ * their FLAGS (one lane per flag, sc1 loads, s_sleep between polls) and only then stages its activations - with sc1
+ * loads, from tensors the producers published with sc1 (write-through) stores, so no release / acquire fence sits on the
+ * path (0.7-1.15 us per hop against 3.9 us for a counter barrier among 256 workgroups: tools/grid_barrier_bench).  The
+ * filter pieces of an item's first K chunks, which depend on nothing the chain produces, are in flight before it waits.
+ * A flag holds the GENERATION of the launch that completed its tile; the generation advances once per launch (last
+ * workgroup out), so nothing is reset between replays.
+ *
+ * Every wait is bounded: a poller that has waited longer than `timeout_s` of wall clock raises ctl[LFVDM_CHAIN_CTL_ABORT]
+ * and leaves; every poller also watches that word, so all workgroups reach the end of the kernel.  The host reads the word
+ * (it stays raised), falls back to the per-launch plan and reports the failure.
+ *
+ * Use: fill kind + conv / gn of every stage (conv.tune = a code whose tile is <1,1,4,1> with 32-channel chunks and a
+ * plain split-K factor; outputs of different stages must be DIFFERENT buffers - there is no launch boundary to order a
+ * reuse), call lfvdm_chain_plan (host only: work items, flags, dependency lists, split-K workspace offsets), point each
+ * conv.splitk_ws / splitk_cnt at ws + ws_off / cnt + cnt_off of zero-initialised tickets, copy stages and deps to the
+ * device, zero flags[n_flags] and ctl[LFVDM_CHAIN_CTL_INTS] once, launch lfvdm_level_chain with the planned grid.
+ * ------------------------------------------------------------------------------------- */
+#define LFVDM_CHAIN_CONV 0
+#define LFVDM_CHAIN_GN 1
+#define LFVDM_CHAIN_MAX_DEPS 64
+#define LFVDM_CHAIN_CTL_EPOCH 0    /* int index: generation of the last completed launch */
+#define LFVDM_CHAIN_CTL_EXIT 32    /* workgroups that have left the current launch */
+#define LFVDM_CHAIN_CTL_ABORT 64   /* non-zero: a wait timed out */
+#define LFVDM_CHAIN_CTL_INTS 96
+
+typedef struct lfvdm_gn_args {       /* lfvdm_gn_apply's arguments (one-wave form: P <= 256, (C0+C1)/32 in {2,4,8,16}) */
+    const float* src0;
+    const float* src1;
+    int32_t C0, C1, N, P;
+    const float* gamma;
+    const float* beta;
+    const float* film;
+    int32_t film_div, film_ld;
+    float eps;
+    int32_t act;
+    float* out;
+} lfvdm_gn_args;
+
+typedef struct lfvdm_chain_stage {
+    int32_t kind;            /* LFVDM_CHAIN_CONV | LFVDM_CHAIN_GN */
+    /* filled by lfvdm_chain_plan: */
+    int32_t n_items;         /* work items (conv: the XCD-aware flat grid of the stand-alone launch, padding included) */
+    int32_t flag_base;       /* flags[flag_base + output unit] (conv: output tile; gn: work item) */
+    int32_t n_flags;
+    int32_t dep_base;        /* deps[dep_base + item * dep_stride] = count, followed by `count` flag indices */
+    int32_t dep_stride;
+    int32_t cfg;             /* conv: kernel-body instance */
+    int32_t kz;              /* conv: K slices over workgroups */
+    int32_t nt2;             /* conv: filter tiles */
+    int32_t pad_;
+    int64_t ws_off;          /* conv: this stage's slab region (floats) and ticket region (ints) in the chain's workspace */
+    int64_t cnt_off;
+    lfvdm_conv_args conv;
+    lfvdm_gn_args gn;
+} lfvdm_chain_stage;
+
+/* Host-side planning (no GPU work).  deps: caller's array of deps_cap ints.  -> LFVDM_E_UNSUPPORTED if a stage cannot run
+ * in a chain (tile configuration, layout, more than LFVDM_CHAIN_MAX_DEPS producers for an item, a buffer written twice). */
+int lfvdm_chain_plan(lfvdm_chain_stage* stages, int n_stages, int32_t* deps, int64_t deps_cap, int64_t* deps_used,
+                     int32_t* n_flags, int64_t* ws_floats, int64_t* cnt_ints, int32_t* grid, int32_t* lds_bytes);
+/* LFVDM_OK if this launch could be a chain stage with this tune code (tile / chunk / split-K family the chain kernel holds) */
+int lfvdm_chain_conv_ok(const lfvdm_conv_args* a);
+int lfvdm_chain_gn_ok(int C0, int C1, int N, int P);
+int lfvdm_level_chain(const lfvdm_chain_stage* stages_dev, int n_stages, const int32_t* deps_dev, int32_t* flags, int32_t* ctl,
+                      int grid, int lds_bytes, double timeout_s, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Device-side semaphores between a replayed hipGraph and another stream: host-side plumbing of the bucketed gradient
  * exchange that stands in for DistributedDataParallel's overlapped buckets (train_util.py:116-125,309-313).
  *   lfvdm_flag_add : *flag += 1 once everything enqueued before it on `stream` has completed.  An ordinary kernel node

@@ -1,0 +1,339 @@
+// Persistent level chain (include/lfvdm_hip.h, "Persistent level chain"): the implicit GEMMs and small-map GroupNorms of
+// the low-resolution levels of one forward pass as ONE launch.  A stage is the stand-alone kernel's body (conv_igemm_body.h,
+// gn_wave_body.h: same tiles, same K-slice order, same epilogue - bitwise the same values) run on work items instead of
+// workgroups; launch boundaries become point-to-point tile flags (ChainCtx).  gfx950 only.
+//
+// Why flags and not a grid barrier (tools/grid_barrier_bench, profiles/r05_grid_barrier.json): a relaxed agent-scope add +
+// sc1 poll on ONE word costs 13 ns per arrival or poll - 1.4 / 2.1 / 3.9 us per barrier among 64 / 128 / 256 workgroups -
+// while a consumer that polls the flags of the 1-16 producer tiles it actually reads (one lane per flag, one load
+// instruction) sees them 0.7-1.15 us after they were set, whatever the grid.  The producers' bytes travel without fences:
+// sc1 (write-through) stores, drained, then the flag; sc1 loads (registers and LDS-DMA) on the consumer side.
+#include <algorithm>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "common_hip.h"
+
+#define STAMP(i) do {} while (0)
+#include "conv_igemm_body.h"
+#include "gn_wave_body.h"
+
+namespace {
+
+typedef const lfvdm_chain_stage __attribute__((address_space(4))) * StagePtr;     // constant address space: scalar loads
+typedef const int __attribute__((address_space(4))) * DepPtr;
+
+// kernel-body instances a stage can ask for: tile id 6 = <1,1,4,1> / id 2 = <1,2,2,1> (both 4 waves), 32-channel chunks,
+// 2 / 3 LDS-DMA stages, one-source ("simple") or general operand form
+constexpr int kChainThreads = 256;
+inline int chain_cfg_index(int id, int gl, bool simple) { return (id == 2 ? 4 : 0) + (gl == 3 ? 2 : 0) + (simple ? 0 : 1); }
+inline bool chain_simple(const lfvdm_conv_args* a) { return a->C1 == 0 && a->s2C0 + a->s2C1 == 0 && a->up == 0; }
+
+template <int WM, int WN, int WK, int NT, bool SIMPLE, int GL>
+__device__ __forceinline__ bool run_conv(StagePtr st, const ChainCtx& cx) {
+    const lfvdm_conv_args p = *(const lfvdm_conv_args*)&st->conv;   // constant address space, uniform index: scalar loads
+    return conv_igemm_body<WM, WN, WK, NT, 32, SIMPLE, GL, true>(p, st->nt2, -st->kz, 0, cx);
+}
+
+__global__ __launch_bounds__(kChainThreads) void level_chain_kernel(const lfvdm_chain_stage* stages_g, int n_stages,
+                                                                    const int* deps_g, int* flags, int* ctl,
+                                                                    long long timeout_ticks) {
+    const StagePtr stages = (StagePtr)(uintptr_t)stages_g;
+    const DepPtr deps = (DepPtr)(uintptr_t)deps_g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gen = __builtin_amdgcn_readfirstlane(
+                        __hip_atomic_load(ctl + LFVDM_CHAIN_CTL_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1;
+    __shared__ int s_go2;
+    bool alive = true;
+    for (int s = 0; s < n_stages && alive; ++s) {
+        const StagePtr st = stages + s;
+        const int kind = st->kind, n_items = st->n_items, dstride = st->dep_stride, dbase = st->dep_base;
+        for (int item = blockIdx.x; item < n_items && alive; item += gridDim.x) {
+            __syncthreads();          // the previous item's LDS tiles are no longer read
+            const DepPtr dl = deps + dbase + (size_t)item * dstride;
+            ChainCtx cx;
+            cx.item = item;
+            cx.n_items = n_items;
+            cx.ndeps = dl[0];
+            cx.deps = (const int*)(deps_g + dbase + (size_t)item * dstride + 1);
+            cx.flags = flags;
+            cx.flag_base = st->flag_base;
+            cx.gen = gen;
+            cx.abort_word = ctl + LFVDM_CHAIN_CTL_ABORT;
+            cx.timeout_ticks = timeout_ticks;
+            if (kind == LFVDM_CHAIN_CONV) {
+                switch (st->cfg) {
+                    case 0: alive = run_conv<1, 1, 4, 1, true, 2>(st, cx); break;
+                    case 1: alive = run_conv<1, 1, 4, 1, false, 2>(st, cx); break;
+                    case 2: alive = run_conv<1, 1, 4, 1, true, 3>(st, cx); break;
+                    case 3: alive = run_conv<1, 1, 4, 1, false, 3>(st, cx); break;
+                    case 4: alive = run_conv<1, 2, 2, 1, true, 2>(st, cx); break;
+                    case 5: alive = run_conv<1, 2, 2, 1, false, 2>(st, cx); break;
+                    case 6: alive = run_conv<1, 2, 2, 1, true, 3>(st, cx); break;
+                    default: alive = run_conv<1, 2, 2, 1, false, 3>(st, cx); break;
+                }
+            } else {
+                // GroupNorm item = 4 waves = 4 consecutive (sample, 16-channel) units of one sample
+                const lfvdm_gn_args g = *(const lfvdm_gn_args*)&st->gn;
+                if (wave == 0) {
+                    const bool ok = chain_poll(cx, lane);
+                    if (lane == 0) s_go2 = ok ? 1 : 0;
+                }
+                __syncthreads();
+                if (!s_go2) {
+                    alive = false;
+                    break;
+                }
+                const int C = g.C0 + g.C1, cbs = C >> 4, cg = C >> 5;
+                const int u = item * 4 + wave;
+                if (u < g.N * cbs) {
+                    const int n = u / cbs, cb = u - n * cbs;
+#define LFVDM_GNB(G)                                                                                                          \
+    gn_wave_body<G, true>(n, cb, lane, g.src0, g.src1, g.C0, g.C1, g.P, g.gamma, g.beta, g.film, g.film_div, g.film_ld, g.eps, \
+                          nullptr, nullptr, nullptr, g.out, g.act)
+                    if (cg == 2) LFVDM_GNB(2);
+                    else if (cg == 4) LFVDM_GNB(4);
+                    else if (cg == 8) LFVDM_GNB(8);
+                    else LFVDM_GNB(16);
+#undef LFVDM_GNB
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0)
+                    __hip_atomic_store(flags + cx.flag_base + item, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // last workgroup out advances the generation (the next launch is stream-ordered behind this one)
+    __syncthreads();
+    if (tid == 0) {
+        const int t = __hip_atomic_fetch_add(ctl + LFVDM_CHAIN_CTL_EXIT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (int)gridDim.x - 1) {
+            __hip_atomic_store(ctl + LFVDM_CHAIN_CTL_EXIT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctl + LFVDM_CHAIN_CTL_EPOCH, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host-side planning
+struct Pick2 { int id, kch, kz, gl; };
+inline bool decode_chain_code(const lfvdm_conv_args* a, Pick2* pk) {
+    if (a->tune <= 0) return false;
+    const int t = a->tune - 1;
+    pk->id = t & 15;
+    pk->kch = (t & 16) ? 64 : 32;
+    pk->kz = kKzTable[(t >> 5) & 7];
+    pk->gl = ((t >> 8) & 3) + 1;
+    return true;
+}
+
+bool conv_stage_ok(const lfvdm_conv_args* a, Pick2* pk) {
+    if (!decode_chain_code(a, pk)) return false;
+    if ((pk->id != 6 && pk->id != 2) || pk->kch != 32 || pk->kz < 1 || pk->kz > 8 || (pk->gl != 2 && pk->gl != 3)) return false;
+    if (a->out_mode != LFVDM_OUT_ROWS || a->coefA || a->coefB || a->resA || parity_classes(a) || a->up == 2) return false;
+    const int Cin = a->C0 + a->C1, C2 = a->s2C0 + a->s2C1;
+    if (a->N <= 0 || a->Cout <= 0 || Cin <= 0 || Cin % 32 || a->C0 % 32 || C2 % 32 || a->s2C0 % 32 || a->Cout % 4 || a->ldo % 4) return false;
+    if (a->res && a->ldr % 4) return false;
+    if (!glds_ok(a)) return false;
+    // 32-bit byte offsets of the sc1 epilogue accesses
+    const long M = (long)a->N * a->Ho * a->Wo;
+    if (M * std::max(a->ldo, std::max(a->ldr, a->Cout)) * 4 >= (1L << 31)) return false;
+    lfvdm_conv_args b = *a;        // capacity checks of cfg_valid against a notional workspace: the plan sizes the real one
+    b.splitk_ws = (float*)(uintptr_t)16;
+    b.splitk_cnt = (int32_t*)(uintptr_t)16;
+    b.splitk_ws_floats = 1L << 40;
+    b.splitk_cnt_ints = 1L << 40;
+    return cfg_valid(&b, pk->id, pk->kch, pk->kz, pk->gl);
+}
+
+bool gn_stage_ok(int C0, int C1, int N, int P) {
+    const int C = C0 + C1, cg = C / 32;
+    return N > 0 && P > 0 && P <= 256 && C % 64 == 0 && C0 % 16 == 0 && (cg == 2 || cg == 4 || cg == 8 || cg == 16) &&
+           (long)N * P * C * 4 < (1L << 31);
+}
+
+// who wrote a buffer inside the chain, and in which units
+struct Writer {
+    int stage;
+    bool conv;
+    int BM, BN, MT;       // conv: tile rows / columns, row tiles;  flag = flag_base + by * MT + bx
+    int P, cbs4;          // gn: rows per sample, 64-column blocks per sample;  flag = flag_base + n * cbs4 + j
+    int flag_base;
+    long rows, cols;
+};
+
+}  // namespace
+
+extern "C" int lfvdm_chain_conv_ok(const lfvdm_conv_args* a) {
+    Pick2 pk;
+    return conv_stage_ok(a, &pk) ? LFVDM_OK : LFVDM_E_UNSUPPORTED;
+}
+
+extern "C" int lfvdm_chain_gn_ok(int C0, int C1, int N, int P) { return gn_stage_ok(C0, C1, N, P) ? LFVDM_OK : LFVDM_E_UNSUPPORTED; }
+
+extern "C" int lfvdm_chain_plan(lfvdm_chain_stage* stages, int n_stages, int32_t* deps, int64_t deps_cap, int64_t* deps_used,
+                                int32_t* n_flags_out, int64_t* ws_floats, int64_t* cnt_ints, int32_t* grid_out, int32_t* lds_out) {
+    if (!stages || n_stages <= 0 || !deps || !deps_used || !n_flags_out || !ws_floats || !cnt_ints || !grid_out || !lds_out)
+        return LFVDM_E_SHAPE;
+    std::map<const float*, Writer> writers;
+    std::set<const float*> touched;          // every buffer read or written so far: a later write to one of them has no
+                                             // launch boundary to order it
+    long nflags = 0, ndeps = 0, ws = 0, cnt = 0;
+    int grid = 1, lds = 0;
+
+    // flags of the units of `w` that overlap rows [r0, r1) x columns [c0, c1)
+    auto add_region = [&](std::vector<int>& out, const float* base, long r0, long r1, long c0, long c1) {
+        if (!base || r1 <= r0 || c1 <= c0) return;
+        auto it = writers.find(base);
+        if (it == writers.end()) return;            // produced by an earlier launch: ordered by the launch boundary
+        const Writer& w = it->second;
+        r1 = std::min(r1, w.rows);
+        c1 = std::min(c1, w.cols);
+        if (w.conv) {
+            for (long by = c0 / w.BN; by <= (c1 - 1) / w.BN; ++by)
+                for (long bx = r0 / w.BM; bx <= (r1 - 1) / w.BM; ++bx) out.push_back(w.flag_base + (int)(by * w.MT + bx));
+        } else {
+            for (long n = r0 / w.P; n <= (r1 - 1) / w.P; ++n)
+                for (long j = c0 / 64; j <= (c1 - 1) / 64; ++j) out.push_back(w.flag_base + (int)(n * w.cbs4 + j));
+        }
+    };
+    // columns [c0, c1) of a virtual concat (a | b) -> regions of a and b
+    auto add_cat = [&](std::vector<int>& out, const float* a, int Ca, const float* b, long r0, long r1, long c0, long c1) {
+        if (c0 < Ca) add_region(out, a, r0, r1, c0, std::min<long>(c1, Ca));
+        if (c1 > Ca) add_region(out, b, r0, r1, std::max<long>(c0, Ca) - Ca, c1 - Ca);
+    };
+    auto note_write = [&](const float* base) {
+        if (!base) return true;
+        if (touched.count(base)) return false;
+        touched.insert(base);
+        return true;
+    };
+
+    for (int s = 0; s < n_stages; ++s) {
+        lfvdm_chain_stage& st = stages[s];
+        st.flag_base = (int)nflags;
+        st.dep_base = (int)ndeps;
+        st.ws_off = st.cnt_off = 0;
+        std::vector<std::vector<int>> item_deps;
+        if (st.kind == LFVDM_CHAIN_CONV) {
+            const lfvdm_conv_args& a = st.conv;
+            Pick2 pk;
+            if (!conv_stage_ok(&a, &pk)) return LFVDM_E_UNSUPPORTED;
+            const TileCfg tc = kCfgs[pk.id];
+            const int BM = 32 * tc.WM, BN = 32 * tc.NT * tc.WN, KC = 32;
+            const long M = (long)a.N * a.Ho * a.Wo;
+            const int MT = (int)((M + BM - 1) / BM), NT2 = (a.Cout + BN - 1) / BN, KZ = pk.kz;
+            const long total = (long)MT * NT2 * KZ, per = (total + 7) / 8;
+            if (8 * per >= (1L << 20)) return LFVDM_E_UNSUPPORTED;
+            st.n_items = (int)(8 * per);
+            st.n_flags = MT * NT2;
+            st.cfg = chain_cfg_index(pk.id, pk.gl, chain_simple(&a));
+            st.kz = KZ;
+            st.nt2 = NT2;
+            if (KZ > 1) {
+                st.ws_off = ws;
+                st.cnt_off = cnt;
+                ws += (long)MT * NT2 * KZ * BM * BN;
+                cnt += (long)MT * NT2;
+            }
+            lds = std::max(lds, (int)glds_lds_bytes(tc.WM, tc.WN, tc.WK, tc.NT, KC, pk.gl));
+            const int Cin = a.C0 + a.C1, taps = a.ksize * a.ksize;
+            const int NK1 = taps * (Cin / KC), NK = NK1 + (a.s2C0 + a.s2C1) / KC;
+            const long HoWo = (long)a.Ho * a.Wo, Ps = (long)a.Hs * a.Ws;
+            item_deps.resize(st.n_items);
+            for (int id = 0; id < st.n_items; ++id) {
+                const long L = (long)(id & 7) * per + (id >> 3);       // the kernel's XCD-aware map
+                if (L >= total) continue;                              // padding item
+                const int pair = (int)(L / MT), bx = (int)(L - (long)pair * MT), by = pair / KZ, kz = pair - by * KZ;
+                const long m0 = (long)bx * BM, m1 = std::min<long>(m0 + BM, M);
+                const long n_lo = m0 / HoWo, n_hi = (m1 - 1) / HoWo;
+                std::vector<int>& d = item_deps[id];
+                const int zbeg = (int)((long)NK * kz / KZ), zend = (int)((long)NK * (kz + 1) / KZ);
+                for (int k = zbeg; k < zend; ++k) {
+                    if (k < NK1) {           // main segment: whole source samples of the tile's rows (halo included)
+                        const int ci = k / taps;
+                        add_cat(d, a.src0, a.C0, a.src1, n_lo * Ps, (n_hi + 1) * Ps, (long)ci * KC, (long)ci * KC + KC);
+                    } else {                 // 1x1 skip segment at output resolution
+                        const int ci = k - NK1;
+                        add_cat(d, a.s2src0, a.s2C0, a.s2src1, m0, m1, (long)ci * KC, (long)ci * KC + KC);
+                    }
+                }
+                // the epilogue runs in whichever slice arrives last: every slice of the tile carries its reads
+                add_region(d, a.res, m0, m1, (long)by * BN, std::min<long>((long)by * BN + BN, a.Cout));
+                std::sort(d.begin(), d.end());
+                d.erase(std::unique(d.begin(), d.end()), d.end());
+                if ((int)d.size() > LFVDM_CHAIN_MAX_DEPS) return LFVDM_E_UNSUPPORTED;
+            }
+            for (const float* r : {a.src0, a.src1, a.s2src0, a.s2src1, a.res})
+                if (r) touched.insert(r);
+            const bool raw = !(a.gn_out && a.gn_skip_raw);
+            Writer w{s, true, BM, BN, MT, 0, 0, st.flag_base, M, a.Cout};
+            if (raw) {
+                if (!note_write(a.out)) return LFVDM_E_UNSUPPORTED;
+                writers[a.out] = w;
+            }
+            if (a.gn_out) {
+                if (!note_write(a.gn_out)) return LFVDM_E_UNSUPPORTED;
+                writers[a.gn_out] = w;
+            }
+        } else if (st.kind == LFVDM_CHAIN_GN) {
+            const lfvdm_gn_args& g = st.gn;
+            if (!gn_stage_ok(g.C0, g.C1, g.N, g.P) || !g.src0 || !g.out || (g.C1 > 0 && !g.src1) || (g.film && g.film_div <= 0))
+                return LFVDM_E_UNSUPPORTED;
+            const int C = g.C0 + g.C1, cbs4 = C / 64;
+            st.n_items = g.N * cbs4;
+            st.n_flags = st.n_items;
+            st.cfg = st.kz = st.nt2 = 0;
+            item_deps.resize(st.n_items);
+            for (int id = 0; id < st.n_items; ++id) {
+                const int n = id / cbs4, j = id - n * cbs4;
+                std::vector<int>& d = item_deps[id];
+                add_cat(d, g.src0, g.C0, g.src1, (long)n * g.P, (long)(n + 1) * g.P, 64L * j, 64L * j + 64);
+                std::sort(d.begin(), d.end());
+                d.erase(std::unique(d.begin(), d.end()), d.end());
+                if ((int)d.size() > LFVDM_CHAIN_MAX_DEPS) return LFVDM_E_UNSUPPORTED;
+            }
+            touched.insert(g.src0);
+            if (g.src1) touched.insert(g.src1);
+            if (!note_write(g.out)) return LFVDM_E_UNSUPPORTED;
+            writers[g.out] = Writer{s, false, 0, 0, 0, g.P, cbs4, st.flag_base, (long)g.N * g.P, C};
+        } else {
+            return LFVDM_E_SHAPE;
+        }
+        size_t maxd = 0;
+        for (const auto& d : item_deps) maxd = std::max(maxd, d.size());
+        st.dep_stride = (int)maxd + 1;
+        if (ndeps + (long)st.n_items * st.dep_stride > deps_cap) return LFVDM_E_SHAPE;
+        for (int id = 0; id < st.n_items; ++id) {
+            int32_t* row = deps + ndeps + (long)id * st.dep_stride;
+            row[0] = (int32_t)item_deps[id].size();
+            for (size_t k = 0; k < maxd; ++k) row[1 + k] = k < item_deps[id].size() ? item_deps[id][k] : 0;
+        }
+        ndeps += (long)st.n_items * st.dep_stride;
+        nflags += st.n_flags;
+        grid = std::max(grid, std::min(st.n_items, 256));
+    }
+    *deps_used = ndeps;
+    *n_flags_out = (int32_t)nflags;
+    *ws_floats = ws;
+    *cnt_ints = cnt;
+    *grid_out = grid;
+    *lds_out = lds;
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_level_chain(const lfvdm_chain_stage* stages_dev, int n_stages, const int32_t* deps_dev, int32_t* flags,
+                                 int32_t* ctl, int grid, int lds_bytes, double timeout_s, void* stream) {
+    if (!stages_dev || n_stages <= 0 || !deps_dev || !flags || !ctl || grid <= 0 || grid > 256 || lds_bytes < 0 ||
+        lds_bytes > 160 * 1024 || !(timeout_s > 0))
+        return LFVDM_E_SHAPE;
+    static DynLdsLimit limit;
+    if (int rc = limit.ensure(reinterpret_cast<const void*>(&level_chain_kernel), (size_t)lds_bytes)) return rc;
+    const long long ticks = (long long)(timeout_s * 1.0e8);          // s_memrealtime: 100 MHz
+    hipLaunchKernelGGL(level_chain_kernel, dim3((unsigned)grid), dim3(kChainThreads), (size_t)lds_bytes, (hipStream_t)stream,
+                       stages_dev, n_stages, (const int*)deps_dev, (int*)flags, (int*)ctl, ticks);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}

@@ -1,6 +1,7 @@
 // GroupNorm statistics, the fused input compositing + first conv, and the small-M grouped
 // linear ("row-dot") used for every embedding projection.  All HBM/L2-bound; wave = 64.
 #include "common_hip.h"
+#include "gn_wave_body.h"
 
 namespace {
 
@@ -14,9 +15,6 @@ constexpr int GN_GPW = 8;        // groups per workgroup
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAXCW = 256;    // channels per workgroup: supports C <= 1024
 
-__device__ __forceinline__ f32x4 ld_cat(const float* s0, const float* s1, int C0, int C1, size_t pos, int c) {
-    return c < C0 ? ld4(s0 + pos * C0 + c) : ld4(s1 + pos * C1 + (c - C0));
-}
 
 template <int KEEP>      // float4 per thread held in registers between the passes: 8, or 16 for slices of up to 16 pixel lanes' worth
 __global__ __launch_bounds__(GN_THREADS) void gn_coef_kernel(
@@ -165,90 +163,8 @@ __global__ __launch_bounds__(64) void gn_wave_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
     int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats,
     float* __restrict__ act_out, int act_mode) {
-    constexpr int KEEP = 16;
-    const int C = C0 + C1;
-    const int n = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int q = lane & 3, pl = lane >> 2;
-    const int c = blockIdx.y * 16 + q * 4;
-    const size_t pos0 = (size_t)n * P;
-    // coefficient operands first: their latency hides behind the statistics
-    const f32x4 gam = ld4(gamma + c), bet = ld4(beta + c);
-    f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fsh = fsc;
-    if (film) {
-        const float* f = film + (size_t)(n / film_div) * film_ld;
-        fsc = ld4(f + c);
-        fsh = ld4(f + C + c);
-    }
-    f32x4 keep[KEEP];
-#pragma unroll
-    for (int i = 0; i < KEEP; ++i) {
-        const int p = pl + 16 * i;
-        keep[i] = p < P ? ld_cat(s0, s1, C0, C1, pos0 + p, c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    // sum over a group: the lane's own channels of the group, the pixel lanes (xor 4 ... 32), the quad lanes of the group
-    auto group_sum = [&](f32x4 v) -> f32x4 {
-        if constexpr (CG == 2) { const float a = v.x + v.y, b = v.z + v.w; v = (f32x4){a, a, b, b}; }
-        else { const float a = (v.x + v.y) + (v.z + v.w); v = (f32x4){a, a, a, a}; }
-#pragma unroll
-        for (int off = 4; off < 64; off <<= 1) {
-            v.x += __shfl_xor(v.x, off, 64);
-            if constexpr (CG == 2) v.z += __shfl_xor(v.z, off, 64);
-        }
-        if constexpr (CG >= 8) v.x += __shfl_xor(v.x, 1, 64);
-        if constexpr (CG >= 16) v.x += __shfl_xor(v.x, 2, 64);
-        if constexpr (CG == 2) return (f32x4){v.x, v.x, v.z, v.z};
-        else return (f32x4){v.x, v.x, v.x, v.x};
-    };
-    const float inv = 1.0f / (float)(CG * P);
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < KEEP; ++i) sum += keep[i];
-    const f32x4 mean = group_sum(sum) * inv;
-    f32x4 sq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < KEEP; ++i) {
-        if (pl + 16 * i < P) {
-            const f32x4 d = keep[i] - mean;
-            sq += d * d;
-        }
-    }
-    const f32x4 var = group_sum(sq) * inv;
-    f32x4 rstd;
-    rstd.x = 1.0f / sqrtf(var.x + eps); rstd.y = 1.0f / sqrtf(var.y + eps);
-    rstd.z = 1.0f / sqrtf(var.z + eps); rstd.w = 1.0f / sqrtf(var.w + eps);
-    f32x4 A = rstd * gam;
-    f32x4 B = bet - mean * A;
-    if (film) {
-        const f32x4 sc = fsc + (f32x4){1.f, 1.f, 1.f, 1.f};
-        A = A * sc;
-        B = B * sc + fsh;
-    }
-    if (pl == 0) {
-        if (coefA) {
-            st4(coefA + (size_t)n * C + c, A);
-            st4(coefB + (size_t)n * C + c, B);
-        }
-        if (stats) {       // (mean, rstd) per (sample, group): the first channel of a group reports
-            float* st = stats + (size_t)n * 64;
-            if constexpr (CG == 2) {
-                st[2 * (c / 2)] = mean.x; st[2 * (c / 2) + 1] = rstd.x;
-                st[2 * (c / 2 + 1)] = mean.z; st[2 * (c / 2 + 1) + 1] = rstd.z;
-            } else if (c % CG == 0) {
-                st[2 * (c / CG)] = mean.x; st[2 * (c / CG) + 1] = rstd.x;
-            }
-        }
-    }
-    if (act_out == nullptr) return;
-#pragma unroll
-    for (int i = 0; i < KEEP; ++i) {
-        const int p = pl + 16 * i;
-        if (p < P) {
-            f32x4 v = keep[i] * A + B;
-            if (act_mode == LFVDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-            st4(act_out + (pos0 + p) * C + c, v);
-        }
-    }
+    gn_wave_body<CG, false>(blockIdx.x, blockIdx.y, threadIdx.x, s0, s1, C0, C1, P, gamma, beta, film, film_div, film_ld, eps, coefA,
+                            coefB, stats, act_out, act_mode);
 }
 
 // one wave per (sample, 16 channels) when the map and the group width allow it; false = use the workgroup kernels

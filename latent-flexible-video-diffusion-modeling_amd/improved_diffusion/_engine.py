@@ -36,6 +36,12 @@ SPATIAL_FUSED = os.environ.get("LFVDM_SPATIAL_FUSED", "1") != "0"
 GN_EPILOGUE = os.environ.get("LFVDM_GN_EPILOGUE", "1") != "0"
 # LFVDM_NEXT_GN_EPILOGUE=0: never evaluate the NEXT ResBlock's first GroupNorm in a producer's epilogue (A/B aid)
 NEXT_GN_EPILOGUE = os.environ.get("LFVDM_NEXT_GN_EPILOGUE", "1") != "0"
+# LFVDM_LEVEL_CHAIN=0: every launch of the low-resolution levels stays its own launch (A/B aid; the persistent level chain
+# is bitwise the per-launch plan with the same tile codes).  LFVDM_CHAIN_MAX_M: launches with at most this many output rows
+# (N * Ho * Wo) are candidates (640 = the 4x4 and 2x2 levels of the 20-frame, batch-2 headline configuration)
+LEVEL_CHAIN = os.environ.get("LFVDM_LEVEL_CHAIN", "1") != "0"
+CHAIN_MAX_M = int(os.environ.get("LFVDM_CHAIN_MAX_M", "640"))
+CHAIN_TIMEOUT_S = float(os.environ.get("LFVDM_CHAIN_TIMEOUT_S", "2.0"))
 
 
 class _TableBudget:
@@ -94,6 +100,7 @@ class Plan:
         self.steps = []     # (callable, args) executed in order; every callable takes the stream last
         self.packs = []     # (conv weight parameter, packed buffer)
         self.attn_t, self.attn_s = [], []
+        self.chains = []    # persistent level chains (build_chains): dicts with the device tables and the steps they replace
         self._build()
 
     # ------------------------------------------------------------------ helpers
@@ -105,6 +112,10 @@ class Plan:
     def scratch(self, key, rows, cols):
         """Shared scratch tensor [rows][cols] (launches are stream-ordered; a larger request replaces the buffer for
         later steps, earlier steps keep theirs)."""
+        if LEVEL_CHAIN and rows <= CHAIN_MAX_M:
+            # low-resolution levels: a persistent level chain has no launch boundary to order the reuse of a buffer, so
+            # every use gets its own (a few hundred KB each)
+            return self.buf(rows * cols).view(rows, cols)
         pool = self.__dict__.setdefault("_scratch", {})
         t = pool.get(key)
         if t is None or t.numel() < rows * cols:
@@ -654,13 +665,128 @@ class Plan:
                 continue
             a = args[0]._obj
             key = nat.tune_key(a)
+            if LEVEL_CHAIN and a.N * a.Ho * a.Wo <= CHAIN_MAX_M and a.out_mode == nat.OUT_ROWS:
+                # candidate stage of a persistent level chain: the fastest code among the variants the chain kernel holds
+                # (own cache entry: the unrestricted choice of the same shape stays what the other callers get)
+                ckey = key + ("chain",)
+                if ckey not in cache:
+                    cache[ckey] = nat.autotune_launch(a, rounds, reps, chain_only=True)
+                if cache[ckey]:
+                    a.tune = cache[ckey]
+                    tuned += 1
+                    continue
             if key not in cache:
                 cache[key] = nat.autotune_launch(a, rounds, reps)
             a.tune = cache[key]
             tuned += 1
         self.tuned = True
         nat.tune_cache_save()
+        self.build_chains()
         return tuned
+
+    # ------------------------------------------------------------------ persistent level chains
+    def _chain_stage(self, step):
+        """-> ChainStage for a step that can run inside a persistent level chain, else None."""
+        L = nat.lib()
+        fn, args = step
+        st = nat.ChainStage()
+        if fn is L.lfvdm_conv_igemm:
+            a = args[0]._obj
+            if a.N * a.Ho * a.Wo > CHAIN_MAX_M or L.lfvdm_chain_conv_ok(C.byref(a)) != 0:
+                return None
+            st.kind = nat.CHAIN_CONV
+            C.memmove(C.byref(st.conv), C.byref(a), C.sizeof(nat.ConvArgs))
+            return st
+        if fn is L.lfvdm_gn_apply:
+            (src0, src1, C0, C1, N, P, gamma, beta, film, film_div, film_ld, eps, act, out, cA, cB, stats) = args
+            if N * P > CHAIN_MAX_M or cA or cB or stats or L.lfvdm_chain_gn_ok(C0, C1, N, P) != 0:
+                return None
+            st.kind = nat.CHAIN_GN
+            g = st.gn
+            g.src0, g.src1, g.C0, g.C1, g.N, g.P = src0, src1, C0, C1, N, P
+            g.gamma, g.beta, g.film, g.film_div, g.film_ld, g.eps, g.act, g.out = gamma, beta, film, film_div, film_ld, eps, act, out
+            return st
+        return None
+
+    def _make_chain(self, run):
+        """One lfvdm_level_chain step for a run of chainable steps (list of (step, ChainStage)), or None."""
+        L = nat.lib()
+        n = len(run)
+        stages = (nat.ChainStage * n)(*[st for _, st in run])
+        cap = 1 << 20
+        deps = (C.c_int32 * cap)()
+        used, ws_f, cnt_i = C.c_int64(), C.c_int64(), C.c_int64()
+        n_flags, grid, lds = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = L.lfvdm_chain_plan(stages, n, deps, cap, C.byref(used), C.byref(n_flags), C.byref(ws_f), C.byref(cnt_i),
+                                C.byref(grid), C.byref(lds))
+        if rc != 0:
+            return None
+        ws = self.buf(max(1, ws_f.value))
+        cnt = self.buf(max(1, cnt_i.value), dtype=th.int32).zero_()
+        for i in range(n):
+            if stages[i].kind == nat.CHAIN_CONV:
+                cv = stages[i].conv
+                cv.splitk_ws, cv.splitk_cnt = _p(ws) + 4 * stages[i].ws_off, _p(cnt) + 4 * stages[i].cnt_off
+                cv.splitk_ws_floats, cv.splitk_cnt_ints = ws.numel() - stages[i].ws_off, cnt.numel() - stages[i].cnt_off
+        stages_dev = th.frombuffer(bytearray(bytes(memoryview(stages))), dtype=th.uint8).to(self.dev)
+        deps_dev = th.tensor(list(deps[:max(1, used.value)]), dtype=th.int32, device=self.dev)
+        flags = self.buf(max(1, n_flags.value), dtype=th.int32).zero_()
+        ctl = self.buf(nat.CHAIN_CTL_INTS, dtype=th.int32).zero_()
+        self.keep += [stages_dev, deps_dev]
+        ch = dict(steps=[st for st, _ in run], n=n, ctl=ctl, grid=grid.value, lds=lds.value, items=[s.n_items for s in stages],
+                  kinds=[s.kind for s in stages])
+        ch["step"] = (L.lfvdm_level_chain, (_p(stages_dev), n, _p(deps_dev), _p(flags), _p(ctl), grid.value, lds.value,
+                                            CHAIN_TIMEOUT_S))
+        return ch
+
+    def build_chains(self):
+        """Replace every run of >= 2 consecutive chainable launches (tuned implicit GEMMs and one-wave GroupNorms of the
+        low-resolution levels) by ONE persistent launch (lfvdm_level_chain).  Idempotent; called by ``autotune``."""
+        if not LEVEL_CHAIN or self.chains or getattr(self, "chains_off", False):
+            return 0
+        head_last = self.head["step"] == len(self.steps) - 1
+        out, run = [], []
+
+        def flush():
+            ch = self._make_chain(run) if len(run) >= 2 else None
+            if ch is None:
+                out.extend(st for st, _ in run)
+            else:
+                self.chains.append(ch)
+                out.append(ch["step"])
+            run.clear()
+
+        for step in self.steps:
+            st = self._chain_stage(step)
+            if st is not None:
+                run.append((step, st))
+            else:
+                flush()
+                out.append(step)
+        flush()
+        self.steps = out
+        if head_last:
+            self.head["step"] = len(self.steps) - 1
+        return len(self.chains)
+
+    def disable_chains(self):
+        """Back to one launch per stage (after a chain reported a timeout, or for A/B runs)."""
+        if not self.chains:
+            self.chains_off = True
+            return
+        head_last = self.head["step"] == len(self.steps) - 1
+        by_step = {id(ch["step"]): ch for ch in self.chains}
+        out = []
+        for step in self.steps:
+            ch = by_step.get(id(step))
+            out.extend(ch["steps"] if ch is not None else [step])
+        self.steps, self.chains, self.chains_off = out, [], True
+        if head_last:
+            self.head["step"] = len(self.steps) - 1
+
+    def chains_aborted(self):
+        """Did a wait inside a persistent level chain time out?  (synchronises)"""
+        return any(int(ch["ctl"][nat.CHAIN_CTL_ABORT].item()) != 0 for ch in self.chains)
 
     # ------------------------------------------------------------------ run
     def weight_signature(self):

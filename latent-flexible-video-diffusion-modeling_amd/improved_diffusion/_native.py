@@ -40,6 +40,23 @@ class ConvArgs(C.Structure):
     ]
 
 
+class GnArgs(C.Structure):
+    _fields_ = [("src0", c_fp), ("src1", c_fp), ("C0", C.c_int32), ("C1", C.c_int32), ("N", C.c_int32), ("P", C.c_int32),
+                ("gamma", c_fp), ("beta", c_fp), ("film", c_fp), ("film_div", C.c_int32), ("film_ld", C.c_int32),
+                ("eps", C.c_float), ("act", C.c_int32), ("out", c_fp)]
+
+
+class ChainStage(C.Structure):
+    """lfvdm_chain_stage (include/lfvdm_hip.h): one stage of a persistent level chain."""
+    _fields_ = [("kind", C.c_int32), ("n_items", C.c_int32), ("flag_base", C.c_int32), ("n_flags", C.c_int32),
+                ("dep_base", C.c_int32), ("dep_stride", C.c_int32), ("cfg", C.c_int32), ("kz", C.c_int32), ("nt2", C.c_int32),
+                ("pad_", C.c_int32), ("ws_off", C.c_int64), ("cnt_off", C.c_int64), ("conv", ConvArgs), ("gn", GnArgs)]
+
+
+CHAIN_CONV, CHAIN_GN = 0, 1
+CHAIN_CTL_EPOCH, CHAIN_CTL_EXIT, CHAIN_CTL_ABORT, CHAIN_CTL_INTS = 0, 32, 64, 96
+
+
 class AdamWArgs(C.Structure):
     _fields_ = [("p", c_fp), ("g", c_fp), ("m", c_fp), ("v", c_fp), ("ema", c_fp * 4), ("ema_rate", C.c_float * 4),
                 ("n_ema", C.c_int32), ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
@@ -155,6 +172,11 @@ _SIGS = {
     "lfvdm_p_sample": ([c_fp] * 9 + [c_i] + [c_fp] * 3 + [c_i, c_i, c_fp], c_i),
     "lfvdm_masked_mse": ([c_fp] * 4 + [c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_prepare_batch": ([c_fp] * 6 + [c_i] * 4 + [c_fp], c_i),
+    "lfvdm_chain_plan": ([C.POINTER(ChainStage), c_i, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                          C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], c_i),
+    "lfvdm_chain_conv_ok": ([C.POINTER(ConvArgs)], c_i),
+    "lfvdm_chain_gn_ok": ([c_i, c_i, c_i, c_i], c_i),
+    "lfvdm_level_chain": ([c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_double, c_fp], c_i),
     "lfvdm_flag_add": ([c_fp, c_fp], c_i),
     "lfvdm_flag_wait": ([c_fp, c_i, C.c_double, c_fp, c_fp], c_i),
 }
@@ -279,10 +301,11 @@ def tune_cache_save():
         pass
 
 
-def autotune_launch(a, rounds=3, reps=6):
+def autotune_launch(a, rounds=3, reps=6, chain_only=False):
     """Time every legal variant of this implicit-GEMM launch (the launch is idempotent) and return the fastest
     code.  Must not be called while the stream is capturing.  LFVDM_TUNE_REPS / LFVDM_TUNE_ROUNDS: longer measurements
-    (what the committed table was made with: 20 x 5)."""
+    (what the committed table was made with: 20 x 5).  chain_only: only the variants the persistent level chain holds
+    (lfvdm_chain_conv_ok: 4-wave tiles, 32-channel chunks, plain split-K); 0 if there is none."""
     rounds = int(os.environ.get("LFVDM_TUNE_ROUNDS", rounds))
     reps = int(os.environ.get("LFVDM_TUNE_REPS", reps))
     L, s = lib(), stream()
@@ -290,8 +313,10 @@ def autotune_launch(a, rounds=3, reps=6):
     n = L.lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     best, best_t = 0, float("inf")
-    for code in [0] + [codes[i] for i in range(n)]:
+    for code in ([] if chain_only else [0]) + [codes[i] for i in range(n)]:
         a.tune = code
+        if chain_only and L.lfvdm_chain_conv_ok(C.byref(a)) != 0:
+            continue
         if L.lfvdm_conv_igemm(C.byref(a), s) != 0:
             continue
         t_min = float("inf")

@@ -541,6 +541,14 @@ class GraphSampler:
     def begin(self, img, model_kwargs):
         pl = self.plan
         B, T = pl.B, pl.T
+        if pl.chains and pl.chains_aborted():
+            # a wait inside a persistent level chain gave up (LFVDM_CHAIN_TIMEOUT_S): the samples of the previous chain are
+            # not to be trusted - say so, and run this plan one launch per stage from now on
+            import sys
+            print("[lfvdm] ERROR: a persistent level chain timed out; falling back to the per-launch plan", file=sys.stderr, flush=True)
+            pl.disable_chains()
+            self.graph = self.graph_k = None
+            self.chain_timeouts = getattr(self, "chain_timeouts", 0) + 1
         if pl._sig != pl.weight_signature():
             pl.refresh_weights()  # parameters changed since the last chain
         with th.no_grad():
