@@ -845,6 +845,16 @@ def main():
                   "steps_per_s_public_api": round(diffusion.num_timesteps / public_wall, 2),
                   "finite": bool(th.isfinite(pub).all().item()),
                   "note": "diffusion.p_sample_loop(model, shape, model_kwargs=..., return_decoded=False), best of 2 warm chains"}
+    # persistent level chains of the TIMED plan, and that none of their waits timed out (a timed-out chain leaves garbage in
+    # the samples and the sampler falls back to one launch per stage: neither may end up in the line)
+    pl_ = sampler.plan
+    chains_rec = {"enabled": bool(pl_.chains), "chains": [{"stages": c["n"], "grid": c["grid"], "lds_bytes": c["lds"],
+                                                          "work_items": c["items"]} for c in pl_.chains],
+                  "launches_replaced": sum(c["n"] for c in pl_.chains) - len(pl_.chains),
+                  "timed_out": bool(pl_.chains_aborted()) or bool(getattr(sampler, "chain_timeouts", 0)),
+                  "fell_back": bool(getattr(pl_, "chains_off", False)) and os.environ.get("LFVDM_LEVEL_CHAIN", "1") != "0"}
+    if chains_rec["timed_out"] or chains_rec["fell_back"]:
+        raise SystemExit("bench.py: a persistent level chain timed out (LFVDM_CHAIN_TIMEOUT_S) during the timed run")
     train = None
     if args.train_steps > 0:
         del sampler
@@ -881,6 +891,7 @@ def main():
                    "steps_per_graph_launch": int(getattr(sampler, "K", 1)),
                    "gpus_requested": args.gpus},
     }
+    out["level_chains"] = chains_rec
     # ---- the collective, self-checked: what the launcher asked for is what the process group is
     rehearsal = world > 1 and backend != "nccl"
     out["collective_world_size"] = dist.get_world_size() if world > 1 else 1

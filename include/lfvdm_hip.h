@@ -121,7 +121,8 @@ typedef struct lfvdm_conv_args {
     int32_t gn_act;         /* LFVDM_ACT_* */
     int32_t gn_skip_raw;
     float gn_eps;
-    int32_t gn_pad_;
+    int32_t gn_general;     /* non-zero: the general (LDS tile) form of the fused GroupNorm even where the register form
+                             * applies (P and Cout/32 powers of two) - A/B and test aid, same statistics */
 } lfvdm_conv_args;
 
 int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream);

@@ -83,6 +83,7 @@ struct ChainCtx {
     int gen;                  // generation of this launch: a flag equal to it means "complete in this launch"
     int* abort_word;          // raised by any poller whose wall-clock timeout expired
     long long timeout_ticks;  // of the 100 MHz s_memrealtime clock
+    int stage;                // stage index (diagnostic stamps only)
 };
 
 // Poll (lanes < ndeps of the calling wave, one line each) until every dependency carries this launch's generation.
@@ -265,6 +266,91 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
+    // ---- epilogue operands: bias, residual rows and the coefficients of the fused GroupNorm depend on nothing this
+    // launch computes (in a chain: on tiles whose flags this item has already seen), and their ~0.5-0.8 us of cold-load
+    // latency used to sit behind the split-K seam, on the path of the tile's last arriver (round-5 chain stamps: epi
+    // 0.45-0.7 us, gn 1.1-1.5 us once the statistics had gone to registers; requested just in front of the seam they only
+    // moved into its vmcnt drain; requested inside the K loop, into the counted vmcnt of its next chunk: vmcnt counts in
+    // order).  Small tiles (EPV <= 2 float4 per thread: the latency-bound low-resolution launches) request them FIRST, in
+    // front of the filter pieces; large tiles - where the registers are worth more than the latency - in front of the
+    // seam.  A thread owns 4 consecutive output columns of EPV rows.
+    constexpr int QN = BN / 4;                              // float4 per tile row
+    constexpr int EPV = (BM * QN + CF::NTHREADS - 1) / CF::NTHREADS;   // float4 per thread
+    constexpr int RSTEP = CF::NTHREADS / QN;
+    static_assert(CF::NTHREADS % QN == 0, "column ownership");
+    const bool nchw = p.out_mode == LFVDM_OUT_NCHW;
+    const bool gn = p.gn_out != nullptr;
+    const int c4 = (tid % QN) * 4;
+    const int row0 = tid / QN;
+    const int co = n0 + c4;
+    const bool cok = co < p.Cout && row0 < BM;   // Cout % 4 == 0 is checked by the launcher for this layout
+    const int cc = cok ? co : 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 rv[EPV], ra[EPV], rb[EPV];
+    f32x4 gam = {0.f, 0.f, 0.f, 0.f}, bet = gam, fsc[EPV], fsh[EPV];
+    int mo[EPV];
+    constexpr bool EPI_EARLY = EPV <= 2;
+    auto load_epilogue_operands = [&](bool params, bool residual) {      // each part exactly once per tile
+      if (!nchw) {
+        if (params) {
+            if (p.bias) bsum += ld4(p.bias + cc);
+            if (p.bias2) bsum += ld4(p.bias2 + cc);
+        }
+        const float rHoWo = 1.0f / (float)HoWo;
+        // parity classes: class row (n, i, j) of the source grid -> output row (n, 2i + py, 2j + px)
+        const int sHW = p.Hs * p.Ws;
+        const float rsHW = __builtin_amdgcn_rcpf((float)sHW), rsW = __builtin_amdgcn_rcpf((float)p.Ws);
+        auto out_row = [&](int m) {
+            if (!par) return m;
+            const int n = fast_div(m, sHW, rsHW), rem = m - n * sHW;
+            const int i = fast_div(rem, p.Ws, rsW), j = rem - i * p.Ws;
+            return (n * p.Ho + 2 * i + ppy) * p.Wo + 2 * j + ppx;
+        };
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) {
+            const int m = min(m0 + min(row0 + i * RSTEP, BM - 1), M - 1);
+            if (residual) {
+                mo[i] = out_row(m);
+                rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.res) {
+                    if constexpr (CHAIN) rv[i] = ld4_sc1(whole_rsrc(p.res), (unsigned)(mo[i] * p.ldr + cc) * 4u);
+                    else rv[i] = ld4(p.res + (unsigned)(mo[i] * p.ldr + cc));
+                }
+            }
+            if (params) {
+                ra[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                rb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.resA) {
+                    const int n = fast_div(m, HoWo, rHoWo);
+                    ra[i] = ld4(p.resA + (unsigned)(n * p.Cout + cc));
+                    rb[i] = ld4(p.resB + (unsigned)(n * p.Cout + cc));
+                }
+            }
+        }
+        if (gn && params) {
+            const float rPF = __builtin_amdgcn_rcpf((float)(HoWo * p.gn_film_div));
+            if (cok) {
+                gam = ld4(p.gn_gamma + cc);
+                bet = ld4(p.gn_beta + cc);
+            }
+#pragma unroll
+            for (int i = 0; i < EPV; ++i) {
+                fsc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                fsh[i] = fsc[i];
+                const int m = min(m0 + min(row0 + i * RSTEP, BM - 1), M - 1);
+                if (p.gn_film && cok) {
+                    const float* fl = p.gn_film + (size_t)fast_div(m, HoWo * p.gn_film_div, rPF) * p.gn_film_ld + cc;
+                    fsc[i] = ld4(fl);
+                    fsh[i] = ld4(fl + p.Cout);
+                }
+            }
+        }
+    }
+    };
+    // small tiles: parameters at once (in flight while the filter pieces are issued and - chain stage - while the item
+    // waits for its producers); the residual rows with them, or - chain stage - behind the poll (K loop, first chunk)
+    if constexpr (EPI_EARLY) load_epilogue_operands(true, !CHAIN);
+
   {
     // ---- LDS-DMA main loop.  `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 B to ONE contiguous 1 KiB piece
     // of LDS (wave-uniform base + lane * 16) while every lane supplies its own source offset.  The stage image is
@@ -419,6 +505,9 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
            form, which lets the scheduler slide the wait + barrier of the next step above the last MFMA group, \
            was the fastest on every shape (tools/ab_libs.sh, tools/ab_shapes.sh) */                            \
         issue(kbeg + (IT_) + GL - 1, ((S_) + GL - 1) % GL);                                                    \
+        /* chain stage, small tile: the residual rows (another stage's tile: legal only behind the poll) are     \
+           requested behind the first chunk's wait and land under the MFMAs */                                   \
+        if constexpr (EPI_EARLY && CHAIN) { if ((IT_) == 0) load_epilogue_operands(false, true); }               \
         const float* st_ = gbase + (S_) * CF::STAGE;                                                           \
         _Pragma("unroll") for (int g = 0; g < KC / 8; ++g) {                                                   \
             const f32x4 a4 = ld4(st_ + offA[g]);                                                               \
@@ -440,11 +529,13 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
             // the producers' tiles: polled by wave 0 (its filter pieces are in flight; the first poll result queues behind
             // them), the other waves park at the barrier - an LDS-only barrier, the DMA stays in flight
             __shared__ int s_go;
+            STAMP(16);
             if (wave == 0) {
                 const bool ok = chain_poll(cx, lane);
                 if (lane == 0) s_go = ok ? 1 : 0;
             }
             lds_barrier();
+            STAMP(17);
             if (!s_go) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 return false;
@@ -492,6 +583,8 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
     // visibility follows the agent-scope release/acquire recipe of the CDNA guide (G16): stores ->
     // every wave s_waitcnt vmcnt(0) -> barrier -> lane 0: release fence + drained ticket atomic;
     // last arriver: acquire fence -> barrier -> plain loads.
+    if constexpr (!EPI_EARLY) load_epilogue_operands(true, true);
+
     bool do_epilogue = true;
     if (KZ > 1) {
         // Slabs are published WRITE-THROUGH (16-byte `sc1` stores: the bytes leave the XCD's L2 at once, no dirty
@@ -507,17 +600,17 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
         const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, BM * BN * 4, 0x00020000);
 #endif
         for (int e = tid; e < BM * QNs; e += CF::NTHREADS) {
-            const int row = e / QNs, c4 = (e - row * QNs) * 4;
+            const int row = e / QNs, c4s = (e - row * QNs) * 4;
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < WK; ++w) {
-                const float* r = smem + w * CF::GROUP_LDS + row * RED_LD + c4;
+                const float* r = smem + w * CF::GROUP_LDS + row * RED_LD + c4s;
                 t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
             }
 #ifdef LFVDM_SEAM_FENCES
-            st4(slab + row * BN + c4, t);
+            st4(slab + row * BN + c4s, t);
 #else
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rs_slab, (row * BN + c4) * 4, 0, 16 /* sc1 */);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rs_slab, (row * BN + c4s) * 4, 0, 16 /* sc1 */);
 #endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -554,21 +647,21 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
             const __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, KZ * BM * BN * 4, 0x00020000);
 #endif
             for (int e = tid; e < BM * QNs; e += CF::NTHREADS) {
-                const int row = e / QNs, c4 = (e - row * QNs) * 4;
+                const int row = e / QNs, c4s = (e - row * QNs) * 4;
                 f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #ifdef LFVDM_SEAM_FENCES
-                for (int z = 0; z < KZ; ++z) t += ld4(base + (size_t)z * (BM * BN) + row * BN + c4);
+                for (int z = 0; z < KZ; ++z) t += ld4(base + (size_t)z * (BM * BN) + row * BN + c4s);
 #else
                 // all slab loads of the element in flight at once (KZ <= 8: cfg_valid), summed in slice order
                 u32x4 sv[8];
 #pragma unroll
                 for (int z = 0; z < 8; ++z)
-                    sv[z] = __builtin_amdgcn_raw_buffer_load_b128(rs_all, z < KZ ? (z * (BM * BN) + row * BN + c4) * 4 : -1, 0, 16 /* sc1 */);
+                    sv[z] = __builtin_amdgcn_raw_buffer_load_b128(rs_all, z < KZ ? (z * (BM * BN) + row * BN + c4s) * 4 : -1, 0, 16 /* sc1 */);
 #pragma unroll
                 for (int z = 0; z < 8; ++z)
                     if (z < KZ) t += __builtin_bit_cast(f32x4, sv[z]);
 #endif
-                float* r = smem + row * RED_LD + c4;
+                float* r = smem + row * RED_LD + c4s;
                 r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
             }
             lds_barrier();
@@ -580,50 +673,7 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
 
     // ---- epilogue: a thread owns 4 consecutive output columns of EPV rows: bias is read once as a
     // float4, all residual loads are issued back to back, stores are 16-byte.
-    constexpr int QN = BN / 4;                              // float4 per tile row
-    constexpr int EPV = (BM * QN + CF::NTHREADS - 1) / CF::NTHREADS;   // float4 per thread
-    const bool nchw = p.out_mode == LFVDM_OUT_NCHW;
     if (!nchw) {
-        const int c4 = (tid % QN) * 4;
-        const int row0 = tid / QN;
-        constexpr int RSTEP = CF::NTHREADS / QN;
-        static_assert(CF::NTHREADS % QN == 0, "column ownership");
-        const int co = n0 + c4;
-        const bool cok = co < p.Cout && row0 < BM;   // Cout % 4 == 0 is checked by the launcher for this layout
-        const int cc = cok ? co : 0;
-        f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bsum += ld4(p.bias + cc);
-        if (p.bias2) bsum += ld4(p.bias2 + cc);
-        f32x4 rv[EPV], ra[EPV], rb[EPV];
-        const float rHoWo = 1.0f / (float)HoWo;
-        // parity classes: class row (n, i, j) of the source grid -> output row (n, 2i + py, 2j + px)
-        const int sHW = p.Hs * p.Ws;
-        const float rsHW = __builtin_amdgcn_rcpf((float)sHW), rsW = __builtin_amdgcn_rcpf((float)p.Ws);
-        auto out_row = [&](int m) {
-            if (!par) return m;
-            const int n = fast_div(m, sHW, rsHW), rem = m - n * sHW;
-            const int i = fast_div(rem, p.Ws, rsW), j = rem - i * p.Ws;
-            return (n * p.Ho + 2 * i + ppy) * p.Wo + 2 * j + ppx;
-        };
-        int mo[EPV];
-#pragma unroll
-        for (int i = 0; i < EPV; ++i) {
-            const int m = min(m0 + min(row0 + i * RSTEP, BM - 1), M - 1);
-            mo[i] = out_row(m);
-            rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            ra[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
-            rb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (p.res) {
-                if constexpr (CHAIN) rv[i] = ld4_sc1(whole_rsrc(p.res), (unsigned)(mo[i] * p.ldr + cc) * 4u);
-                else rv[i] = ld4(p.res + (unsigned)(mo[i] * p.ldr + cc));
-            }
-            if (p.resA) {
-                const int n = fast_div(m, HoWo, rHoWo);
-                ra[i] = ld4(p.resA + (unsigned)(n * p.Cout + cc));
-                rb[i] = ld4(p.resB + (unsigned)(n * p.Cout + cc));
-            }
-        }
-        const bool gn = p.gn_out != nullptr;
         const bool store_raw = !gn || p.gn_skip_raw == 0;
         f32x4 tv[EPV];
 #pragma unroll
@@ -650,24 +700,130 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
             // exact two-pass mean / variance per (sample, group) unit, then the affine on the registers.
             // the per-channel / per-sample coefficients are fetched first: their latency hides behind the statistics
             const int P = HoWo, gw = p.Cout >> 5;
-            const float rPF = __builtin_amdgcn_rcpf((float)(P * p.gn_film_div)), rP = __builtin_amdgcn_rcpf((float)P),
-                        rgw = __builtin_amdgcn_rcpf((float)gw);       // fast_div operands here are < 2^21
-            f32x4 gam = {0.f, 0.f, 0.f, 0.f}, bet = gam, fsc[EPV], fsh[EPV];
-            if (cok) {
-                gam = ld4(p.gn_gamma + cc);
-                bet = ld4(p.gn_beta + cc);
-            }
+            const float rP = __builtin_amdgcn_rcpf((float)P), rgw = __builtin_amdgcn_rcpf((float)gw);   // fast_div operands here are < 2^21
+            // ---- register form (round 5): P and gw powers of two (every 64 ... 512-channel layer on 2x2 ... 8x8 maps).  The
+            // finished values stay in their owners' registers; a unit's sums are lane butterflies over the quads of the
+            // group and the rows of the sample inside a wave, plus - where a sample spans several waves - ONE exchange
+            // through LDS per pass.  Two barriers instead of four, no tile rewrite, no per-unit loops: the general form
+            // below spends ~2 us on a 32 x 32 tile in LDS round trips, divisions and serial row loops
+            // (profiles/r03_conv_phase_stamps.txt, r05 chain stamps).  Exact two-pass statistics as before.
+            constexpr int RPW = 64 / QN;                       // tile rows per wave (QN = float4 per tile row: 8, 16 or 32)
+            constexpr int QSH = QN == 8 ? 3 : QN == 16 ? 4 : 5;
+            static_assert(QN == 8 || QN == 16 || QN == 32, "epilogue lane map");
+            const bool pow2 = (P & (P - 1)) == 0 && (gw & (gw - 1)) == 0 && gw >= 2 && gw <= 16 && !p.gn_general;
+            if (pow2) {
+                const int q = tid & (QN - 1);
+                const bool two = gw == 2;                      // two groups per float4
+                const int gq = gw >= 4 ? gw >> 2 : 1;          // float4 quads per group
+                const int rw = P < RPW ? P : RPW;              // rows of a sample inside one wave
+                const int ipg = P > RSTEP ? P / RSTEP : 1;     // consecutive i (row0 + i * RSTEP) of one sample
+                const int wps = P > RPW ? (P < RSTEP ? P : RSTEP) / RPW : 1;      // waves a sample spans
+                const float inv = 1.0f / (float)(P * gw);
+                float* part = smem + BM * RED_LD;              // [pass][i][wave][QN][2], behind group 0's reduction tile
+                f32x2 sv[EPV];
+                auto combine = [&](int pass) {
+                    // sv[j] (j = first i of an i-group) holds this thread's partial of its unit(s): sum it over the unit
 #pragma unroll
-            for (int i = 0; i < EPV; ++i) {
-                fsc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                fsh[i] = fsc[i];
-                const int m = min(m0 + min(row0 + i * RSTEP, BM - 1), M - 1);
-                if (p.gn_film && cok) {
-                    const float* fl = p.gn_film + (size_t)fast_div(m, P * p.gn_film_div, rPF) * p.gn_film_ld + cc;
-                    fsc[i] = ld4(fl);
-                    fsh[i] = ld4(fl + p.Cout);
+                    for (int j = 0; j < EPV; ++j) {
+                        f32x2 v = sv[j];
+                        for (int o = 1; o < gq; o <<= 1) v.x += __shfl_xor(v.x, o, 64);
+                        for (int o = QN; o < QN * rw; o <<= 1) {
+                            v.x += __shfl_xor(v.x, o, 64);
+                            if (two) v.y += __shfl_xor(v.y, o, 64);
+                        }
+                        sv[j] = v;
+                    }
+                    if (wps > 1) {          // workgroup-uniform
+                        float* pp = part + pass * (EPV * (CF::NTHREADS / 64) * QN * 2);
+                        if ((lane >> QSH) == 0) {
+#pragma unroll
+                            for (int j = 0; j < EPV; ++j) {
+                                float* w2 = pp + ((j * (CF::NTHREADS / 64) + wave) * QN + q) * 2;
+                                w2[0] = sv[j].x;
+                                w2[1] = sv[j].y;
+                            }
+                        }
+                        lds_barrier();
+                        const int w0 = (wave / wps) * wps;
+#pragma unroll
+                        for (int j = 0; j < EPV; ++j) {
+                            f32x2 t = {0.f, 0.f};
+                            for (int k = 0; k < wps; ++k) {
+                                const float* r2 = pp + ((j * (CF::NTHREADS / 64) + w0 + k) * QN + q) * 2;
+                                t.x += r2[0];
+                                t.y += r2[1];
+                            }
+                            sv[j] = t;
+                        }
+                    }
+                };
+                // pass 1: sums
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) sv[j] = (f32x2){0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) {
+                    const int j = (i / ipg) * ipg;             // (ipg is a power of two <= EPV)
+                    const f32x4 t = tv[i];
+                    const f32x2 a = two ? (f32x2){t.x + t.y, t.z + t.w} : (f32x2){(t.x + t.y) + (t.z + t.w), 0.f};
+#pragma unroll
+                    for (int jj = 0; jj < EPV; ++jj)
+                        if (jj == j) sv[jj] += a;
                 }
-            }
+                combine(0);
+                f32x4 mean4[EPV];
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) {
+                    const int j = (i / ipg) * ipg;
+                    f32x2 mu = {0.f, 0.f};
+#pragma unroll
+                    for (int jj = 0; jj < EPV; ++jj)
+                        if (jj == j) mu = sv[jj] * inv;
+                    mean4[i] = two ? (f32x4){mu.x, mu.x, mu.y, mu.y} : (f32x4){mu.x, mu.x, mu.x, mu.x};
+                }
+                // pass 2: centred squares
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) sv[j] = (f32x2){0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < EPV; ++i) {
+                    const int j = (i / ipg) * ipg;
+                    const f32x4 d = tv[i] - mean4[i];
+                    const f32x2 a = two ? (f32x2){d.x * d.x + d.y * d.y, d.z * d.z + d.w * d.w}
+                                        : (f32x2){(d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w), 0.f};
+#pragma unroll
+                    for (int jj = 0; jj < EPV; ++jj)
+                        if (jj == j) sv[jj] += a;
+                }
+                STAMP(12);
+                combine(1);
+                STAMP(13);
+                STAMP(14);
+                if (cok) {
+#pragma unroll
+                    for (int i = 0; i < EPV; ++i) {
+                        const int row = row0 + i * RSTEP;
+                        const int m = m0 + row;
+                        if (row < BM && m < M) {
+                            const int j = (i / ipg) * ipg;
+                            f32x2 var = {0.f, 0.f};
+#pragma unroll
+                            for (int jj = 0; jj < EPV; ++jj)
+                                if (jj == j) var = sv[jj] * inv;
+                            const float r0 = 1.0f / sqrtf(var.x + p.gn_eps), r1 = two ? 1.0f / sqrtf(var.y + p.gn_eps) : r0;
+                            f32x4 A = (f32x4){r0, r0, r1, r1} * gam;
+                            f32x4 B = bet - mean4[i] * A;
+                            if (p.gn_film) {
+                                const f32x4 sc = fsc[i] + (f32x4){1.f, 1.f, 1.f, 1.f};
+                                A = A * sc;
+                                B = B * sc + fsh[i];
+                            }
+                            f32x4 y = tv[i] * A + B;
+                            if (p.gn_act == LFVDM_ACT_SILU) { y.x = silu_f(y.x); y.y = silu_f(y.y); y.z = silu_f(y.z); y.w = silu_f(y.w); }
+                            if constexpr (CHAIN) st4_sc1(whole_rsrc(p.gn_out), (unsigned)(m * p.Cout + co) * 4u, y);
+                            else st4(p.gn_out + ((size_t)m * p.Cout + co), y);
+                        }
+                    }
+                }
+            } else {
             lds_barrier();                 // every partial-tile read above is done before group 0's tile is rewritten
 #pragma unroll
             for (int i = 0; i < EPV; ++i) {
@@ -741,6 +897,7 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
                     }
                 }
             }
+            }       // general form
         }
         STAMP(8);
     } else {
@@ -768,6 +925,7 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (tid == 0) __hip_atomic_store(cx.flags + cx.flag_base + (int)tile_id, cx.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        STAMP(18);
     }
     return true;
 }

@@ -15,7 +15,26 @@
 
 #include "common_hip.h"
 
+#ifdef LFVDM_CHAIN_STAMP
+// diagnostic build only (tools/chain_stamps.py; never compiled into the product): thread 0 of every workgroup stamps the
+// 100 MHz s_memrealtime clock, common to all CUs, at the phase boundaries of every stage it works on
+constexpr int kCsStages = 64, kCsWGs = 256, kCsN = 20;
+__device__ unsigned long long g_cstamps[kCsStages * kCsWGs * kCsN];
+#define CSTAMP(stage, i) do { if (threadIdx.x == 0 && (stage) < kCsStages)                                                   \
+        g_cstamps[((stage) * kCsWGs + blockIdx.x) * kCsN + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP(i) CSTAMP(cx.stage, i)
+extern "C" int lfvdm_debug_chain_stamps(unsigned long long* host_out, int clear) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_cstamps), sizeof(g_cstamps)) != hipSuccess) return 2;
+    if (clear) {
+        static unsigned long long zeros[kCsStages * kCsWGs * kCsN];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_cstamps), zeros, sizeof(zeros)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#else
+#define CSTAMP(stage, i) do {} while (0)
 #define STAMP(i) do {} while (0)
+#endif
 #include "conv_igemm_body.h"
 #include "gn_wave_body.h"
 
@@ -63,6 +82,7 @@ __global__ __launch_bounds__(kChainThreads) void level_chain_kernel(const lfvdm_
             cx.gen = gen;
             cx.abort_word = ctl + LFVDM_CHAIN_CTL_ABORT;
             cx.timeout_ticks = timeout_ticks;
+            cx.stage = s;
             if (kind == LFVDM_CHAIN_CONV) {
                 switch (st->cfg) {
                     case 0: alive = run_conv<1, 1, 4, 1, true, 2>(st, cx); break;
@@ -77,6 +97,8 @@ __global__ __launch_bounds__(kChainThreads) void level_chain_kernel(const lfvdm_
             } else {
                 // GroupNorm item = 4 waves = 4 consecutive (sample, 16-channel) units of one sample
                 const lfvdm_gn_args g = *(const lfvdm_gn_args*)&st->gn;
+                CSTAMP(s, 0);
+                CSTAMP(s, 16);
                 if (wave == 0) {
                     const bool ok = chain_poll(cx, lane);
                     if (lane == 0) s_go2 = ok ? 1 : 0;
@@ -86,6 +108,7 @@ __global__ __launch_bounds__(kChainThreads) void level_chain_kernel(const lfvdm_
                     alive = false;
                     break;
                 }
+                CSTAMP(s, 17);
                 const int C = g.C0 + g.C1, cbs = C >> 4, cg = C >> 5;
                 const int u = item * 4 + wave;
                 if (u < g.N * cbs) {
@@ -103,6 +126,7 @@ __global__ __launch_bounds__(kChainThreads) void level_chain_kernel(const lfvdm_
                 __syncthreads();
                 if (tid == 0)
                     __hip_atomic_store(flags + cx.flag_base + item, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                CSTAMP(s, 18);
             }
         }
     }

@@ -668,7 +668,7 @@ class Plan:
             if LEVEL_CHAIN and a.N * a.Ho * a.Wo <= CHAIN_MAX_M and a.out_mode == nat.OUT_ROWS:
                 # candidate stage of a persistent level chain: the fastest code among the variants the chain kernel holds
                 # (own cache entry: the unrestricted choice of the same shape stays what the other callers get)
-                ckey = key + ("chain",)
+                ckey = key + (nat.TUNE_CHAIN,)
                 if ckey not in cache:
                     cache[ckey] = nat.autotune_launch(a, rounds, reps, chain_only=True)
                 if cache[ckey]:
@@ -681,7 +681,8 @@ class Plan:
             tuned += 1
         self.tuned = True
         nat.tune_cache_save()
-        self.build_chains()
+        if self.build_chains() and os.environ.get("LFVDM_CHAIN_TUNE", "1") != "0":
+            self.tune_chains()
         return tuned
 
     # ------------------------------------------------------------------ persistent level chains
@@ -708,8 +709,9 @@ class Plan:
             return st
         return None
 
-    def _make_chain(self, run):
-        """One lfvdm_level_chain step for a run of chainable steps (list of (step, ChainStage)), or None."""
+    def _make_chain(self, run, keep=True):
+        """One lfvdm_level_chain step for a run of chainable steps (list of (step, ChainStage)), or None.  keep=False: the
+        device tables live only as long as the returned dict (the in-chain tuner builds hundreds of candidates)."""
         L = nat.lib()
         n = len(run)
         stages = (nat.ChainStage * n)(*[st for _, st in run])
@@ -721,23 +723,99 @@ class Plan:
                                 C.byref(grid), C.byref(lds))
         if rc != 0:
             return None
-        ws = self.buf(max(1, ws_f.value))
-        cnt = self.buf(max(1, cnt_i.value), dtype=th.int32).zero_()
+        ws = th.empty(max(1, ws_f.value), device=self.dev)
+        cnt = th.zeros(max(1, cnt_i.value), dtype=th.int32, device=self.dev)
         for i in range(n):
             if stages[i].kind == nat.CHAIN_CONV:
                 cv = stages[i].conv
                 cv.splitk_ws, cv.splitk_cnt = _p(ws) + 4 * stages[i].ws_off, _p(cnt) + 4 * stages[i].cnt_off
                 cv.splitk_ws_floats, cv.splitk_cnt_ints = ws.numel() - stages[i].ws_off, cnt.numel() - stages[i].cnt_off
         stages_dev = th.frombuffer(bytearray(bytes(memoryview(stages))), dtype=th.uint8).to(self.dev)
-        deps_dev = th.tensor(list(deps[:max(1, used.value)]), dtype=th.int32, device=self.dev)
-        flags = self.buf(max(1, n_flags.value), dtype=th.int32).zero_()
-        ctl = self.buf(nat.CHAIN_CTL_INTS, dtype=th.int32).zero_()
-        self.keep += [stages_dev, deps_dev]
-        ch = dict(steps=[st for st, _ in run], n=n, ctl=ctl, grid=grid.value, lds=lds.value, items=[s.n_items for s in stages],
-                  kinds=[s.kind for s in stages])
+        deps_dev = th.frombuffer(bytearray(bytes(memoryview(deps))[:4 * max(1, used.value)]), dtype=th.int32).to(self.dev)
+        flags = th.zeros(max(1, n_flags.value), dtype=th.int32, device=self.dev)
+        ctl = th.zeros(nat.CHAIN_CTL_INTS, dtype=th.int32, device=self.dev)
+        ch = dict(steps=[st for st, _ in run], run=list(run), n=n, ctl=ctl, grid=grid.value, lds=lds.value,
+                  items=[s.n_items for s in stages], kinds=[s.kind for s in stages], codes=[s.conv.tune for s in stages],
+                  tensors=[ws, cnt, stages_dev, deps_dev, flags, ctl])
         ch["step"] = (L.lfvdm_level_chain, (_p(stages_dev), n, _p(deps_dev), _p(flags), _p(ctl), grid.value, lds.value,
                                             CHAIN_TIMEOUT_S))
+        if keep:
+            self.keep += ch["tensors"]
         return ch
+
+    def _time_chain(self, ch, reps, rounds):
+        """Microseconds per launch of one chain on its own, back to back (minimum over `rounds`)."""
+        fn, args = ch["step"]
+        s = nat.stream()
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            fn(*args, s)
+        best = float("inf")
+        for _ in range(rounds):
+            e0.record()
+            for _ in range(reps):
+                fn(*args, s)
+            e1.record()
+            e1.synchronize()
+            best = min(best, 1000.0 * e0.elapsed_time(e1) / reps)
+        if int(ch["ctl"][nat.CHAIN_CTL_ABORT].item()) != 0:
+            return float("inf")
+        return best
+
+    def tune_chains(self, reps=20, rounds=3):
+        """Tile codes of the chains' GEMM stages chosen INSIDE the chain (one pass of coordinate descent: every legal code
+        of a stage with the other stages at their current choice, the chain timed on its own).  A stand-alone launch and a
+        chain stage have different optima: in a chain the filter pieces are in flight before the wait, so a third LDS-DMA
+        stage (the whole K slice of a k-group requested up front) pays where it did not per launch, and a stage with more
+        work items than workgroups runs in rounds.  Cached per launch shape (key + TUNE_IN_CHAIN)."""
+        if not self.chains or th.cuda.is_current_stream_capturing():
+            return 0
+        L, cache, changed = nat.lib(), nat.tune_cache(), 0
+        reps = int(os.environ.get("LFVDM_TUNE_REPS", reps))
+        rounds = int(os.environ.get("LFVDM_TUNE_ROUNDS", rounds))
+        codes = (C.c_int * 256)()
+        for ci in range(len(self.chains)):
+            ch = self.chains[ci]
+            run, cur, cur_t = ch["run"], ch, None
+            for si, (step, st) in enumerate(run):
+                if st.kind != nat.CHAIN_CONV:
+                    continue
+                a = step[1][0]._obj
+                key = nat.tune_key(a) + (nat.TUNE_IN_CHAIN,)
+                if key in cache:
+                    if cache[key] != st.conv.tune:
+                        st.conv.tune = a.tune = cache[key]
+                        nxt = self._make_chain(run, keep=False)
+                        if nxt is not None:
+                            cur, cur_t = nxt, None
+                    continue
+                if cur_t is None:
+                    cur_t = self._time_chain(cur, reps, rounds)
+                n = L.lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
+                start = st.conv.tune
+                best_code = start
+                for code in [codes[i] for i in range(n)]:
+                    if code == start:
+                        continue
+                    st.conv.tune = code
+                    if L.lfvdm_chain_conv_ok(C.byref(st.conv)) != 0:
+                        continue
+                    cand = self._make_chain(run, keep=False)
+                    if cand is None:
+                        continue
+                    t = self._time_chain(cand, reps, rounds)
+                    if t < cur_t * 0.995:
+                        cur, cur_t, best_code = cand, t, code
+                st.conv.tune = a.tune = best_code
+                cache[key] = best_code
+            if cur is not ch:
+                changed += 1
+                self.keep += cur["tensors"]
+                idx = next(i for i, stp in enumerate(self.steps) if stp is ch["step"])
+                self.steps[idx] = cur["step"]
+                self.chains[ci] = cur
+        nat.tune_cache_save()
+        return changed
 
     def build_chains(self):
         """Replace every run of >= 2 consecutive chainable launches (tuned implicit GEMMs and one-wave GroupNorms of the

@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
         ("splitk_ws", c_fp), ("splitk_cnt", c_fp), ("splitk_ws_floats", C.c_int64), ("splitk_cnt_ints", C.c_int64),
         ("gn_gamma", c_fp), ("gn_beta", c_fp), ("gn_film", c_fp), ("gn_out", c_fp), ("gn_film_ld", C.c_int32),
         ("gn_film_div", C.c_int32), ("gn_act", C.c_int32), ("gn_skip_raw", C.c_int32), ("gn_eps", C.c_float),
-        ("gn_pad_", C.c_int32),
+        ("gn_general", C.c_int32),
     ]
 
 
@@ -259,6 +259,11 @@ def splitk_workspace(device):
 # LFVDM_TUNE_CACHE to refresh it in place - tools/refresh_profiles.sh does), and only by rank 0 of a multi-process job.
 _tune = None
 _tune_saved = 0
+
+
+# markers appended to a launch-shape key (integers: the table is stored as JSON lists of ints): the fastest code among the
+# variants the persistent level chain holds, measured per launch / measured inside its chain
+TUNE_CHAIN, TUNE_IN_CHAIN = -101, -102
 
 
 def tune_key(a):

@@ -304,7 +304,12 @@ class GaussianDiffusion:
             sampler = self._graph_sampler(inner, tuple(shape), clip_denoised)
             sampler.begin(img, model_kwargs)
             if _final_only and not progress:      # p_sample_loop: nobody looks at the intermediate states
-                yield sampler.run(self.num_timesteps - 1, self.num_timesteps)
+                out = sampler.run(self.num_timesteps - 1, self.num_timesteps)
+                if sampler.chain_timed_out():     # a persistent level chain gave up a wait: the samples are garbage
+                    sampler.fall_back()           # (said on stderr) -> one launch per stage, and the chain again
+                    sampler.begin(img, model_kwargs)
+                    out = sampler.run(self.num_timesteps - 1, self.num_timesteps)
+                yield out
                 return
             for i in indices:
                 out = sampler.step(i)
@@ -541,14 +546,8 @@ class GraphSampler:
     def begin(self, img, model_kwargs):
         pl = self.plan
         B, T = pl.B, pl.T
-        if pl.chains and pl.chains_aborted():
-            # a wait inside a persistent level chain gave up (LFVDM_CHAIN_TIMEOUT_S): the samples of the previous chain are
-            # not to be trusted - say so, and run this plan one launch per stage from now on
-            import sys
-            print("[lfvdm] ERROR: a persistent level chain timed out; falling back to the per-launch plan", file=sys.stderr, flush=True)
-            pl.disable_chains()
-            self.graph = self.graph_k = None
-            self.chain_timeouts = getattr(self, "chain_timeouts", 0) + 1
+        if self.chain_timed_out():
+            self.fall_back()        # (callers that drive step() / run() themselves: checked once per chain, here)
         if pl._sig != pl.weight_signature():
             pl.refresh_weights()  # parameters changed since the last chain
         with th.no_grad():
@@ -594,6 +593,20 @@ class GraphSampler:
             self.t_buf.fill_(self.diffusion.num_timesteps)     # the step pre-decrements
             self.seed.random_()                                 # this chain's noise key (torch's generator: seedable)
         self.expected_t = self.diffusion.num_timesteps - 1
+
+    def chain_timed_out(self):
+        """Did a wait inside one of the plan's persistent level chains give up (LFVDM_CHAIN_TIMEOUT_S)?  Synchronises."""
+        return bool(self.plan.chains) and self.plan.chains_aborted()
+
+    def fall_back(self):
+        """After a chain timeout: the samples of the chain that just ran are not to be trusted.  Say so, run this plan one
+        launch per stage from now on, and have the step graphs captured again."""
+        import sys
+        print("[lfvdm] ERROR: a persistent level chain timed out (lfvdm_level_chain); falling back to the per-launch plan",
+              file=sys.stderr, flush=True)
+        self.plan.disable_chains()
+        self.graph = self.graph_k = None
+        self.chain_timeouts = getattr(self, "chain_timeouts", 0) + 1
 
     def chain_table_ms(self):
         """GPU milliseconds of ALL table building of one chain of this sampler (every R block once; the FiLM rows are per

@@ -84,3 +84,28 @@ def test_level_chain_eager_launches_repeat_bitwise():
     pl.launch()
     torch.cuda.synchronize()
     assert torch.equal(ref, pl.out)
+
+
+def test_a_raised_abort_word_makes_the_sampler_fall_back(capfd):
+    """Every wait inside a chain is bounded: a poller that times out raises the chain's abort word, every other poller sees
+    it and leaves.  The host side of that contract: ``p_sample_loop`` finds the word raised after the chain, says so on
+    stderr, takes the plan apart into one launch per stage and runs the chain again - the caller gets valid samples."""
+    from improved_diffusion import _native as nat
+    cfg, sd, inp = load_case("cfgB")
+    model = build_native(cfg, sd)
+    d = {k: v.cuda() for k, v in inp.items()}
+    mk = dict(frame_indices=d["frame_indices"], obs_mask=d["obs_mask"], latent_mask=d["latent_mask"], x0=d["x0"])
+    shape = tuple(inp["x"].shape)
+    diff = make_diffusion(1000, "25")
+    torch.manual_seed(11)
+    a, _ = diff.p_sample_loop(model, shape, clip_denoised=True, model_kwargs=mk, return_decoded=False)
+    s = diff._graph_sampler(model, shape, True)
+    assert s.plan.chains and not s.chain_timed_out()
+    s.plan.chains[0]["ctl"][nat.CHAIN_CTL_ABORT] = 1            # what a timed-out poller does
+    b, _ = diff.p_sample_loop(model, shape, clip_denoised=True, model_kwargs=mk, return_decoded=False)
+    err = capfd.readouterr().err
+    assert "persistent level chain timed out" in err
+    assert not s.plan.chains and s.chain_timeouts == 1 and bool(torch.isfinite(b).all())
+    n_steps = len(s.plan.steps)
+    c, _ = diff.p_sample_loop(model, shape, clip_denoised=True, model_kwargs=mk, return_decoded=False)      # stays per launch
+    assert len(s.plan.steps) == n_steps and not s.plan.chains and bool(torch.isfinite(c).all())

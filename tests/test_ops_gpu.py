@@ -1021,12 +1021,14 @@ def test_conv_fused_output_groupnorm_every_tune_code(nat, N, Cin, Cout, H, film,
     codes = (C.c_int * 256)()
     n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
     assert n > 0
-    for code in [0] + [codes[i] for i in range(n)]:
-        a.tune = code
+    # both forms of the epilogue: registers + lane butterflies (P and Cout/32 powers of two: every case here) and the general
+    # LDS-tile form (gn_general, what other shapes get)
+    for code, general in [(c, g) for c in [0] + [codes[i] for i in range(n)] for g in (0, 1)]:
+        a.tune, a.gn_general = code, general
         out.fill_(float("nan")); gn_out.fill_(float("nan"))
         nat.conv_igemm_struct(a)
         err = float((from_cl(gn_out, N, H, H, Cout).cpu() - ref).abs().max())
-        assert err < 1e-4, f"tune code {code}: fused GroupNorm max|d| = {err:.3e}"
+        assert err < 1e-4, f"tune code {code}, general form {general}: fused GroupNorm max|d| = {err:.3e}"
         if skip_raw:
             assert bool(torch.isnan(out).all()), "raw output must not be written with gn_skip_raw"
         else:
