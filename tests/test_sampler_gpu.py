@@ -366,3 +366,67 @@ def test_rolling_R_window_is_bitwise_the_whole_chain_tables(monkeypatch):
         assert torch.equal(outs[ring][2], outs["0"][2]), ring
         assert outs[ring][4] > 0
     assert outs["16"][3] < 0.4 * outs["0"][3], (outs["16"][3], outs["0"][3])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("tag", ["cfgD_window", "cfgB"])
+def test_full_chain_drift_vs_oracle(tag):
+    """"K-step sampler trajectories ... report the observed curve".  The WHOLE chain of the metric's own
+    workloads - cfg B (batch 2, 20 frames, 1000 steps) and a cfg-D window (batch 1, 20 frames with hierarchy-2 anchor
+    frames, 250-step respacing) - on the MI355X (``GraphSampler(inject_noise=True)``: the replayed, autotuned plan with its
+    persistent level chains) and through the CPU oracle (oracle/unet_oracle.py + diffusion_oracle.py, fp32), both FREE
+    RUNNING from the same start with the same recipe noise at every step (reference gaussian_diffusion.py:369-401,509-522,
+    respace.py:110-124).  Every step is compared; the curve max|x_hip - x_oracle| is printed every 50 steps (collected into
+    profiles/r05_parity_deviations.txt).  Asserted bound, at every step k (1-based): 2e-4 * k - the per-step tolerance of the
+    trajectory goldens (2e-4 per step taken) accumulated linearly, NOT a number tuned to the observation (DESIGN.md section 3);
+    the x0 prediction of the last step is held to the same bound."""
+    from improved_diffusion.gaussian_diffusion import GraphSampler
+    from oracle import unet_oracle as uo, diffusion_oracle as do
+    try:                                       # the GPU box grants 16 host cores per GPU; a 256-thread OpenMP team on a CPU quota crawls
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(cores, 16)))
+    cfg, sd, inp = load_case("cfgB")
+    model = build_native(cfg, sd)
+    if tag == "cfgB":
+        diff, tab = make_diffusion(1000, ""), do.Tables(do.linear_betas(1000))
+        x0, x, fi, obs, lat = inp["x0"], inp["x"].clone(), inp["frame_indices"], inp["obs_mask"], inp["latent_mask"]
+    else:
+        g = np.load(os.path.join(GOLDEN, "sampler_cfgD_window.npz"))
+        diff, tab = make_diffusion(1000, "250"), do.Tables(do.linear_betas(1000), do.space_timesteps(1000, "250"))
+        K = 20
+        w = {k: torch.from_numpy(v) for k, v in recipe.make_inputs(f"cfgD_w{K}", 1, K, cfg["in_channels"], 16, 16).items()}
+        x0, x, fi = w["x0"], w["x"].clone(), torch.from_numpy(g[f"w{K}_frame_indices"])
+        obs = torch.zeros(1, K, 1, 1, 1)
+        obs[:, :int(g[f"w{K}_n_obs"])] = 1.0
+        lat = 1 - obs
+    n_t = diff.num_timesteps
+    shape = tuple(x.shape)
+    mk = dict(frame_indices=fi.cuda(), obs_mask=obs.cuda(), latent_mask=lat.cuda(), x0=x0.cuda())
+    s = GraphSampler(diff, model, shape, True, inject_noise=True)
+    s.begin(x.cuda(), mk)
+    assert getattr(s.plan, "tuned", False) and s.graph is not None
+    xo = x.clone()
+    worst, curve, pred_o = 0.0, [], None
+    with torch.no_grad():
+        for k, i in enumerate(range(n_t - 1, -1, -1)):
+            noise = torch.from_numpy(recipe.gaussianish(f"drift/{tag}/noise{i}", x.numel()).reshape(shape).astype(np.float32))
+            s.noise.copy_(noise.cuda())
+            out = s.step(i)
+            ti = torch.full((shape[0],), i, dtype=torch.long)
+            eps = uo.unet_forward(sd, cfg, xo, x0, do.model_timesteps(tab, ti), fi, obs, lat)[0]
+            xo, pred_o = do.p_sample(tab, eps, xo, ti, noise)
+            err = float((out["sample"].cpu() - xo).abs().max())
+            worst = max(worst, err)
+            assert err < 2e-4 * (k + 1), (tag, k, i, err)
+            if (k + 1) % 50 == 0 or k == 0 or i == 0:
+                curve.append((k + 1, err))
+                print(flush=True, end="")
+                print(f"[drift {tag}] after {k + 1:4d} steps (t={i:3d}): max|x_hip - x_oracle| = {err:.3e}   (bound {2e-4 * (k + 1):.1e})")
+    pred_h = s.pred.cpu()
+    perr = float((pred_h - pred_o["pred_xstart"]).abs().max()) if isinstance(pred_o, dict) else float((pred_h - pred_o).abs().max())
+    print(f"[drift {tag}] whole chain of {n_t} steps: worst max|d| over all steps {worst:.3e}, final sample {curve[-1][1]:.3e}, "
+          f"final x0 prediction {perr:.3e}; no persistent-chain timeout: {not s.chain_timed_out()}")
+    assert not s.chain_timed_out()
+    assert perr < 2e-4 * n_t and bool(torch.isfinite(out["sample"]).all())

@@ -12,7 +12,7 @@
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/refresh
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 rm -rf $OUT
 mkdir -p $OUT
 export LFVDM_TUNE_CACHE=$ROOT/profiles/tune_cache_mi355x.json      # read-only
@@ -66,7 +66,7 @@ if [ -f $ROOT/devlib/liblfvdm_stamp.so ]; then
   echo "phase stamps done"
 fi
 # 6. the parity tests that print their deviations from the reference fixtures
-cd $ROOT && step 500 python3 -m pytest tests/test_forward_gpu.py tests/test_backward_gpu.py tests/test_sampler_gpu.py tests/test_train_gpu.py -m gpu -q -s --timeout 400 -k "reference or cfgC_training or replayed or full_size or fp64 or parameter_gradients" > $OUT/parity_deviations.txt 2>&1; cd /tmp
+cd $ROOT && step 1500 python3 -m pytest tests/test_forward_gpu.py tests/test_backward_gpu.py tests/test_sampler_gpu.py tests/test_train_gpu.py -m gpu -q -s -k "reference or cfgC_training or replayed or full_size or fp64 or parameter_gradients or drift" --timeout 1200 > $OUT/parity_deviations.txt 2>&1; cd /tmp
 echo "parity deviations done"
 # 7. the whole 1000-frame hierarchy-2 video (BASELINE.json configs[3] at full size: 97 windows x 250 steps)
 step 400 python3 $ROOT/bench.py --steps 50 --warmup 10 --train-steps 0 --pixel-steps 0 --no-cpu --long-video-windows 97 > $OUT/long_video_line.json 2> $OUT/long_video.err
