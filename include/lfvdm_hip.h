@@ -545,6 +545,9 @@ typedef struct lfvdm_adamw_args {
     float* grad_sqsum;                 /* optional: += sum (grad_scale*g)^2 */
     const int32_t* skip_flag;          /* optional: a non-zero word (the `timed_out` word of lfvdm_flag_wait) turns the
                                           launch into a no-op: nothing is read or written */
+    const int32_t* skip_flag2;         /* optional second word, same meaning: the element of the gradient arena behind the
+                                          last bucket that lfvdm_flag_wait2 raises to 1.0f and the bucket's SUM all-reduce
+                                          carries to every rank (read as bits: any non-zero value skips) */
 } lfvdm_adamw_args;
 
 int lfvdm_adamw_ema(const lfvdm_adamw_args* a, void* stream);
@@ -653,6 +656,8 @@ int lfvdm_level_chain(const lfvdm_chain_stage* stages_dev, int n_stages, const i
  * ------------------------------------------------------------------------------------- */
 int lfvdm_flag_add(int32_t* flag, void* stream);
 int lfvdm_flag_wait(const int32_t* flag, int32_t target, double timeout_s, int32_t* timed_out, void* stream);
+/* the same, and on a timeout *timed_out_f32 = 1.0f as well (optional; see lfvdm_adamw_args.skip_flag2) */
+int lfvdm_flag_wait2(const int32_t* flag, int32_t target, double timeout_s, int32_t* timed_out, float* timed_out_f32, void* stream);
 
 #ifdef __cplusplus
 }

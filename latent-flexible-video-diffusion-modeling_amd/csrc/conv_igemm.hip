@@ -279,4 +279,4 @@ extern "C" int lfvdm_conv_igemm_config(const lfvdm_conv_args* a, int* nt, int* n
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_abi_version(void) { return 8; }
+extern "C" int lfvdm_abi_version(void) { return 9; }

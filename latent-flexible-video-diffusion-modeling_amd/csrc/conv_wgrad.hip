@@ -784,6 +784,7 @@ static int wgrad_taps_wseg(const lfvdm_conv_args* a, long M) {
     static const bool off = getenv("LFVDM_WGRAD_NO_TAPS") != nullptr;          // A/B aid
     const int Cin = a->C0 + a->C1;
     if (off || a->ksize != 3 || a->stride != 1 || a->up != 0 || a->coefA || a->act != LFVDM_ACT_NONE) return 0;
+    if (a->out_mode != 0) return 0;       // the tap-fused kernels only write the packed [Cout][tap][Cin] accumulator layout
     if (Cin % 64 || a->C0 % 64 || a->Cout < 64 || a->Hs != a->Ho || a->Ws != a->Wo || (a->Ho * a->Wo) % 32) return 0;
     if (!wgrad_dma_ok(a, M)) return 0;
     if (a->Wo % 32 == 0) return 32;

@@ -6,29 +6,64 @@
 
 namespace {
 
+// one float4 of the update; returns the new parameter quad and the squared gradient norm contribution
+__device__ __forceinline__ f32x4 adamw_quad(const lfvdm_adamw_args& a, float step, f32x4 g, f32x4 p, f32x4& m, f32x4& v, float& sq) {
+    g = g * a.grad_scale;
+    sq += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+    p = p * (1.0f - a.lr * a.weight_decay);            // decoupled weight decay (torch AdamW)
+    m = m * a.beta1 + g * (1.0f - a.beta1);
+    v = v * a.beta2 + (g * g) * (1.0f - a.beta2);
+    f32x4 d;
+    d.x = sqrtf(v.x) / a.bias_corr2_sqrt + a.eps; d.y = sqrtf(v.y) / a.bias_corr2_sqrt + a.eps;
+    d.z = sqrtf(v.z) / a.bias_corr2_sqrt + a.eps; d.w = sqrtf(v.w) / a.bias_corr2_sqrt + a.eps;
+    p.x -= step * (m.x / d.x); p.y -= step * (m.y / d.y); p.z -= step * (m.z / d.z); p.w -= step * (m.w / d.w);
+    return p;
+}
+__device__ __forceinline__ f32x4 ld4_nt(const float* q) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)); }
+__device__ __forceinline__ void st4_nt(float* q, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q)); }
+
+// NE = number of EMA copies (compile time: their loads join the batch), U float4 per thread and iteration.  Every load of
+// an iteration is issued before the first use (round-3 lesson: a rolled loop of global loads is a chain of dependent round
+// trips; here 2 * (4 + NE) 16-byte loads are in flight per thread), the streams that nothing re-reads soon - gradients in,
+// moments and EMA copies out - are non-temporal (they would only push the parameters, which the next forward pass reads,
+// out of the caches).  9 streams of 4 bytes per parameter: HBM-bound (hbm_phases.adamw_ema).
+template <int NE>
 __global__ __launch_bounds__(256) void adamw_ema_kernel(const lfvdm_adamw_args a) {
     // a gradient bucket was reduced before the backward pass had finished writing it (lfvdm_flag_wait gave up): the
     // gradients of this step are garbage - touch nothing, the host raises
     if (a.skip_flag && __hip_atomic_load(a.skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    // ... or on ANOTHER rank: the word that rode in the last bucket's SUM all-reduce (any non-zero bit pattern)
+    if (a.skip_flag2 && __hip_atomic_load(a.skip_flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    constexpr int U = 2;
     const int64_t n4 = a.n / 4;
     float sq = 0.f;
     const float step = a.lr / a.bias_corr1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        f32x4 g = ld4(a.g + i * 4) * a.grad_scale;
-        f32x4 p = ld4(a.p + i * 4);
-        f32x4 m = ld4(a.m + i * 4), v = ld4(a.v + i * 4);
-        sq += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
-        p = p * (1.0f - a.lr * a.weight_decay);            // decoupled weight decay (torch AdamW)
-        m = m * a.beta1 + g * (1.0f - a.beta1);
-        v = v * a.beta2 + (g * g) * (1.0f - a.beta2);
-        f32x4 d;
-        d.x = sqrtf(v.x) / a.bias_corr2_sqrt + a.eps; d.y = sqrtf(v.y) / a.bias_corr2_sqrt + a.eps;
-        d.z = sqrtf(v.z) / a.bias_corr2_sqrt + a.eps; d.w = sqrtf(v.w) / a.bias_corr2_sqrt + a.eps;
-        p.x -= step * (m.x / d.x); p.y -= step * (m.y / d.y); p.z -= step * (m.z / d.z); p.w -= step * (m.w / d.w);
-        st4(a.p + i * 4, p); st4(a.m + i * 4, m); st4(a.v + i * 4, v);
-        for (int e = 0; e < a.n_ema; ++e) {
-            const f32x4 t = ld4(a.ema[e] + i * 4);
-            st4(a.ema[e] + i * 4, t * a.ema_rate[e] + p * (1.0f - a.ema_rate[e]));   // targ*r + src*(1-r)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += U * stride) {
+        int64_t idx[U];
+        f32x4 g[U], p[U], m[U], v[U], e[U][NE > 0 ? NE : 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            idx[u] = i < n4 ? i : -1;
+            const int64_t j = (i < n4 ? i : i0) * 4;          // (a clamped duplicate load; its result is not used)
+            g[u] = ld4_nt(a.g + j);
+            p[u] = ld4(a.p + j);
+            m[u] = ld4_nt(a.m + j);
+            v[u] = ld4_nt(a.v + j);
+#pragma unroll
+            for (int k = 0; k < NE; ++k) e[u][k] = ld4_nt(a.ema[k] + j);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (idx[u] < 0) continue;
+            const int64_t j = idx[u] * 4;
+            const f32x4 pn = adamw_quad(a, step, g[u], p[u], m[u], v[u], sq);
+            st4(a.p + j, pn);
+            st4_nt(a.m + j, m[u]);
+            st4_nt(a.v + j, v[u]);
+#pragma unroll
+            for (int k = 0; k < NE; ++k) st4_nt(a.ema[k] + j, e[u][k] * a.ema_rate[k] + pn * (1.0f - a.ema_rate[k]));   // targ*r + src*(1-r)
         }
     }
     // tail (n not a multiple of 4)
@@ -59,7 +94,13 @@ extern "C" int lfvdm_adamw_ema(const lfvdm_adamw_args* a, void* stream) {
     int64_t blocks = (a->n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    switch (a->n_ema) {
+        case 0: hipLaunchKernelGGL(adamw_ema_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a); break;
+        case 1: hipLaunchKernelGGL(adamw_ema_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a); break;
+        case 2: hipLaunchKernelGGL(adamw_ema_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a); break;
+        case 3: hipLaunchKernelGGL(adamw_ema_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a); break;
+        default: hipLaunchKernelGGL(adamw_ema_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a); break;
+    }
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -15,7 +15,7 @@ __global__ void flag_add_kernel(int* flag) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void flag_wait_kernel(const int* flag, int target, long long timeout_ticks, int* timed_out) {
+__global__ void flag_wait_kernel(const int* flag, int target, long long timeout_ticks, int* timed_out, int* timed_out_f32) {
     // One lane polls with device-scope loads (served by the memory side, never by this CU's L1) and sleeps between polls:
     // a parked wave, no measurable bandwidth.  The exit condition is always reached: the counter arrives, or the
     // 100 MHz wall clock passes the deadline.  Then `timed_out` is raised: the optimizer launch of the step reads the
@@ -28,6 +28,9 @@ __global__ void flag_wait_kernel(const int* flag, int target, long long timeout_
             __builtin_amdgcn_s_sleep(64);
             if (wall_clock64() - t0 > timeout_ticks) {
                 atomicExch(timed_out, 1);
+                // second word (optional): 1.0f, an element of the gradient arena that rides in the last bucket's SUM
+                // all-reduce - any rank's timeout reaches every rank's optimizer launch without a collective of its own
+                if (timed_out_f32) atomicExch(timed_out_f32, 0x3f800000);
                 break;
             }
         }
@@ -44,10 +47,16 @@ extern "C" int lfvdm_flag_add(int32_t* flag, void* stream) {
     return LFVDM_OK;
 }
 
-extern "C" int lfvdm_flag_wait(const int32_t* flag, int32_t target, double timeout_s, int32_t* timed_out, void* stream) {
+extern "C" int lfvdm_flag_wait2(const int32_t* flag, int32_t target, double timeout_s, int32_t* timed_out, float* timed_out_f32,
+                                void* stream) {
     if (!flag || !timed_out || !(timeout_s > 0)) return LFVDM_E_SHAPE;
     const long long ticks = (long long)(timeout_s * 1.0e8);      // wall_clock64 runs at 100 MHz on gfx950
-    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, target, ticks, timed_out);
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, target, ticks, timed_out,
+                       (int*)timed_out_f32);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
+}
+
+extern "C" int lfvdm_flag_wait(const int32_t* flag, int32_t target, double timeout_s, int32_t* timed_out, void* stream) {
+    return lfvdm_flag_wait2(flag, target, timeout_s, timed_out, nullptr, stream);
 }

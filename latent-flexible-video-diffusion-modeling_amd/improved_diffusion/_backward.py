@@ -308,6 +308,15 @@ class _SkipSlot:
         return g
 
     @staticmethod
+    def reset_stale():
+        """Start of a forward pass: autograd does not run the queued end-of-backward callbacks when a backward pass RAISES
+        (out of memory, a kernel error), so ``queued`` would stay set and the leftover slots full - the next healthy backward
+        pass would trip over them ("filled twice") or run without the drained check.  No backward pass is running here."""
+        for s in _SkipSlot.pending:
+            s.g = None
+        _SkipSlot.pending, _SkipSlot.queued = [], False
+
+    @staticmethod
     def check_drained():
         """End-of-backward callback: a slot that is still full means its consumer never ran or did not compute an input
         gradient (a partial ``torch.autograd.grad(..., inputs=subset)``, a first layer without an input gradient): the
@@ -1138,6 +1147,7 @@ class UNetFunction:
         from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
         m = engine.model
         attns = {"spatial": [], "temporal": [], "mixed": []} if return_attn_weights else None
+        _SkipSlot.reset_stale()
         _mode.inplace = bool(getattr(m, "native_grad_accumulation", False))
         B, T, Cx, H, W = x.shape
         N = B * T

@@ -49,32 +49,45 @@ def stage_of(name):
     return None            # time_embed: late
 
 
-def plan_buckets(named_params, n_buckets=4):
+def plan_buckets(named_params, n_buckets=5):
     """-> (groups, marks): ``groups`` = parameter indices per bucket, in layout order (bucket 0 is finished first by the
-    backward pass); ``marks`` = {stage key: bucket} for the stages whose INPUT carries the bucket's marker node."""
+    backward pass); ``marks`` = {stage key: bucket} for the stages whose INPUT carries the bucket's marker node.
+
+    The last bucket holds ONLY what is complete at the very end of the backward pass: the parameters whose gradients come
+    from the end-of-backward grouped launches (``is_late``) and the input convolution (stage (0, 0): its weight gradient
+    is the last kernel of the U-Net's backward; no marker can sit in front of it - the network input carries no
+    gradient).  Every other stage belongs to one of the ``n_buckets - 1`` early buckets, whose collectives start INSIDE
+    the backward pass: the stages are walked from the output head back to input_blocks.1 and cut into groups of about
+    equal size, the last group's marker sitting at the input of input_blocks.1.  (Round 4 left the stages behind the third
+    cut in the last bucket as well: 44.5 of 122 MB that could not start before the graph's end at the training shape.)"""
     named = list(named_params)
     stages = {}
     for i, (n, p) in enumerate(named):
         s = stage_of(n)
         if s is not None and not is_late(n):
             stages.setdefault(s, []).append(i)
-    order = sorted(stages, reverse=True)                      # backward order: head first
-    total = sum(named[i][1].numel() for idx in stages.values() for i in idx)
+    order = [s for s in sorted(stages, reverse=True) if s != (0, 0)]          # backward order: head first; (0, 0) is the tail's
     late = [i for i, (n, _) in enumerate(named) if stage_of(n) is None or is_late(n)]
-    n_early = max(0, n_buckets - 1)
-    groups, marks, cur, acc, target = [], {}, [], 0, (total / n_buckets if n_buckets else 0)
+    tail = stages.get((0, 0), []) + late
+    n_early = min(max(0, n_buckets - 1), len(order))
+    total = sum(named[i][1].numel() for s in order for i in stages[s])
+    groups, marks, cur, acc = [], {}, [], 0
+    target = total / n_early if n_early else 0
     for pos, s in enumerate(order):
-        if len(groups) < n_early:
-            cur += stages[s]
-            acc += sum(named[i][1].numel() for i in stages[s])
-            last_stage = pos == len(order) - 1
-            if acc >= target and not last_stage:              # cut here: the marker sits at the input of stage s
-                marks[s] = len(groups)
-                groups.append(cur)
-                cur, acc = [], 0
-        else:
-            cur += stages[s]
-    groups.append(cur + late)                                # finished at the end of the backward pass
+        cur += stages[s]
+        acc += sum(named[i][1].numel() for i in stages[s])
+        left = len(order) - 1 - pos                           # stages still to place
+        last_group = len(groups) == n_early - 1
+        # cut here (the marker sits at the input of stage s): the group is full and later groups can still get a stage each;
+        # the last early group runs to the end of the walk
+        if n_early and ((not last_group and acc >= target and left >= n_early - 1 - len(groups)) or left == 0):
+            marks[s] = len(groups)
+            groups.append(cur)
+            cur, acc = [], 0
+    if n_early == 0:        # one bucket: everything behind the graph's end
+        tail = cur + tail
+    groups.append(tail)
+    groups = [g for g in groups if g]
     assert sorted(i for g in groups for i in g) == list(range(len(named)))
     return groups, marks
 
@@ -134,9 +147,18 @@ class GradExchange:
                     break
                 rejected.append(self.comm)
             del rejected
-            if self.overlap_probe["ok"]:
+            # The decision must be the SAME on every rank: it changes what each rank enqueues (device-side waits in front
+            # of the early collectives or not) - a rank whose probe failed would otherwise run a different schedule than
+            # its peers against the same collectives.  MIN over the ranks: overlap only if every rank's probe passed.
+            ok = bool(self.overlap_probe["ok"])
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                t = th.tensor([1 if ok else 0], device=arena.g.device, dtype=th.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                self.overlap_probe["ok_on_every_rank"] = bool(t.item())
+                ok = ok and bool(t.item())
+            if ok:
                 self.flags = nat.StreamFlags(self.n_early, arena.g.device)
-            else:               # every stream shares main's hardware queue (or the waits gave up): exchange behind the graph's end
+            else:               # a stream shares main's hardware queue (or a wait gave up) on some rank: exchange behind the graph's end
                 self.overlap = False
         self._works = []
         self._timing = []              # (start, end) event pairs of the exposed waits, read lazily
@@ -166,11 +188,26 @@ class GradExchange:
         th.cuda.synchronize(dev)
         lead = e_comm.elapsed_time(e_main)
         ok = (not sig.timed_out()) and lead > 1.0
+        if os.environ.get("LFVDM_TEST_PROBE_FAIL_RANK", "") == os.environ.get("RANK", "0"):
+            ok = False          # test hook: this rank's probe "fails" (tests/test_dist_gpu.py: the decision must stay collective)
         return {"ok": bool(ok), "wait_returned_ms_before_main_idle": round(float(lead), 3), "wait_timed_out": bool(sig.timed_out())}
 
     def skip_flag_ptr(self):
-        """Device word the optimizer launch checks (lfvdm_adamw_args.skip_flag): non-zero once a bucket wait gave up."""
+        """Device word the optimizer launch checks (lfvdm_adamw_args.skip_flag): non-zero once a bucket wait of THIS rank
+        gave up (sticky until ``reset_timeout``)."""
         return self.flags.timed_out_ptr() if self.flags is not None else None
+
+    def skip_word(self):
+        """The float behind the last gradient bucket (``ParamArena.g_full[numel]``): a timed-out wait raises it to 1.0 on
+        the rank it happened on, the last bucket's SUM all-reduce - which carries it as one extra element - makes it
+        non-zero on EVERY rank before the optimizer launch reads it (lfvdm_adamw_args.skip_flag2), ``zero_grad`` clears it
+        with the gradients.  No collective of its own (round 4 spent a separate MAX all-reduce per step on this)."""
+        gf = getattr(self.arena, "g_full", None)
+        return gf[self.arena.numel:self.arena.numel + 1] if gf is not None and self.on_gpu else None
+
+    def skip_word_ptr(self):
+        w = self.skip_word()
+        return w.data_ptr() if w is not None else None
 
     def poll_timeout(self, sync=False):
         """Once per optimizer step, after the optimizer launch: raises if a bucket's wait on the backward graph timed out
@@ -185,8 +222,13 @@ class GradExchange:
         if sync:
             bad = self.flags.timed_out()
         else:
-            host = th.empty(1, dtype=th.int32).pin_memory()
-            host.copy_(self.flags.buf[self.flags.n, :1], non_blocking=True)
+            host = th.empty(2, dtype=th.int32).pin_memory()
+            host[:1].copy_(self.flags.buf[self.flags.n, :1], non_blocking=True)
+            w = self.skip_word()                    # (bits of the float: any rank's timeout, after the reduce)
+            if w is not None:
+                host[1:].copy_(w.view(th.int32), non_blocking=True)
+            else:
+                host[1] = 0
             ev = th.cuda.Event()
             ev.record()
             self._late.append((host, ev))
@@ -194,12 +236,15 @@ class GradExchange:
             while len(self._late) > 1:              # everything but the word just enqueued: fixed one-step lag
                 h, e = self._late.pop(0)
                 e.synchronize()
-                bad = bad or bool(h.item())
+                bad = bad or bool(h[0].item()) or bool(h[1].item())
         if bad:
             self.reset_timeout()
+            self.skipped_steps = 2
             raise RuntimeError("gradient exchange: a bucket's wait on the backward graph timed out (lfvdm_flag_wait) on "
-                               "at least one rank; every rank's optimizer skipped that step - parameters are those of "
-                               "the last good step")
+                               "at least one rank.  Every rank's optimizer launch skipped that step and the one after it "
+                               "(the word is examined one step late, by every rank in the same step): parameters, moments "
+                               "and EMA are those of the last good step; TrainLoop.opt_step has been taken back by the two "
+                               "skipped steps")
 
     def reset_timeout(self):
         """After a timeout has been reported: whoever catches the error and carries on gets the exchange behind the
@@ -260,19 +305,21 @@ class GradExchange:
                     continue
                 early = k < self.n_early and self.overlap and self.fired[k] and not tail_started
                 if early:
-                    self.flags.wait(k, self.micro_steps, self.comm, timeout_s=self.wait_timeout_s)
+                    self.flags.wait(k, self.micro_steps, self.comm, timeout_s=self.wait_timeout_s, also_f32=self.skip_word_ptr())
                     self.stats["buckets_behind_event"] += 1
                 else:
                     if not tail_started:
                         self.comm.wait_event(end)
                         tail_started = True
                     self.stats["buckets_behind_graph_end"] += 1
-                self._works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
-            if self.flags is not None:
-                # collective skip decision: a wait that gave up on ONE rank has let a half-written bucket into the sums
-                # every rank received - MAX over ranks of the timed-out word, behind the buckets, before the optimizer
-                # launch (which is ordered behind this stream by wait()) reads it as skip_flag
-                self._works.append(dist.all_reduce(self.flags.buf[self.flags.n, :1], op=dist.ReduceOp.MAX, async_op=True))
+                buf = g[lo:hi]
+                if k == len(self.ranges) - 1 and self.skip_word() is not None:
+                    # collective skip decision without a collective of its own: the last bucket carries the skip word
+                    # (ParamArena.g_full[numel], raised to 1.0 by a wait that gave up on this rank) as one extra element
+                    # of its SUM - non-zero on every rank afterwards if ANY rank let a half-written bucket into the sums.
+                    # Every rank does this whatever its own overlap state: the sequence of collectives is rank-invariant
+                    buf = self.arena.g_full[lo:self.arena.numel + 4]
+                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
     def micro_step_done(self):
         """Called by TrainLoop after every micro-step it has enqueued (eager or graph replay)."""
         self.micro_steps += 1

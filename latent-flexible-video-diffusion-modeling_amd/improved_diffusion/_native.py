@@ -61,7 +61,7 @@ class AdamWArgs(C.Structure):
     _fields_ = [("p", c_fp), ("g", c_fp), ("m", c_fp), ("v", c_fp), ("ema", c_fp * 4), ("ema_rate", C.c_float * 4),
                 ("n_ema", C.c_int32), ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("weight_decay", C.c_float), ("bias_corr1", C.c_float), ("bias_corr2_sqrt", C.c_float),
-                ("grad_scale", C.c_float), ("grad_sqsum", c_fp), ("skip_flag", c_fp)]
+                ("grad_scale", C.c_float), ("grad_sqsum", c_fp), ("skip_flag", c_fp), ("skip_flag2", c_fp)]
 
 
 class RowdotJob(C.Structure):
@@ -179,6 +179,7 @@ _SIGS = {
     "lfvdm_level_chain": ([c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_double, c_fp], c_i),
     "lfvdm_flag_add": ([c_fp, c_fp], c_i),
     "lfvdm_flag_wait": ([c_fp, c_i, C.c_double, c_fp, c_fp], c_i),
+    "lfvdm_flag_wait2": ([c_fp, c_i, C.c_double, c_fp, c_fp, c_fp], c_i),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -418,7 +419,7 @@ def _wgrad_codes(a):
     # tap-fused kernels (stage field 0): tile 1 = one filter row (three taps) per workgroup, tile 2 = all nine taps
     HW = a.Ho * a.Wo
     if (a.ksize == 3 and a.stride == 1 and a.up == 0 and HW % 32 == 0 and (a.Wo % 32 == 0 or a.Wo in (8, 16))
-            and a.Hs == a.Ho and a.Ws == a.Wo):
+            and a.Hs == a.Ho and a.Ws == a.Wo and a.out_mode == 0):        # (packed accumulator layout only: no OIHW store)
         for tile, rows in ((1, 3), (2, 1)):
             tiles = rows * (Cin // 64) * ((a.Cout + 63) // 64)
             for target in (128, 192, 256, 320, 384, 512):
@@ -435,35 +436,54 @@ def _tuned_wgrad_code(a, out_floats):
     (filter tile, channel tile, M slice) workgroups divide the 256 CUs differs per layer."""
     cache = tune_cache()
     key = _wgrad_key(a)
+    store = _rank_store()
+    skey = "lfvdm/wgrad/" + json.dumps([int(x) for x in key])
+
+    def publish(code):
+        # rank 0, every resolution once a store exists - also the ones made BEFORE the process group existed (the first
+        # call found no store) and the heuristic 0 taken under stream capture: a peer blocked on a key that is never set
+        # would sit in the backward pass until the store's timeout
+        if store is not None and store[1] == 0 and key not in _wgrad_published:
+            store[0].set(skey, str(int(code)))
+            _wgrad_published.add(key)
+
     code = _wgrad_agreed.get(key)
     if code is not None:
+        publish(code)
         return code
-    store = _rank_store()
     if store is not None and store[1] != 0:
         # data-parallel job: ranks must run the SAME kernels (bitwise-equal replicas in deterministic mode, no skew from
         # one rank tuning while its peers sit in a bucket all-reduce): rank 0 decides, the others read its choice from
-        # the rendezvous store (a blocking get per shape, once per process; no collective that could mismatch)
+        # the rendezvous store (once per shape and process; no collective that could mismatch).  Bounded: if rank 0 does
+        # not publish within LFVDM_WGRAD_AGREE_S seconds the cached / heuristic code is used and said on stderr
         if torch.cuda.is_current_stream_capturing():
             return cache.get(key, 0)
-        code = int(store[0].get("lfvdm/wgrad/" + json.dumps([int(x) for x in key])).decode())
+        import datetime
+        try:
+            store[0].wait([skey], datetime.timedelta(seconds=float(os.environ.get("LFVDM_WGRAD_AGREE_S", "60"))))
+            code = int(store[0].get(skey).decode())
+        except Exception:
+            code = cache.get(key, 0)
+            import sys
+            print(f"[lfvdm] rank {store[1]}: no weight-gradient launch code from rank 0 for {skey}; using {code}", file=sys.stderr,
+                  flush=True)
         _wgrad_agreed[key] = code
         return code
     code = cache.get(key)
     if code is None:
-        if torch.cuda.is_current_stream_capturing():
-            return 0                    # nothing may be measured (or published) from inside a capture
-        if os.environ.get("LFVDM_AUTOTUNE", "1") == "0" or deterministic():
-            code = 0                    # the heuristic; still published below so that the other ranks do not wait
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("LFVDM_AUTOTUNE", "1") == "0" or deterministic():
+            code = 0                    # the heuristic (nothing may be measured inside a capture): kept for the process and
+                                        # published below, so that every rank runs it and nobody waits
         else:
             code = _measure_wgrad_code(a, out_floats)
             cache[key] = code
     _wgrad_agreed[key] = code
-    if store is not None:
-        store[0].set("lfvdm/wgrad/" + json.dumps([int(x) for x in key]), str(int(code)))
+    publish(code)
     return code
 
 
 _wgrad_agreed = {}
+_wgrad_published = set()
 _store_memo = []
 
 
@@ -654,11 +674,12 @@ class StreamFlags:
         """Counter k += 1 behind everything enqueued so far on the current stream (capturable)."""
         check(lib().lfvdm_flag_add(self.buf[k].data_ptr(), stream()), "lfvdm_flag_add")
 
-    def wait(self, k, target, torch_stream, timeout_s=20.0):
-        """``torch_stream`` proceeds once counter k has reached ``target``."""
+    def wait(self, k, target, torch_stream, timeout_s=20.0, also_f32=None):
+        """``torch_stream`` proceeds once counter k has reached ``target``.  also_f32: device address of a float that a
+        timeout raises to 1.0 as well (the skip word that rides in the last gradient bucket)."""
         wrapped = ((int(target) + 2 ** 31) % 2 ** 32) - 2 ** 31        # the device counter is a wrapping int32: so is the target
-        check(lib().lfvdm_flag_wait(self.buf[k].data_ptr(), wrapped, float(timeout_s), self.buf[self.n].data_ptr(),
-                                    torch_stream.cuda_stream), "lfvdm_flag_wait")
+        check(lib().lfvdm_flag_wait2(self.buf[k].data_ptr(), wrapped, float(timeout_s), self.buf[self.n].data_ptr(), also_f32,
+                                     torch_stream.cuda_stream), "lfvdm_flag_wait2")
 
     def timed_out_ptr(self):
         """Device address of the timed-out word (lfvdm_adamw_args.skip_flag)."""

@@ -62,7 +62,10 @@ class ParamArena:
             self.bucket_ranges.append((lo, off))
         self.numel = off
         self.p = th.zeros(off, device=dev, dtype=th.float32)
-        self.g = th.zeros(off, device=dev, dtype=th.float32)
+        # four spare floats behind the last bucket: element `numel` is the exchange's skip word (a timed-out bucket wait on
+        # ANY rank raises it to 1.0; it rides in the last bucket's SUM all-reduce, _exchange.GradExchange); zero_grad clears it
+        self.g_full = th.zeros(off + 4, device=dev, dtype=th.float32)
+        self.g = self.g_full[:off]
         with th.no_grad():
             for p, o, n in zip(self.params, self.offsets, self.sizes):
                 self.p[o:o + n].copy_(p.detach().reshape(-1))
@@ -73,7 +76,7 @@ class ParamArena:
         return [flat[o:o + n].view(p.shape) for p, o, n in zip(self.params, self.offsets, self.sizes)]
 
     def zero_grad(self):
-        self.g.zero_()
+        self.g_full.zero_()
         for p, o, n in zip(self.params, self.offsets, self.sizes):
             if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:
                 p.grad = self.g[o:o + n].view(p.shape)
@@ -127,7 +130,7 @@ class TrainLoop:
         exchanging = self.world > 1 or os.environ.get("LFVDM_FORCE_EXCHANGE") == "1"
         if exchanging and not dist.is_initialized():
             dist_util.setup_dist()
-        n_buckets = int(os.environ.get("LFVDM_GRAD_BUCKETS", "4")) if exchanging else 1
+        n_buckets = int(os.environ.get("LFVDM_GRAD_BUCKETS", "5")) if exchanging else 1
         groups, marks = plan_buckets(self.model.named_parameters(), max(1, n_buckets))
         self.arena = ParamArena(self.model_params, groups)
         self.exchange = GradExchange(self.arena, marks, self.world if self.world > 1 else (2 if exchanging else 1))
@@ -560,11 +563,16 @@ class TrainLoop:
         a.bias_corr2_sqrt = math.sqrt(1.0 - self.betas[1] ** self.opt_step)
         a.grad_scale = 1.0 / self.world
         a.grad_sqsum = self.grad_sqsum.data_ptr()
-        a.skip_flag = self.exchange.skip_flag_ptr()     # a timed-out bucket wait turns this launch into a no-op
+        a.skip_flag = self.exchange.skip_flag_ptr()     # a timed-out bucket wait turns this launch into a no-op ...
+        a.skip_flag2 = self.exchange.skip_word_ptr()    # ... on every rank: the word that rode in the last bucket
         import ctypes
         nat.check(nat.lib().lfvdm_adamw_ema(ctypes.byref(a), nat.stream()), "lfvdm_adamw_ema")
         self._invalidate_engine()
-        self.exchange.poll_timeout()             # every step, no host stall (the word is read one step late)
+        try:
+            self.exchange.poll_timeout()         # every step: the words of the PREVIOUS step, read through pinned memory
+        except RuntimeError:
+            self.opt_step -= getattr(self.exchange, "skipped_steps", 0)      # bias correction counts applied steps only
+            raise
         if self.step % self.log_interval == 0:   # the only host sync of the optimizer phase
             logger.logkv_mean("grad_norm", float(np.sqrt(self.grad_sqsum.item())))
             self.exchange.poll_timeout(sync=True)

@@ -20,3 +20,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Two GPU tests create a world-1 process group INSIDE the pytest process (``dist_util.setup_dist()`` as the reference's
+    scripts do, scripts/video_train.py:93): shut it down before the interpreter exits (torch warns about a leaked
+    ProcessGroupNCCL otherwise)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass

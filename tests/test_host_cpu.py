@@ -108,7 +108,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     for name in _native.EXPORTS:
         assert name in declared, f"{name} is bound in Python but not declared in the header"
-    assert lib.lfvdm_abi_version() == 8
+    assert lib.lfvdm_abi_version() == 9
 
 
 def _loop_stub(max_frames=6, pad=True):

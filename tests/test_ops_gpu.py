@@ -1353,3 +1353,33 @@ def test_tensors_above_one_gibibyte_take_the_range_paths(nat):
         nat.check(nat.lib().lfvdm_conv_wgrad(C.byref(a), nat.stream()), "lfvdm_conv_wgrad")
         err = float((gp.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2) - w.grad).abs().max())
         assert err < 5e-4 * sw, (key, code, err, sw)
+
+
+def test_conv_wgrad_oihw_output_every_tune_code(nat):
+    """out_mode = 1 (dW written in the parameter's own OIHW layout, include/lfvdm_hip.h): the tap-fused kernels only know the
+    packed accumulator layout, so the tuner must not offer them here and a tap code set by hand must run another kernel -
+    every code gives torch's dW directly in OIHW."""
+    import ctypes as C
+    N, Cin, Cout, H, k = 4, 128, 128, 16, 3
+    x = rnd("wgo/x", N, Cin, H, H)
+    w = (rnd("wgo/w", Cout, Cin, k, k, scale=0.05)).requires_grad_(True)
+    b = rnd("wgo/b", Cout).requires_grad_(True)
+    F.conv2d(x, w, b, padding=1).backward(rnd("wgo/d", N, Cout, H, H))
+    dout = rnd("wgo/d", N, Cout, H, H)
+    g = torch.zeros(Cout, Cin, k, k, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    keep = dict(src0=cl(x), res=cl(dout))
+    a = nat.fill_conv_args(C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, ksize=k, ldr=Cout, out=g, bias=db, Cout=Cout, out_mode=1, **keep)
+    packed_codes = nat._wgrad_codes(nat.fill_conv_args(C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, ksize=k, ldr=Cout, out=g, bias=db,
+                                                       Cout=Cout, **keep))
+    taps = [c for c in packed_codes if ((c - 1) >> 2) & 3 == 0]
+    codes = nat._wgrad_codes(a)
+    assert taps and not [c for c in codes if ((c - 1) >> 2) & 3 == 0], "tap-fused codes are offered for the packed layout only"
+    scale = max(1.0, float(w.grad.abs().max()))
+    for code in [0] + codes + taps[:2]:
+        a.tune = code
+        g.zero_(); db.zero_()
+        nat.check(nat.lib().lfvdm_conv_wgrad(C.byref(a), nat.stream()), "lfvdm_conv_wgrad")
+        err = float((g.cpu() - w.grad).abs().max())
+        assert err < 2e-5 * scale, f"tune code {code}: OIHW dW max|d| = {err:.3e}"
+        assert float((db.cpu() - b.grad).abs().max()) < 2e-5 * max(1.0, float(b.grad.abs().max())), f"tune code {code}: db"
