@@ -779,6 +779,10 @@ def main():
     if n_dev == 0 or not th.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
     shared_cards = world > n_dev             # rehearsal of N ranks on fewer cards
+    if shared_cards:
+        # a persistent level chain needs its workgroups co-resident: two ranks' chains on ONE card can starve each other
+        # until the bounded waits give up (then the sampler falls back, by design) - a rehearsal runs one launch per stage
+        os.environ["LFVDM_LEVEL_CHAIN"] = "0"
     local %= n_dev
     th.cuda.set_device(local)
     dev = th.device("cuda", local)
@@ -852,7 +856,8 @@ def main():
                                                           "work_items": c["items"]} for c in pl_.chains],
                   "launches_replaced": sum(c["n"] for c in pl_.chains) - len(pl_.chains),
                   "timed_out": bool(pl_.chains_aborted()) or bool(getattr(sampler, "chain_timeouts", 0)),
-                  "fell_back": bool(getattr(pl_, "chains_off", False)) and os.environ.get("LFVDM_LEVEL_CHAIN", "1") != "0"}
+                  "fell_back": bool(getattr(pl_, "chains_off", False)) and os.environ.get("LFVDM_LEVEL_CHAIN", "1") != "0",
+                  "off_because_ranks_share_a_gpu": bool(shared_cards)}
     if chains_rec["timed_out"] or chains_rec["fell_back"]:
         raise SystemExit("bench.py: a persistent level chain timed out (LFVDM_CHAIN_TIMEOUT_S) during the timed run")
     train = None

@@ -39,7 +39,15 @@ NEXT_GN_EPILOGUE = os.environ.get("LFVDM_NEXT_GN_EPILOGUE", "1") != "0"
 # LFVDM_LEVEL_CHAIN=0: every launch of the low-resolution levels stays its own launch (A/B aid; the persistent level chain
 # is bitwise the per-launch plan with the same tile codes).  LFVDM_CHAIN_MAX_M: launches with at most this many output rows
 # (N * Ho * Wo) are candidates (640 = the 4x4 and 2x2 levels of the 20-frame, batch-2 headline configuration)
-LEVEL_CHAIN = os.environ.get("LFVDM_LEVEL_CHAIN", "1") != "0"
+def level_chain_enabled():
+    """Read when a plan is built / tuned (not at import): a process that learns late that it SHARES its GPU with another
+    process - bench.py's N-ranks-on-fewer-cards rehearsal - switches the chains off for the plans it builds afterwards.  A
+    chain needs all its workgroups co-resident; two processes' chains on one card can each get part of the CUs and wait for
+    workgroups that cannot start (every wait is bounded: the timeout raises the abort word and the sampler falls back, but
+    that costs LFVDM_CHAIN_TIMEOUT_S seconds)."""
+    return os.environ.get("LFVDM_LEVEL_CHAIN", "1") != "0"
+
+
 CHAIN_MAX_M = int(os.environ.get("LFVDM_CHAIN_MAX_M", "640"))
 CHAIN_TIMEOUT_S = float(os.environ.get("LFVDM_CHAIN_TIMEOUT_S", "2.0"))
 
@@ -112,7 +120,7 @@ class Plan:
     def scratch(self, key, rows, cols):
         """Shared scratch tensor [rows][cols] (launches are stream-ordered; a larger request replaces the buffer for
         later steps, earlier steps keep theirs)."""
-        if LEVEL_CHAIN and rows <= CHAIN_MAX_M:
+        if level_chain_enabled() and rows <= CHAIN_MAX_M:
             # low-resolution levels: a persistent level chain has no launch boundary to order the reuse of a buffer, so
             # every use gets its own (a few hundred KB each)
             return self.buf(rows * cols).view(rows, cols)
@@ -665,7 +673,7 @@ class Plan:
                 continue
             a = args[0]._obj
             key = nat.tune_key(a)
-            if LEVEL_CHAIN and a.N * a.Ho * a.Wo <= CHAIN_MAX_M and a.out_mode == nat.OUT_ROWS:
+            if level_chain_enabled() and a.N * a.Ho * a.Wo <= CHAIN_MAX_M and a.out_mode == nat.OUT_ROWS:
                 # candidate stage of a persistent level chain: the fastest code among the variants the chain kernel holds
                 # (own cache entry: the unrestricted choice of the same shape stays what the other callers get)
                 ckey = key + (nat.TUNE_CHAIN,)
@@ -820,7 +828,7 @@ class Plan:
     def build_chains(self):
         """Replace every run of >= 2 consecutive chainable launches (tuned implicit GEMMs and one-wave GroupNorms of the
         low-resolution levels) by ONE persistent launch (lfvdm_level_chain).  Idempotent; called by ``autotune``."""
-        if not LEVEL_CHAIN or self.chains or getattr(self, "chains_off", False):
+        if not level_chain_enabled() or self.chains or getattr(self, "chains_off", False):
             return 0
         head_last = self.head["step"] == len(self.steps) - 1
         out, run = [], []
