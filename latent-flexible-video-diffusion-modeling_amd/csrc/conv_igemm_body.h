@@ -290,7 +290,7 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
     f32x4 gam = {0.f, 0.f, 0.f, 0.f}, bet = gam, fsc[EPV], fsh[EPV];
     int mo[EPV];
     constexpr bool EPI_EARLY = EPV <= 2;
-    auto load_epilogue_operands = [&](bool params, bool residual) {      // each part exactly once per tile
+    auto load_epilogue_operands = [&](bool params, bool residual, bool gn_coefs) {      // each part exactly once per tile
       if (!nchw) {
         if (params) {
             if (p.bias) bsum += ld4(p.bias + cc);
@@ -327,7 +327,7 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
                 }
             }
         }
-        if (gn && params) {
+        if (gn && gn_coefs) {
             const float rPF = __builtin_amdgcn_rcpf((float)(HoWo * p.gn_film_div));
             if (cok) {
                 gam = ld4(p.gn_gamma + cc);
@@ -349,7 +349,7 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
     };
     // small tiles: parameters at once (in flight while the filter pieces are issued and - chain stage - while the item
     // waits for its producers); the residual rows with them, or - chain stage - behind the poll (K loop, first chunk)
-    if constexpr (EPI_EARLY) load_epilogue_operands(true, !CHAIN);
+    if constexpr (EPI_EARLY) load_epilogue_operands(true, !CHAIN, true);
 
   {
     // ---- LDS-DMA main loop.  `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 B to ONE contiguous 1 KiB piece
@@ -507,7 +507,7 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
         issue(kbeg + (IT_) + GL - 1, ((S_) + GL - 1) % GL);                                                    \
         /* chain stage, small tile: the residual rows (another stage's tile: legal only behind the poll) are     \
            requested behind the first chunk's wait and land under the MFMAs */                                   \
-        if constexpr (EPI_EARLY && CHAIN) { if ((IT_) == 0) load_epilogue_operands(false, true); }               \
+        if constexpr (EPI_EARLY && CHAIN) { if ((IT_) == 0) load_epilogue_operands(false, true, false); }        \
         const float* st_ = gbase + (S_) * CF::STAGE;                                                           \
         _Pragma("unroll") for (int g = 0; g < KC / 8; ++g) {                                                   \
             const f32x4 a4 = ld4(st_ + offA[g]);                                                               \
@@ -583,8 +583,6 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
     // visibility follows the agent-scope release/acquire recipe of the CDNA guide (G16): stores ->
     // every wave s_waitcnt vmcnt(0) -> barrier -> lane 0: release fence + drained ticket atomic;
     // last arriver: acquire fence -> barrier -> plain loads.
-    if constexpr (!EPI_EARLY) load_epilogue_operands(true, true);
-
     bool do_epilogue = true;
     if (KZ > 1) {
         // Slabs are published WRITE-THROUGH (16-byte `sc1` stores: the bytes leave the XCD's L2 at once, no dirty
@@ -674,6 +672,9 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
     // ---- epilogue: a thread owns 4 consecutive output columns of EPV rows: bias is read once as a
     // float4, all residual loads are issued back to back, stores are 16-byte.
     if (!nchw) {
+        // large tiles: bias / residual rows here, GroupNorm coefficients inside the normalisation (their live ranges stay
+        // apart: hoisting all of them in front of the seam cost the 64 x 128 tile half its occupancy, 143 -> 230 VGPRs)
+        if constexpr (!EPI_EARLY) load_epilogue_operands(true, true, false);
         const bool store_raw = !gn || p.gn_skip_raw == 0;
         f32x4 tv[EPV];
 #pragma unroll
@@ -701,7 +702,10 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
             // the per-channel / per-sample coefficients are fetched first: their latency hides behind the statistics
             const int P = HoWo, gw = p.Cout >> 5;
             const float rP = __builtin_amdgcn_rcpf((float)P), rgw = __builtin_amdgcn_rcpf((float)gw);   // fast_div operands here are < 2^21
-            // ---- register form (round 5): P and gw powers of two (every 64 ... 512-channel layer on 2x2 ... 8x8 maps).  The
+            if constexpr (!EPI_EARLY) load_epilogue_operands(false, false, true);
+            // ---- register form (round 5; small tiles: EPV <= 2 float4 per thread - larger tiles keep the general form, whose
+            // registers do not pile up on top of the K loop's): P and gw powers of two (every 64 ... 512-channel layer on
+            // 2x2 ... 8x8 maps).  The
             // finished values stay in their owners' registers; a unit's sums are lane butterflies over the quads of the
             // group and the rows of the sample inside a wave, plus - where a sample spans several waves - ONE exchange
             // through LDS per pass.  Two barriers instead of four, no tile rewrite, no per-unit loops: the general form
@@ -710,7 +714,7 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
             constexpr int RPW = 64 / QN;                       // tile rows per wave (QN = float4 per tile row: 8, 16 or 32)
             constexpr int QSH = QN == 8 ? 3 : QN == 16 ? 4 : 5;
             static_assert(QN == 8 || QN == 16 || QN == 32, "epilogue lane map");
-            const bool pow2 = (P & (P - 1)) == 0 && (gw & (gw - 1)) == 0 && gw >= 2 && gw <= 16 && !p.gn_general;
+            const bool pow2 = EPI_EARLY && (P & (P - 1)) == 0 && (gw & (gw - 1)) == 0 && gw >= 2 && gw <= 16 && !p.gn_general;
             if (pow2) {
                 const int q = tid & (QN - 1);
                 const bool two = gw == 2;                      // two groups per float4
