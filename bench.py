@@ -411,7 +411,9 @@ def exchange_machinery_probe(dev, steps=12):
     bucket over ONE rank on RCCL's stream behind the polling kernel, the collective skip word, the optimizer behind them."""
     os.environ["LFVDM_FORCE_EXCHANGE"] = "1"
     try:
-        return bench_train(0, 1, dev, steps, 4, probe_only=True)
+        # (8 untimed steps: the first replays next to a freshly created communicator run 0.2-0.3 ms slow - round 5 measured
+        # 7.64 ms over steps 5-16 and 7.38 over steps 6-25 of the same job, tools/exchange_probe.py)
+        return bench_train(0, 1, dev, steps, 8, probe_only=True)
     finally:
         os.environ.pop("LFVDM_FORCE_EXCHANGE", None)
 
@@ -754,7 +756,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--train-steps", type=int, default=30, help="timed optimizer steps of the training leg (0 = skip)")
-    ap.add_argument("--machinery-steps", type=int, default=12,
+    ap.add_argument("--machinery-steps", type=int, default=20,
                     help="N = 1 only: optimizer steps of the forced-exchange probe (LFVDM_FORCE_EXCHANGE=1; 0 = skip)")
     ap.add_argument("--pixel-train-steps", type=int, default=5, help="timed optimizer steps of each pixel-space training leg (0 = skip)")
     ap.add_argument("--pixel-steps", type=int, default=5, help="timed steps of the pixel-space stress config, configs[4] (0 = skip)")

@@ -123,6 +123,13 @@ typedef struct lfvdm_conv_args {
     float gn_eps;
     int32_t gn_general;     /* non-zero: the general (LDS tile) form of the fused GroupNorm even where the register form
                              * applies (P and Cout/32 powers of two) - A/B and test aid, same statistics */
+    /* the fused normalisation as ONE HALF of a GroupNorm over a channel concat (the first normalisation of a decoder
+     * ResBlock, unet.py:460 + :152-155: 32 groups over C0 + C1 channels, whose group boundaries never straddle the concat
+     * when (C0 + C1) / 32 divides C0): gn_gw = channels per group (0: Cout / 32), gn_ld = row stride of gn_out (0: Cout; the
+     * concat's width when gn_out is the left part of the consumer's operand - the other half comes from lfvdm_gn_apply_part);
+     * gn_gamma / gn_beta point at this half's first channel */
+    int32_t gn_gw;
+    int32_t gn_ld;
 } lfvdm_conv_args;
 
 int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream);
@@ -236,6 +243,12 @@ int lfvdm_gn_coef(const float* src0, const float* src1, int C0, int C1, int N, i
 int lfvdm_gn_apply(const float* src0, const float* src1, int C0, int C1, int N, int P,
                    const float* gamma, const float* beta, const float* film, int film_div, int film_ld,
                    float eps, int act, float* out, float* coefA, float* coefB, float* stats, void* stream);
+/* A PART of a GroupNorm over a wider tensor: C channels of src [N][P][C] normalised in groups of `cg` channels (2, 4, 8, 16;
+ * C % 16 == 0, P <= 256: the one-wave kernel), gamma / beta pointing at the part's first channel, written to
+ * out[(n*P + p) * ldo + c].  With lfvdm_conv_args.gn_gw / gn_ld this evaluates the GroupNorm over a channel concat half by
+ * half - each half where its tensor is produced - instead of materialising the concat first. */
+int lfvdm_gn_apply_part(const float* src, int C, int N, int P, int cg, const float* gamma, const float* beta, float eps, int act,
+                        float* out, int ldo, void* stream);
 /* lfvdm_gn_apply for LARGE maps (pixel space, 32x32 latents): when a (sample, 8 groups) slice does not fit the registers of
  * one workgroup, the slice is cut into chunks of positions owned by separate workgroups - chunk statistics (exact two-pass
  * mean / M2 per group) into `ws`, then every workgroup combines the partials of its groups in a fixed order (Chan et al.)
@@ -613,7 +626,12 @@ typedef struct lfvdm_gn_args {       /* lfvdm_gn_apply's arguments (one-wave for
     int32_t film_div, film_ld;
     float eps;
     int32_t act;
-    float* out;
+    float* out;              /* first element this stage writes */
+    int32_t cg;              /* channels per group (0: (C0 + C1) / 32): a PART of a wider normalisation (lfvdm_gn_apply_part) */
+    int32_t ldo;             /* row stride of out (0: C0 + C1) */
+    float* out_base;         /* the buffer `out` points into (NULL: out) and its first column there: what readers of the */
+    int32_t out_col;         /* buffer are matched against when dependencies are planned */
+    int32_t pad_;
 } lfvdm_gn_args;
 
 typedef struct lfvdm_chain_stage {
@@ -627,7 +645,8 @@ typedef struct lfvdm_chain_stage {
     int32_t cfg;             /* conv: kernel-body instance */
     int32_t kz;              /* conv: K slices over workgroups */
     int32_t nt2;             /* conv: filter tiles */
-    int32_t pad_;
+    int32_t wg_off;          /* work item i runs on workgroup (i + wg_off) mod grid: stages that depend on nothing inside the
+                              * chain (the skip half of a concat GroupNorm) are put on the workgroups the GEMM stages leave idle */
     int64_t ws_off;          /* conv: this stage's slab region (floats) and ticket region (ints) in the chain's workspace */
     int64_t cnt_off;
     lfvdm_conv_args conv;

@@ -212,6 +212,8 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
     if (9L * Cin + C2 >= (1L << 20)) return LFVDM_E_UNSUPPORTED;     // K-slice arithmetic of the kernel: NK * KZ < 2^21
     if (a->gn_out && (!a->gn_gamma || !a->gn_beta || a->gn_film_div <= 0 || (a->gn_film && a->gn_film_ld < 2 * a->Cout)))
         return LFVDM_E_SHAPE;
+    if (a->gn_out && ((a->gn_gw && (a->gn_gw < 0 || a->Cout % a->gn_gw)) || (a->gn_ld && (a->gn_ld < a->Cout || a->gn_ld % 4))))
+        return LFVDM_E_SHAPE;
     if (glds_ok(a)) return conv_igemm_one(a, s);
     // Per-lane byte offsets are 32-bit and end below 2^30: a batch whose tensors exceed that (pixel space at large
     // batch) is processed in sample ranges - samples are independent in every operand and in the fused GroupNorm; the
@@ -235,7 +237,7 @@ extern "C" int lfvdm_conv_igemm(const lfvdm_conv_args* a, void* stream) {
         if (a->resA) { b.resA = a->resA + n0 * a->Cout; b.resB = a->resB + n0 * a->Cout; }
         b.out = a->out + (a->out_mode == LFVDM_OUT_NCHW ? n0 * a->Cout * P : n0 * P * a->ldo);
         if (a->gn_out) {
-            b.gn_out = a->gn_out + n0 * P * a->Cout;
+            b.gn_out = a->gn_out + n0 * P * (a->gn_ld ? a->gn_ld : a->Cout);
             if (a->gn_film) b.gn_film = a->gn_film + (n0 / a->gn_film_div) * a->gn_film_ld;
         }
         if (!glds_ok(&b)) return LFVDM_E_UNSUPPORTED;

@@ -700,7 +700,7 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
             // back into group 0's LDS tile (each element is read and rewritten by its one owner thread), then one
             // exact two-pass mean / variance per (sample, group) unit, then the affine on the registers.
             // the per-channel / per-sample coefficients are fetched first: their latency hides behind the statistics
-            const int P = HoWo, gw = p.Cout >> 5;
+            const int P = HoWo, gw = p.gn_gw ? p.gn_gw : p.Cout >> 5, gld = p.gn_ld ? p.gn_ld : p.Cout;
             const float rP = __builtin_amdgcn_rcpf((float)P), rgw = __builtin_amdgcn_rcpf((float)gw);   // fast_div operands here are < 2^21
             if constexpr (!EPI_EARLY) load_epilogue_operands(false, false, true);
             // ---- register form (round 5; small tiles: EPV <= 2 float4 per thread - larger tiles keep the general form, whose
@@ -822,8 +822,8 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
                             }
                             f32x4 y = tv[i] * A + B;
                             if (p.gn_act == LFVDM_ACT_SILU) { y.x = silu_f(y.x); y.y = silu_f(y.y); y.z = silu_f(y.z); y.w = silu_f(y.w); }
-                            if constexpr (CHAIN) st4_sc1(whole_rsrc(p.gn_out), (unsigned)(m * p.Cout + co) * 4u, y);
-                            else st4(p.gn_out + ((size_t)m * p.Cout + co), y);
+                            if constexpr (CHAIN) st4_sc1(whole_rsrc(p.gn_out), (unsigned)(m * gld + co) * 4u, y);
+                            else st4(p.gn_out + ((size_t)m * gld + co), y);
                         }
                     }
                 }
@@ -896,8 +896,8 @@ __device__ __forceinline__ bool conv_igemm_body(const lfvdm_conv_args& p, int hy
                         }
                         f32x4 y = tv[i] * A + B;
                         if (p.gn_act == LFVDM_ACT_SILU) { y.x = silu_f(y.x); y.y = silu_f(y.y); y.z = silu_f(y.z); y.w = silu_f(y.w); }
-                        if constexpr (CHAIN) st4_sc1(whole_rsrc(p.gn_out), (unsigned)(m * p.Cout + co) * 4u, y);
-                        else st4(p.gn_out + ((size_t)m * p.Cout + co), y);
+                        if constexpr (CHAIN) st4_sc1(whole_rsrc(p.gn_out), (unsigned)(m * gld + co) * 4u, y);
+                        else st4(p.gn_out + ((size_t)m * gld + co), y);
                     }
                 }
             }
@@ -999,7 +999,7 @@ inline int encode_tune(int id, int kch, int kz, int gl) {
 // fused output GroupNorm: the tile must hold whole samples and whole groups, and the unit statistics must fit
 // behind the reduction tile in the first k-group's LDS (checked against the smallest stage layout: 2 stages of 32 channels)
 inline bool gn_tile_ok(const lfvdm_conv_args* a, int BM, int BN) {
-    const int P = a->Ho * a->Wo, gw = a->Cout / 32;
+    const int P = a->Ho * a->Wo, gw = a->gn_gw ? a->gn_gw : a->Cout / 32;
     if (a->Cout % 32 || a->out_mode != LFVDM_OUT_ROWS || P <= 0 || BM % P || gw <= 0 || BN % gw || a->Cout % 4) return false;
     const int U = (BM / P) * (BN / gw);
     return BM * (BN + 1) + 2 * U <= 2 * (BM + BN) * 32;

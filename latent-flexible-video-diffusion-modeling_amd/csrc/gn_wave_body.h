@@ -24,9 +24,10 @@ __device__ __forceinline__ void gn_wave_body(
     int n, int cb, int lane, const float* __restrict__ s0, const float* __restrict__ s1, int C0, int C1, int P,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
     int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats,
-    float* __restrict__ act_out, int act_mode) {
+    float* __restrict__ act_out, int act_mode, int ldo = 0) {
     constexpr int KEEP = 16;
     const int C = C0 + C1;
+    if (ldo == 0) ldo = C;              // row stride of act_out (a part of a wider tensor: lfvdm_gn_apply_part)
     const int q = lane & 3, pl = lane >> 2;
     const int c = cb * 16 + q * 4;
     const size_t pos0 = (size_t)n * P;
@@ -108,8 +109,8 @@ __device__ __forceinline__ void gn_wave_body(
             if constexpr (CHAIN)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
                                                        __builtin_amdgcn_make_buffer_rsrc((void*)act_out, 0, 0x7fffffff, 0x00020000),
-                                                       (int)(((unsigned)(pos0 + p) * (unsigned)C + (unsigned)c) * 4u), 0, 16 /* sc1 */);
-            else st4(act_out + (pos0 + p) * C + c, v);
+                                                       (int)(((unsigned)(pos0 + p) * (unsigned)ldo + (unsigned)c) * 4u), 0, 16 /* sc1 */);
+            else st4(act_out + (pos0 + p) * ldo + c, v);
         }
     }
 }

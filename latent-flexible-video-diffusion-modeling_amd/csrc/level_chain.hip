@@ -69,7 +69,9 @@ __global__ __launch_bounds__(kChainThreads) void level_chain_kernel(const lfvdm_
     for (int s = 0; s < n_stages && alive; ++s) {
         const StagePtr st = stages + s;
         const int kind = st->kind, n_items = st->n_items, dstride = st->dep_stride, dbase = st->dep_base;
-        for (int item = blockIdx.x; item < n_items && alive; item += gridDim.x) {
+        int first = (int)blockIdx.x - st->wg_off;          // (wg_off < gridDim.x: lfvdm_chain_plan)
+        if (first < 0) first += (int)gridDim.x;
+        for (int item = first; item < n_items && alive; item += gridDim.x) {
             __syncthreads();          // the previous item's LDS tiles are no longer read
             const DepPtr dl = deps + dbase + (size_t)item * dstride;
             ChainCtx cx;
@@ -109,13 +111,13 @@ __global__ __launch_bounds__(kChainThreads) void level_chain_kernel(const lfvdm_
                     break;
                 }
                 CSTAMP(s, 17);
-                const int C = g.C0 + g.C1, cbs = C >> 4, cg = C >> 5;
+                const int C = g.C0 + g.C1, cbs = C >> 4, cg = g.cg ? g.cg : C >> 5, ldo = g.ldo ? g.ldo : C;
                 const int u = item * 4 + wave;
                 if (u < g.N * cbs) {
                     const int n = u / cbs, cb = u - n * cbs;
 #define LFVDM_GNB(G)                                                                                                          \
     gn_wave_body<G, true>(n, cb, lane, g.src0, g.src1, g.C0, g.C1, g.P, g.gamma, g.beta, g.film, g.film_div, g.film_ld, g.eps, \
-                          nullptr, nullptr, nullptr, g.out, g.act)
+                          nullptr, nullptr, nullptr, g.out, g.act, ldo)
                     if (cg == 2) LFVDM_GNB(2);
                     else if (cg == 4) LFVDM_GNB(4);
                     else if (cg == 8) LFVDM_GNB(8);
@@ -163,7 +165,7 @@ bool conv_stage_ok(const lfvdm_conv_args* a, Pick2* pk) {
     if (!glds_ok(a)) return false;
     // 32-bit byte offsets of the sc1 epilogue accesses
     const long M = (long)a->N * a->Ho * a->Wo;
-    if (M * std::max(a->ldo, std::max(a->ldr, a->Cout)) * 4 >= (1L << 31)) return false;
+    if (M * std::max(std::max(a->ldo, a->gn_ld), std::max(a->ldr, a->Cout)) * 4 >= (1L << 31)) return false;
     lfvdm_conv_args b = *a;        // capacity checks of cfg_valid against a notional workspace: the plan sizes the real one
     b.splitk_ws = (float*)(uintptr_t)16;
     b.splitk_cnt = (int32_t*)(uintptr_t)16;
@@ -172,8 +174,8 @@ bool conv_stage_ok(const lfvdm_conv_args* a, Pick2* pk) {
     return cfg_valid(&b, pk->id, pk->kch, pk->kz, pk->gl);
 }
 
-bool gn_stage_ok(int C0, int C1, int N, int P) {
-    const int C = C0 + C1, cg = C / 32;
+bool gn_stage_ok(int C0, int C1, int N, int P, int cg_given = 0) {
+    const int C = C0 + C1, cg = cg_given ? cg_given : C / 32;
     return N > 0 && P > 0 && P <= 256 && C % 64 == 0 && C0 % 16 == 0 && (cg == 2 || cg == 4 || cg == 8 || cg == 16) &&
            (long)N * P * C * 4 < (1L << 31);
 }
@@ -186,6 +188,7 @@ struct Writer {
     int P, cbs4;          // gn: rows per sample, 64-column blocks per sample;  flag = flag_base + n * cbs4 + j
     int flag_base;
     long rows, cols;
+    long col0;            // first column of the buffer this writer covers (a concat operand written half by half)
 };
 
 }  // namespace
@@ -201,26 +204,28 @@ extern "C" int lfvdm_chain_plan(lfvdm_chain_stage* stages, int n_stages, int32_t
                                 int32_t* n_flags_out, int64_t* ws_floats, int64_t* cnt_ints, int32_t* grid_out, int32_t* lds_out) {
     if (!stages || n_stages <= 0 || !deps || !deps_used || !n_flags_out || !ws_floats || !cnt_ints || !grid_out || !lds_out)
         return LFVDM_E_SHAPE;
-    std::map<const float*, Writer> writers;
-    std::set<const float*> touched;          // every buffer read or written so far: a later write to one of them has no
-                                             // launch boundary to order it
+    std::multimap<const float*, Writer> writers;      // (a buffer may have several writers, each with its own columns)
+    std::set<const float*> was_read;         // a later write to a buffer that was read (or to columns that were written)
+                                             // has no launch boundary to order it: refused
     long nflags = 0, ndeps = 0, ws = 0, cnt = 0;
     int grid = 1, lds = 0;
 
     // flags of the units of `w` that overlap rows [r0, r1) x columns [c0, c1)
     auto add_region = [&](std::vector<int>& out, const float* base, long r0, long r1, long c0, long c1) {
         if (!base || r1 <= r0 || c1 <= c0) return;
-        auto it = writers.find(base);
-        if (it == writers.end()) return;            // produced by an earlier launch: ordered by the launch boundary
-        const Writer& w = it->second;
-        r1 = std::min(r1, w.rows);
-        c1 = std::min(c1, w.cols);
-        if (w.conv) {
-            for (long by = c0 / w.BN; by <= (c1 - 1) / w.BN; ++by)
-                for (long bx = r0 / w.BM; bx <= (r1 - 1) / w.BM; ++bx) out.push_back(w.flag_base + (int)(by * w.MT + bx));
-        } else {
-            for (long n = r0 / w.P; n <= (r1 - 1) / w.P; ++n)
-                for (long j = c0 / 64; j <= (c1 - 1) / 64; ++j) out.push_back(w.flag_base + (int)(n * w.cbs4 + j));
+        auto range = writers.equal_range(base);     // (none: produced by an earlier launch, ordered by the launch boundary)
+        for (auto it = range.first; it != range.second; ++it) {
+            const Writer& w = it->second;
+            const long rr1 = std::min(r1, w.rows);
+            const long a0 = std::max(c0, w.col0) - w.col0, a1 = std::min(c1, w.col0 + w.cols) - w.col0;   // in the writer's columns
+            if (rr1 <= r0 || a1 <= a0) continue;
+            if (w.conv) {
+                for (long by = a0 / w.BN; by <= (a1 - 1) / w.BN; ++by)
+                    for (long bx = r0 / w.BM; bx <= (rr1 - 1) / w.BM; ++bx) out.push_back(w.flag_base + (int)(by * w.MT + bx));
+            } else {
+                for (long n = r0 / w.P; n <= (rr1 - 1) / w.P; ++n)
+                    for (long j = a0 / 64; j <= (a1 - 1) / 64; ++j) out.push_back(w.flag_base + (int)(n * w.cbs4 + j));
+            }
         }
     };
     // columns [c0, c1) of a virtual concat (a | b) -> regions of a and b
@@ -228,10 +233,12 @@ extern "C" int lfvdm_chain_plan(lfvdm_chain_stage* stages, int n_stages, int32_t
         if (c0 < Ca) add_region(out, a, r0, r1, c0, std::min<long>(c1, Ca));
         if (c1 > Ca) add_region(out, b, r0, r1, std::max<long>(c0, Ca) - Ca, c1 - Ca);
     };
-    auto note_write = [&](const float* base) {
+    auto note_write = [&](const float* base, long col0, long cols) {
         if (!base) return true;
-        if (touched.count(base)) return false;
-        touched.insert(base);
+        if (was_read.count(base)) return false;
+        auto range = writers.equal_range(base);
+        for (auto it = range.first; it != range.second; ++it)
+            if (col0 < it->second.col0 + it->second.cols && it->second.col0 < col0 + cols) return false;
         return true;
     };
 
@@ -291,21 +298,24 @@ extern "C" int lfvdm_chain_plan(lfvdm_chain_stage* stages, int n_stages, int32_t
                 if ((int)d.size() > LFVDM_CHAIN_MAX_DEPS) return LFVDM_E_UNSUPPORTED;
             }
             for (const float* r : {a.src0, a.src1, a.s2src0, a.s2src1, a.res})
-                if (r) touched.insert(r);
+                if (r) was_read.insert(r);
             const bool raw = !(a.gn_out && a.gn_skip_raw);
-            Writer w{s, true, BM, BN, MT, 0, 0, st.flag_base, M, a.Cout};
+            const Writer w{s, true, BM, BN, MT, 0, 0, st.flag_base, M, a.Cout, 0};
             if (raw) {
-                if (!note_write(a.out)) return LFVDM_E_UNSUPPORTED;
-                writers[a.out] = w;
+                if (!note_write(a.out, 0, a.Cout)) return LFVDM_E_UNSUPPORTED;
+                writers.insert({a.out, w});
             }
-            if (a.gn_out) {
-                if (!note_write(a.gn_out)) return LFVDM_E_UNSUPPORTED;
-                writers[a.gn_out] = w;
+            if (a.gn_out) {         // (gn_ld > Cout: the left part of a wider operand; columns [0, Cout) of it)
+                if (!note_write(a.gn_out, 0, a.Cout)) return LFVDM_E_UNSUPPORTED;
+                writers.insert({a.gn_out, w});
             }
         } else if (st.kind == LFVDM_CHAIN_GN) {
             const lfvdm_gn_args& g = st.gn;
-            if (!gn_stage_ok(g.C0, g.C1, g.N, g.P) || !g.src0 || !g.out || (g.C1 > 0 && !g.src1) || (g.film && g.film_div <= 0))
+            if (!gn_stage_ok(g.C0, g.C1, g.N, g.P, g.cg) || !g.src0 || !g.out || (g.C1 > 0 && !g.src1) || (g.film && g.film_div <= 0))
                 return LFVDM_E_UNSUPPORTED;
+            if ((g.ldo && (g.ldo < g.C0 + g.C1 || g.ldo % 4)) || (long)g.N * g.P * std::max(g.ldo, g.C0 + g.C1) * 4 >= (1L << 31) ||
+                (g.out_base && (g.out_col < 0 || g.out != g.out_base + g.out_col)))
+                return LFVDM_E_SHAPE;
             const int C = g.C0 + g.C1, cbs4 = C / 64;
             st.n_items = g.N * cbs4;
             st.n_flags = st.n_items;
@@ -319,10 +329,11 @@ extern "C" int lfvdm_chain_plan(lfvdm_chain_stage* stages, int n_stages, int32_t
                 d.erase(std::unique(d.begin(), d.end()), d.end());
                 if ((int)d.size() > LFVDM_CHAIN_MAX_DEPS) return LFVDM_E_UNSUPPORTED;
             }
-            touched.insert(g.src0);
-            if (g.src1) touched.insert(g.src1);
-            if (!note_write(g.out)) return LFVDM_E_UNSUPPORTED;
-            writers[g.out] = Writer{s, false, 0, 0, 0, g.P, cbs4, st.flag_base, (long)g.N * g.P, C};
+            was_read.insert(g.src0);
+            if (g.src1) was_read.insert(g.src1);
+            const float* base = g.out_base ? g.out_base : g.out;
+            if (!note_write(base, g.out_col, C)) return LFVDM_E_UNSUPPORTED;
+            writers.insert({base, Writer{s, false, 0, 0, 0, g.P, cbs4, st.flag_base, (long)g.N * g.P, C, g.out_col}});
         } else {
             return LFVDM_E_SHAPE;
         }
@@ -338,6 +349,17 @@ extern "C" int lfvdm_chain_plan(lfvdm_chain_stage* stages, int n_stages, int32_t
         ndeps += (long)st.n_items * st.dep_stride;
         nflags += st.n_flags;
         grid = std::max(grid, std::min(st.n_items, 256));
+    }
+    // stages none of whose items waits for anything inside the chain (the skip half of a concat GroupNorm: its source
+    // comes from an earlier launch) go to the workgroups at the top of the grid, which the GEMM stages - 24 ... 240 work
+    // items, assigned from workgroup 0 upwards - mostly leave idle: they run at once, beside the chain's critical path
+    for (int s = 0; s < n_stages; ++s) {
+        lfvdm_chain_stage& st = stages[s];
+        st.wg_off = 0;
+        if (st.kind != LFVDM_CHAIN_GN || st.n_items > grid) continue;
+        bool free_standing = true;
+        for (int id = 0; id < st.n_items && free_standing; ++id) free_standing = deps[st.dep_base + (long)id * st.dep_stride] == 0;
+        if (free_standing) st.wg_off = grid - st.n_items;
     }
     *deps_used = ndeps;
     *n_flags_out = (int32_t)nflags;

@@ -162,9 +162,9 @@ __global__ __launch_bounds__(64) void gn_wave_kernel(
     const float* __restrict__ s0, const float* __restrict__ s1, int C0, int C1, int P,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
     int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats,
-    float* __restrict__ act_out, int act_mode) {
+    float* __restrict__ act_out, int act_mode, int ldo) {
     gn_wave_body<CG, false>(blockIdx.x, blockIdx.y, threadIdx.x, s0, s1, C0, C1, P, gamma, beta, film, film_div, film_ld, eps, coefA,
-                            coefB, stats, act_out, act_mode);
+                            coefB, stats, act_out, act_mode, ldo);
 }
 
 // one wave per (sample, 16 channels) when the map and the group width allow it; false = use the workgroup kernels
@@ -177,7 +177,7 @@ inline bool gn_wave_launch(const float* src0, const float* src1, int C0, int C1,
     const dim3 grid(N, C / 16);
 #define LFVDM_GNW(G)                                                                                                   \
     hipLaunchKernelGGL(gn_wave_kernel<G>, grid, dim3(64), 0, s, src0, src1, C0, C1, P, gamma, beta, film, film_div, film_ld, \
-                       eps, coefA, coefB, stats, out, act)
+                       eps, coefA, coefB, stats, out, act, 0)
     if (cg == 2) LFVDM_GNW(2);
     else if (cg == 4) LFVDM_GNW(4);
     else if (cg == 8) LFVDM_GNW(8);
@@ -1007,6 +1007,25 @@ extern "C" int lfvdm_gn_apply(const float* src0, const float* src1, int C0, int 
     else
         hipLaunchKernelGGL(gn_coef_kernel<8>, dim3(N, 32 / GN_GPW), dim3(GN_THREADS), 0, (hipStream_t)stream, src0, src1, C0,
                            C1, P, gamma, beta, film, film_div, film_ld, eps, coefA, coefB, stats, out, act);
+    LFVDM_CHECK_LAUNCH();
+    return LFVDM_OK;
+}
+
+extern "C" int lfvdm_gn_apply_part(const float* src, int C, int N, int P, int cg, const float* gamma, const float* beta, float eps,
+                                   int act, float* out, int ldo, void* stream) {
+    if (!src || !gamma || !beta || !out || N <= 0 || N > 65535 || P <= 0 || P > 256 || C <= 0 || C % 16 || ldo < C || ldo % 4)
+        return LFVDM_E_SHAPE;
+    if ((cg != 2 && cg != 4 && cg != 8 && cg != 16) || C % cg) return LFVDM_E_UNSUPPORTED;
+    const dim3 grid(N, C / 16);
+    hipStream_t s = (hipStream_t)stream;
+#define LFVDM_GNP(G)                                                                                                          \
+    hipLaunchKernelGGL(gn_wave_kernel<G>, grid, dim3(64), 0, s, src, (const float*)nullptr, C, 0, P, gamma, beta, (const float*)nullptr, \
+                       1, 0, eps, (float*)nullptr, (float*)nullptr, (float*)nullptr, out, act, ldo)
+    if (cg == 2) LFVDM_GNP(2);
+    else if (cg == 4) LFVDM_GNP(4);
+    else if (cg == 8) LFVDM_GNP(8);
+    else LFVDM_GNP(16);
+#undef LFVDM_GNP
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -199,6 +199,7 @@ class Plan:
             a.gn_film_ld = self.rows_ld if film is not None else 0
             a.gn_film_div = self.T if film is not None else 1
             a.gn_act, a.gn_skip_raw, a.gn_eps = g("gn_act", nat.ACT_NONE), int(g("gn_skip_raw", 0)), gn.eps
+            a.gn_gw, a.gn_ld = int(g("gn_gw", 0)), int(g("gn_ld", 0))
         # shared split-K workspace (launches are stream-ordered, so one buffer serves every conv of the plan)
         if getattr(self, "splitk_ws", None) is None:
             self.splitk_ws = self.buf(2 * 1024 * 1024)                      # 8 MiB of slabs
@@ -383,17 +384,23 @@ class Plan:
         cur = dict(parts=[(h0, ch)], H=H, W=W)
         hs = [cur]
         stages = list(m.input_blocks)[1:] + [m.middle_block]
+        outs = list(m.output_blocks)
         for i, blk in enumerate(stages):
             # the layer that consumes this stage's output (when it is not a concat): lets the stage's last GEMM
             # evaluate that layer's first GroupNorm + SiLU in its epilogue at the low-resolution levels
             nxt = stages[i + 1][0] if i + 1 < len(stages) else None
-            cur = self._stage(blk, cur, after=nxt)
-            if blk is not m.middle_block:
+            if blk is m.middle_block:       # its output is concatenated with the last skip by output_blocks[0]
+                cur = self._stage(blk, cur, after_cat=(outs[0][0], hs[-1]) if outs else None)
+            else:
+                cur = self._stage(blk, cur, after=nxt)
                 hs.append(dict(parts=cur["parts"], H=cur["H"], W=cur["W"]))      # (the skip carries no pre-activation)
-        for blk in m.output_blocks:
+        for i, blk in enumerate(outs):
             skip = hs.pop()
             assert skip["H"] == cur["H"] and len(cur["parts"]) == 1 and len(skip["parts"]) == 1
-            cur = self._stage(blk, dict(parts=cur["parts"] + skip["parts"], H=cur["H"], W=cur["W"]))
+            cat_act = cur.get("act1cat")            # GroupNorm + SiLU of the concat, already evaluated half by half
+            nxt_cat = (outs[i + 1][0], hs[-1]) if i + 1 < len(outs) and hs else None
+            cur = self._stage(blk, dict(parts=cur["parts"] + skip["parts"], H=cur["H"], W=cur["W"],
+                                        **({"act1": cat_act} if cat_act is not None else {})), after_cat=nxt_cat)
             cur.pop("act1", None)
         # head: GN + SiLU + 3x3 conv straight into the (B,T,C,H,W) layout
         (hb, hc), = cur["parts"]
@@ -406,12 +413,18 @@ class Plan:
         self.head = dict(act=act, Wp=wp, bias=conv.bias, C=hc, Cout=m.out_channels, step=len(self.steps) - 1)
         self.head_fused = False
 
-    def _stage(self, blk, cur, after=None):
+    def _stage(self, blk, cur, after=None, after_cat=None):
+        """after: the layer that consumes the stage's output as it is; after_cat = (ResBlock, skip): the decoder ResBlock that
+        consumes it CONCATENATED with a skip tensor (unet.py:460)."""
         from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
         layers = list(blk)
         for i, layer in enumerate(layers):
-            nxt = layers[i + 1] if i + 1 < len(layers) else after
+            last = i + 1 == len(layers)
+            nxt = layers[i + 1] if not last else after
             ngn = nxt.in_layers[0] if (isinstance(nxt, ResBlock) and NEXT_GN_EPILOGUE) else None
+            self._cat_next = None
+            if last and after_cat is not None and isinstance(after_cat[0], ResBlock) and NEXT_GN_EPILOGUE:
+                self._cat_next = after_cat          # read by _final_conv of this layer's last GEMM
             if isinstance(layer, ResBlock):
                 cur = self._res(layer, cur, ngn)
             elif isinstance(layer, FactorizedAttentionBlock):
@@ -422,6 +435,7 @@ class Plan:
                 cur = self._resample(layer.conv, cur, False, None)
             else:
                 raise NotImplementedError(type(layer))
+        self._cat_next = None
         return cur
 
     def _final_conv(self, kw, next_gn, M):
@@ -431,8 +445,43 @@ class Plan:
             actn = self.scratch("actn", M, kw["Cout"])
             if self.conv_fused_gn(gn=next_gn, gn_out=actn, gn_act=nat.ACT_SILU, gn_skip_raw=0, **kw):
                 return actn
+        cat = getattr(self, "_cat_next", None)
+        if cat is not None and self._final_conv_cat(kw, cat, M):
+            return None          # (the consumer finds the normalised concat in self._cat_done)
         self.add_conv(**kw)
         return None
+
+    def _final_conv_cat(self, kw, cat, M):
+        """The consumer is a decoder ResBlock that normalises concat(this output, skip) first (unet.py:460, :152-155).  With
+        gw = (C0 + C1) / 32 dividing both halves no group straddles the concat, so GroupNorm32 + SiLU of the concat is the
+        two halves normalised on their own: the left half in THIS GEMM's epilogue (gn_gw / gn_ld: written into the left
+        columns of the consumer's operand), the skip half by one lfvdm_gn_apply_part that depends on nothing the decoder
+        computes - in a persistent level chain it runs ahead, off the critical path, where lfvdm_gn_apply on the concat was
+        a stage of its own between two GEMMs (2.3 us + two flag hops, four times per denoising step).  Low-resolution
+        levels only (tiles that hold whole samples; M <= LFVDM_CHAIN_MAX_M).  -> True if the steps were added."""
+        rb, skip = cat
+        (sb, C1), = skip["parts"]
+        C0, L = kw["Cout"], nat.lib()
+        N, P = kw["N"], kw["Ho"] * kw["Wo"]
+        Ccat = C0 + C1
+        gw = Ccat // 32
+        gn = rb.in_layers[0]
+        if (not level_chain_enabled() or M > CHAIN_MAX_M or gn.weight.shape[0] != Ccat or Ccat % 32 or C0 % gw or C1 % gw
+                or gw not in (2, 4, 8, 16) or C1 % 64 or P > 256 or skip["H"] * skip["W"] != P):
+            return False
+        act = self.buf(M, Ccat)
+        a = self.conv_args(gn=gn, gn_out=act, gn_act=nat.ACT_SILU, gn_skip_raw=0, gn_gw=gw, gn_ld=Ccat, **kw)
+        nt, nw = C.c_int(), C.c_int()
+        if not GN_EPILOGUE or L.lfvdm_conv_igemm_config(C.byref(a), C.byref(nt), C.byref(nw)) != 0:
+            return False
+        out_ptr = _p(act) + 4 * C0
+        self.part_bases = getattr(self, "part_bases", {})
+        self.part_bases[out_ptr] = (_p(act), C0)
+        self.add(L.lfvdm_gn_apply_part, _p(sb), C1, N, P, gw, _p(gn.weight) + 4 * C0, _p(gn.bias) + 4 * C0, gn.eps, nat.ACT_SILU,
+                 out_ptr, Ccat)
+        self.add_conv_args(a)
+        self._cat_done = act
+        return True
 
     def _res(self, rb, cur, next_gn=None):
         L = nat.lib()
@@ -476,6 +525,8 @@ class Plan:
         res = dict(parts=[(out, Cout)], H=H, W=W)
         if nact is not None:
             res["act1"] = nact
+        if getattr(self, "_cat_done", None) is not None:
+            res["act1cat"], self._cat_done = self._cat_done, None
         return res
 
     def _attn(self, ab, cur, next_gn=None):
@@ -529,6 +580,8 @@ class Plan:
         res = dict(parts=[(ys, Cc)], H=H, W=W)
         if nact is not None:
             res["act1"] = nact
+        if getattr(self, "_cat_done", None) is not None:
+            res["act1cat"], self._cat_done = self._cat_done, None
         return res
 
     def _resample(self, conv, cur, down, next_gn=None):
@@ -543,6 +596,8 @@ class Plan:
         res = dict(parts=[(out, Cc)], H=Ho, W=Wo)
         if nact is not None:
             res["act1"] = nact
+        if getattr(self, "_cat_done", None) is not None:
+            res["act1cat"], self._cat_done = self._cat_done, None
         return res
 
     # ------------------------------------------------------------------ timestep tables (sampler plans)
@@ -706,6 +761,17 @@ class Plan:
             st.kind = nat.CHAIN_CONV
             C.memmove(C.byref(st.conv), C.byref(a), C.sizeof(nat.ConvArgs))
             return st
+        if fn is L.lfvdm_gn_apply_part:
+            (src, Cp, N, P, cg, gamma, beta, eps, act, out, ldo) = args
+            if N * P > CHAIN_MAX_M or L.lfvdm_chain_gn_ok(Cp, 0, N, P) != 0:
+                return None
+            st.kind = nat.CHAIN_GN
+            g = st.gn
+            g.src0, g.src1, g.C0, g.C1, g.N, g.P = src, None, Cp, 0, N, P
+            g.gamma, g.beta, g.film, g.film_div, g.film_ld, g.eps, g.act, g.out = gamma, beta, None, 1, 0, eps, act, out
+            g.cg, g.ldo = cg, ldo
+            g.out_base, g.out_col = self.part_bases[out]
+            return st
         if fn is L.lfvdm_gn_apply:
             (src0, src1, C0, C1, N, P, gamma, beta, film, film_div, film_ld, eps, act, out, cA, cB, stats) = args
             if N * P > CHAIN_MAX_M or cA or cB or stats or L.lfvdm_chain_gn_ok(C0, C1, N, P) != 0:
@@ -722,6 +788,14 @@ class Plan:
         device tables live only as long as the returned dict (the in-chain tuner builds hundreds of candidates)."""
         L = nat.lib()
         n = len(run)
+        # stages that read nothing the chain produces (the skip half of a concat GroupNorm) first: the planner puts them on
+        # idle workgroups, and a workgroup walks the stages in list order - at the front they run at once
+        produced = set()
+        for _, st in run:
+            produced |= ({st.conv.out, st.conv.gn_out} if st.kind == nat.CHAIN_CONV else {st.gn.out_base or st.gn.out})
+        produced.discard(None)
+        free = [(sp, st) for sp, st in run if st.kind == nat.CHAIN_GN and st.gn.src0 not in produced and st.gn.src1 not in produced]
+        run = free + [(sp, st) for sp, st in run if not any(st is f for _, f in free)]
         stages = (nat.ChainStage * n)(*[st for _, st in run])
         cap = 1 << 20
         deps = (C.c_int32 * cap)()
@@ -742,7 +816,7 @@ class Plan:
         deps_dev = th.frombuffer(bytearray(bytes(memoryview(deps))[:4 * max(1, used.value)]), dtype=th.int32).to(self.dev)
         flags = th.zeros(max(1, n_flags.value), dtype=th.int32, device=self.dev)
         ctl = th.zeros(nat.CHAIN_CTL_INTS, dtype=th.int32, device=self.dev)
-        ch = dict(steps=[st for st, _ in run], run=list(run), n=n, ctl=ctl, grid=grid.value, lds=lds.value,
+        ch = dict(steps=[st for st, _ in self._launch_order(run)], run=list(run), n=n, ctl=ctl, grid=grid.value, lds=lds.value,
                   items=[s.n_items for s in stages], kinds=[s.kind for s in stages], codes=[s.conv.tune for s in stages],
                   tensors=[ws, cnt, stages_dev, deps_dev, flags, ctl])
         ch["step"] = (L.lfvdm_level_chain, (_p(stages_dev), n, _p(deps_dev), _p(flags), _p(ctl), grid.value, lds.value,
@@ -750,6 +824,12 @@ class Plan:
         if keep:
             self.keep += ch["tensors"]
         return ch
+
+    def _launch_order(self, run):
+        """The run in the order of the plan's step list (what ``disable_chains`` restores): hoisted stages go back to where
+        their launches stood."""
+        pos = self._step_pos          # (positions in the per-launch step list, recorded by build_chains)
+        return sorted(run, key=lambda e: pos[id(e[0])])
 
     def _time_chain(self, ch, reps, rounds):
         """Microseconds per launch of one chain on its own, back to back (minimum over `rounds`)."""
@@ -832,6 +912,7 @@ class Plan:
             return 0
         head_last = self.head["step"] == len(self.steps) - 1
         out, run = [], []
+        self._step_pos = {id(sp): i for i, sp in enumerate(self.steps)}
 
         def flush():
             ch = self._make_chain(run) if len(run) >= 2 else None

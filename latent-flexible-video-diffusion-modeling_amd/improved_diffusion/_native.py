@@ -36,21 +36,22 @@ class ConvArgs(C.Structure):
         ("splitk_ws", c_fp), ("splitk_cnt", c_fp), ("splitk_ws_floats", C.c_int64), ("splitk_cnt_ints", C.c_int64),
         ("gn_gamma", c_fp), ("gn_beta", c_fp), ("gn_film", c_fp), ("gn_out", c_fp), ("gn_film_ld", C.c_int32),
         ("gn_film_div", C.c_int32), ("gn_act", C.c_int32), ("gn_skip_raw", C.c_int32), ("gn_eps", C.c_float),
-        ("gn_general", C.c_int32),
+        ("gn_general", C.c_int32), ("gn_gw", C.c_int32), ("gn_ld", C.c_int32),
     ]
 
 
 class GnArgs(C.Structure):
     _fields_ = [("src0", c_fp), ("src1", c_fp), ("C0", C.c_int32), ("C1", C.c_int32), ("N", C.c_int32), ("P", C.c_int32),
                 ("gamma", c_fp), ("beta", c_fp), ("film", c_fp), ("film_div", C.c_int32), ("film_ld", C.c_int32),
-                ("eps", C.c_float), ("act", C.c_int32), ("out", c_fp)]
+                ("eps", C.c_float), ("act", C.c_int32), ("out", c_fp), ("cg", C.c_int32), ("ldo", C.c_int32), ("out_base", c_fp),
+                ("out_col", C.c_int32), ("pad_", C.c_int32)]
 
 
 class ChainStage(C.Structure):
     """lfvdm_chain_stage (include/lfvdm_hip.h): one stage of a persistent level chain."""
     _fields_ = [("kind", C.c_int32), ("n_items", C.c_int32), ("flag_base", C.c_int32), ("n_flags", C.c_int32),
                 ("dep_base", C.c_int32), ("dep_stride", C.c_int32), ("cfg", C.c_int32), ("kz", C.c_int32), ("nt2", C.c_int32),
-                ("pad_", C.c_int32), ("ws_off", C.c_int64), ("cnt_off", C.c_int64), ("conv", ConvArgs), ("gn", GnArgs)]
+                ("wg_off", C.c_int32), ("ws_off", C.c_int64), ("cnt_off", C.c_int64), ("conv", ConvArgs), ("gn", GnArgs)]
 
 
 CHAIN_CONV, CHAIN_GN = 0, 1
@@ -120,6 +121,7 @@ _SIGS = {
     "lfvdm_gn_coef": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp], c_i),
     "lfvdm_gn_coef_stats": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_fp, c_fp, c_fp, c_fp], c_i),
     "lfvdm_gn_apply": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_i, c_fp, c_fp, c_fp, c_fp, c_fp], c_i),
+    "lfvdm_gn_apply_part": ([c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, C.c_float, c_i, c_fp, c_i, c_fp], c_i),
     "lfvdm_gn_apply_ws_floats": ([c_i, c_i, c_i], C.c_long),
     "lfvdm_gn_apply_ws": ([c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_float, c_i, c_fp, c_fp, c_fp, c_fp, c_fp,
                            C.c_long, c_fp], c_i),
@@ -269,7 +271,8 @@ TUNE_CHAIN, TUNE_IN_CHAIN = -101, -102
 
 def tune_key(a):
     return (a.N, a.Hs, a.Ws, a.up, a.stride, a.ksize, a.Ho, a.Wo, a.C0, a.C1, a.Cout, a.s2C0, a.s2C1, bool(a.coefA), a.act,
-            bool(a.res), bool(a.resA), a.out_mode, bool(a.splitk_ws), (1 + bool(a.gn_film) + 2 * bool(a.gn_skip_raw)) if a.gn_out else 0)
+            bool(a.res), bool(a.resA), a.out_mode, bool(a.splitk_ws),
+            (1 + bool(a.gn_film) + 2 * bool(a.gn_skip_raw) + 4 * bool(a.gn_gw)) if a.gn_out else 0)
 
 
 def tune_cache():

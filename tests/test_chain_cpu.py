@@ -133,3 +133,41 @@ def test_only_the_tile_family_of_the_chain_kernel_is_accepted():
     assert L.lfvdm_chain_conv_ok(C.byref(nchw.conv)) != 0
     assert L.lfvdm_chain_gn_ok(128, 128, 40, 16) == 0 and L.lfvdm_chain_gn_ok(128, 0, 40, 1024) != 0
     assert L.lfvdm_chain_gn_ok(96, 0, 40, 16) != 0           # 96 channels: not a multiple of 64
+
+
+def test_concat_operand_written_half_by_half():
+    """The decoder's first GroupNorm over concat(h, skip) evaluated half by half: the producer GEMM writes the left 128 columns
+    of the consumer's 256-column operand from its epilogue (gn_gw / gn_ld), a free-standing GroupNorm stage the right 128
+    (out_base / out_col).  The consumer's K slices must wait for the GEMM's tiles where they read the left columns and for
+    the GroupNorm's items where they read the right ones; the free-standing stage goes to the top workgroups of the grid."""
+    N, H, Ch = 40, 2, 128
+    X, RAW, ACT, SKIP, OUT = 0x100000, 0x200000, 0x300000, 0x400000, 0x500000
+    prod = conv_stage(X, RAW, Ch, Ch, N, H, code(6, 5, 2), gn_out=ACT)
+    prod.conv.gn_gw, prod.conv.gn_ld = 8, 2 * Ch
+    part = gn_stage(SKIP, 0, Ch, 0, N, H * H, ACT + 4 * Ch)
+    part.gn.cg, part.gn.ldo, part.gn.out_base, part.gn.out_col = 8, 2 * Ch, ACT, Ch
+    cons = conv_stage(ACT, OUT, 2 * Ch, Ch, N, H, code(6, 6, 2))
+    rc, st, deps, nflags, ws, cnt, grid, lds = plan([part, prod, cons])
+    assert rc == 0
+    MT, taps, KZ = 5, 9, 6
+    assert st[0].n_items == N * 2 and st[0].wg_off == grid - st[0].n_items and st[1].wg_off == 0 and st[2].wg_off == 0
+    assert all(not item_deps(st[0], deps, i) for i in range(st[0].n_items))
+    per, total, NK = st[2].n_items // 8, MT * 4 * KZ, taps * 8
+    for item in range(st[2].n_items):
+        Lidx = (item & 7) * per + (item >> 3)
+        if Lidx >= total:
+            continue
+        pair, bx = divmod(Lidx, MT)
+        by, kz = divmod(pair, KZ)
+        want = set()
+        for ci in sorted({k // taps for k in range(NK * kz // KZ, NK * (kz + 1) // KZ)}):
+            if ci < 4:          # left half: the producer GEMM's tile (row tile bx, filter tile ci)
+                want.add(st[1].flag_base + ci * MT + bx)
+            else:               # right half: the GroupNorm items (sample n, 64-column block j) of the tile's 8 samples
+                j = (32 * (ci - 4)) // 64
+                want |= {st[0].flag_base + n * 2 + j for n in range(8 * bx, 8 * bx + 8)}
+        assert item_deps(st[2], deps, item) == sorted(want), (item, bx, by, kz)
+    # the same columns written twice are refused; disjoint halves of one buffer are not
+    again = gn_stage(SKIP, 0, Ch, 0, N, H * H, ACT + 4 * Ch)
+    again.gn.cg, again.gn.ldo, again.gn.out_base, again.gn.out_col = 8, 2 * Ch, ACT, Ch
+    assert plan([part, again])[0] == 3
