@@ -129,7 +129,9 @@ def kernel_breakdown(plan, reps=10, inner=4):
                 if f2.__name__ == "lfvdm_conv_igemm":
                     flops += conv_flops(a2[0]._obj)
                     nbytes += conv_bytes(a2[0]._obj)
-                else:
+                elif f2.__name__ == "lfvdm_gn_apply_part":       # (src, C, N, P, ...): read once, written once
+                    nbytes += 2.0 * 4.0 * a2[1] * a2[2] * a2[3]
+                else:                                            # lfvdm_gn_apply (src0, src1, C0, C1, N, P, ...)
                     nbytes += 2.0 * 4.0 * a2[4] * a2[5] * (a2[2] + a2[3])
         elif name in ("lfvdm_gn_apply", "lfvdm_gn_apply_ws"):      # (src0, src1, C0, C1, N, P, ...): read once, written once
             nbytes = 2.0 * 4.0 * args[4] * args[5] * (args[2] + args[3])

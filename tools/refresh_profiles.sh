@@ -24,12 +24,6 @@ export LFVDM_TUNE_CACHE=$ROOT/profiles/tune_cache_mi355x.json      # read-only
 export LFVDM_TUNE_CACHE_OUT=$OUT/tune_cache_mi355x.json             # committed table + anything measured in these runs
 cd /tmp && export TMPDIR=/tmp
 step() { local lim=$1; shift; timeout -k 10 $lim "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed at its limit: stopping"; exit 1; fi; return 0; }
-# (launch shapes that are not in the committed table yet are measured in an unprofiled pass first: both cache files are read)
-if want train; then
-step 300 python3 $ROOT/tools/train_profile.py 4 > $OUT/tpwarm.log 2>&1
-step 300 rocprofv3 --kernel-trace --stats -d $OUT/tp -o tp --output-format csv -- python3 $ROOT/tools/train_profile.py 30 > $OUT/tp.log 2>&1
-cp $OUT/tp/tp_kernel_stats.csv $OUT/train_kernel_stats.csv
-cp $OUT/train_kernel_stats.csv $ROOT/profiles/${ROUND}_train_kernel_stats.csv
 stamp() { python3 - "$1" <<PY
 import json, os, sys
 sys.path.insert(0, "$ROOT"); sys.path.insert(0, os.path.join("$ROOT", "latent-flexible-video-diffusion-modeling_amd"))
@@ -39,6 +33,12 @@ st["git_head"] = os.environ.get("GIT_HEAD") or None
 json.dump(st, open(sys.argv[1] + ".stamp.json", "w"))
 PY
 }
+# (launch shapes that are not in the committed table yet are measured in an unprofiled pass first: both cache files are read)
+if want train; then
+step 300 python3 $ROOT/tools/train_profile.py 4 > $OUT/tpwarm.log 2>&1
+step 300 rocprofv3 --kernel-trace --stats -d $OUT/tp -o tp --output-format csv -- python3 $ROOT/tools/train_profile.py 30 > $OUT/tp.log 2>&1
+cp $OUT/tp/tp_kernel_stats.csv $OUT/train_kernel_stats.csv
+cp $OUT/train_kernel_stats.csv $ROOT/profiles/${ROUND}_train_kernel_stats.csv
 stamp $OUT/train_kernel_stats.csv; cp $OUT/train_kernel_stats.csv.stamp.json $ROOT/profiles/${ROUND}_train_kernel_stats.csv.stamp.json
 echo "train profile done"
 fi
