@@ -72,7 +72,7 @@ fi
 if want line; then
 # 4b. the default bench line LAST among the measurements it quotes: train / pixel-train family splits and PMC traffic are
 #     read from profiles/${ROUND}_*, which must be THIS run's files (stamped with the running code)
-for f in pmc_traffic.json pmc_traffic.json.stamp.json; do cp $OUT/$f $ROOT/profiles/${ROUND}_$f; done
+for f in pmc_traffic.json pmc_traffic.json.stamp.json; do [ -f $OUT/$f ] && cp $OUT/$f $ROOT/profiles/${ROUND}_$f; done
 step 500 python3 $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 echo "bench done"
 fi
