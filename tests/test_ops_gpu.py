@@ -1383,3 +1383,46 @@ def test_conv_wgrad_oihw_output_every_tune_code(nat):
         err = float((g.cpu() - w.grad).abs().max())
         assert err < 2e-5 * scale, f"tune code {code}: OIHW dW max|d| = {err:.3e}"
         assert float((db.cpu() - b.grad).abs().max()) < 2e-5 * max(1.0, float(b.grad.abs().max())), f"tune code {code}: db"
+
+
+@pytest.mark.parametrize("N,Cin,C0,C1,H", [(40, 128, 128, 128, 2), (8, 256, 128, 128, 4), (6, 64, 64, 64, 4), (4, 128, 256, 256, 2)])
+def test_concat_groupnorm_half_by_half_every_tune_code(nat, N, Cin, C0, C1, H):
+    """The decoder's first normalisation, GroupNorm32 + SiLU over concat(h, skip) (unet.py:460 + :152-155), evaluated half by
+    half: h = conv3x3(x) normalised in the producing GEMM's epilogue with the CONCAT's group width (lfvdm_conv_args.gn_gw,
+    written into the left columns of the [M][C0 + C1] operand: gn_ld), the skip half by lfvdm_gn_apply_part.  No group
+    straddles the concat when (C0 + C1) / 32 divides both halves, so the result must equal F.group_norm of the materialised
+    concat in fp64 - for every tile code the tuner may pick, in both forms of the epilogue."""
+    import ctypes as C
+    x, w, b = rnd("cat/x", N, Cin, H, H), rnd("cat/w", C0, Cin, 3, 3, scale=0.05), rnd("cat/b", C0)
+    skip = rnd("cat/skip", N, C1, H, H)
+    Cc = C0 + C1
+    gw = Cc // 32
+    gamma, beta = 1 + 0.1 * rnd("cat/g", Cc), 0.1 * rnd("cat/be", Cc)
+    h = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = F.silu(F.group_norm(torch.cat([h, skip.double()], 1), 32, gamma.double(), beta.double(), eps=1e-5)).float()
+    M, P = N * H * H, H * H
+    act = torch.full((M, Cc), float("nan"), device="cuda")
+    raw = torch.empty(M, C0, device="cuda")
+    g_dev, b_dev = gamma.cuda(), beta.cuda()
+    sk = cl(skip)
+    nat.check(nat.lib().lfvdm_gn_apply_part(sk.data_ptr(), C1, N, P, gw, g_dev.data_ptr() + 4 * C0, b_dev.data_ptr() + 4 * C0, 1e-5,
+                                            nat.ACT_SILU, act.data_ptr() + 4 * C0, Cc, nat.stream()), "lfvdm_gn_apply_part")
+    ws = torch.empty(1 << 22, device="cuda")
+    cnt = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    keep = dict(src0=cl(x), W=packed(nat, w), bias=b.cuda())
+    a = nat.fill_conv_args(C0=Cin, N=N, Hs=H, Ws=H, Ho=H, Wo=H, Cout=C0, out=raw, ldo=C0, gn_out=act, gn_gamma=g_dev, gn_beta=b_dev,
+                           gn_film_div=1, gn_act=nat.ACT_SILU, gn_skip_raw=0, **keep)
+    a.gn_gw, a.gn_ld = gw, Cc
+    a.splitk_ws, a.splitk_cnt, a.splitk_ws_floats, a.splitk_cnt_ints = ws.data_ptr(), cnt.data_ptr(), ws.numel(), cnt.numel()
+    codes = (C.c_int * 256)()
+    n = nat.lib().lfvdm_conv_igemm_candidates(C.byref(a), codes, 256)
+    assert n > 0
+    right = act[:, C0:].clone()
+    for code, general in [(c, g) for c in [0] + [codes[i] for i in range(n)] for g in (0, 1)]:
+        a.tune, a.gn_general = code, general
+        act[:, :C0].fill_(float("nan"))
+        nat.conv_igemm_struct(a)
+        assert torch.equal(act[:, C0:], right), "the GEMM's epilogue must not touch the skip half's columns"
+        err = float((from_cl(act, N, H, H, Cc).cpu() - ref).abs().max())
+        assert err < 1e-4, f"tune code {code}, general form {general}: max|d| = {err:.3e}"
+        assert float((from_cl(raw, N, H, H, C0).cpu() - h.float()).abs().max()) < 5e-5
