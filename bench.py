@@ -512,16 +512,18 @@ def bench_train(rank, world, dev, steps, warmup, probe_only=False):
     return out
 
 
-def bench_long_video(dev, max_windows):
-    """BASELINE.json configs[3]: one 1000-frame video generated by the hierarchy-2 schedule in windows of <= 20
-    frames, 250 respaced steps per window (97 windows with 36 observed frames), batch 1, cfg-B network."""
+def bench_long_video(dev, max_windows, batch=1):
+    """BASELINE.json configs[3]: 1000-frame videos generated by the hierarchy-2 schedule in windows of <= 20 frames, 250
+    respaced steps per window (97 windows with 36 observed frames), cfg-B network.  batch = videos generated side by side
+    (1: the configuration as BASELINE.json words it; 8: the reference's default, scripts/video_sample.py:171 --batch_size=8,
+    :88-99 - eight videos share every window's index lists)."""
     from types import SimpleNamespace
     from improved_diffusion.video_sampler import sample_video, default_sampling_args
     from improved_diffusion.sampling_schemes import sampling_schemes
     model, diffusion = make_model_and_diffusion(64, dev, respacing="250")
     T = 1000
     g = th.Generator().manual_seed(77)
-    video = (th.randn(1, 1, 4, 16, 16, generator=g) + 0.1 * th.randn(1, T, 4, 16, 16, generator=g).cumsum(1)) * 0.5
+    video = (th.randn(batch, 1, 4, 16, 16, generator=g) + 0.1 * th.randn(batch, T, 4, 16, 16, generator=g).cumsum(1)) * 0.5
     args = default_sampling_args(sampling_scheme="hierarchy-2", n_obs=36, max_frames=20, max_latent_frames=10, device=str(dev))
     if max_windows < 97:      # truncated run: shorten the video so that the schedule ends early
         import contextlib, io
@@ -542,10 +544,26 @@ def bench_long_video(dev, max_windows):
     el = time.perf_counter() - t0
     steps = len(used) * diffusion.num_timesteps
     lengths = sorted({len(o[0]) + len(l[0]) for o, l in used})
-    return {"workload": f"long video: hierarchy-2, T={T}, K=20, step=10, n_obs=36, respacing 250 (BASELINE.json configs[3])",
-            "windows": len(used), "window_lengths": lengths, "denoising_steps": steps, "seconds": round(el, 2),
-            "steps_per_s_incl_setup": round(steps / el, 1), "frames_generated_per_s": round((T - 36) / el, 2),
-            "finite": bool(th.isfinite(samples).all())}
+    rec = {"workload": f"long video: hierarchy-2, T={T}, K=20, step=10, n_obs=36, respacing 250, batch {batch} (BASELINE.json "
+                       "configs[3]" + ("" if batch == 1 else "; the reference's default --batch_size") + ")",
+           "batch": batch, "windows": len(used), "window_lengths": lengths, "denoising_steps": steps, "seconds": round(el, 2),
+           "steps_per_s_incl_setup": round(steps / el, 1), "frames_generated_per_s": round(batch * (T - 36) / el, 2),
+           "frame_steps_per_s": round(batch * 20 * steps / el, 1), "finite": bool(th.isfinite(samples).all())}
+    # the implicit-GEMM body at this batch's launch shapes (M = batch x 20 x H x W rows): live event timing of the 20-frame
+    # window's plan, as for the headline workload
+    try:
+        sm = next(v for k, v in diffusion._samplers.items() if k[1][1] == 20)
+        groups = kernel_breakdown(sm.plan, reps=3, inner=2)
+        convs = {k: v for k, v in groups.items() if k.startswith("conv_igemm") or k == "level_chain_kernel"}
+        fl, ms = sum(v["flops"] for v in convs.values()), sum(v["ms"] for v in convs.values())
+        rec.update({"launches_per_step": len(sm.plan.steps), "conv_gemm_gflop_per_step": round(fl / 1e9, 2),
+                    "conv_gemm_us_per_step": round(1000 * ms, 1), "conv_gemm_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                    "conv_gemm_frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                    "level_chains": [dict(stages=c["n"], work_items=c["items"]) for c in sm.plan.chains],
+                    "time_table_fallback": sm.plan.time_table_fallback})
+    except StopIteration:
+        pass
+    return rec
 
 
 def bench_pixel(dev, steps):
@@ -939,6 +957,8 @@ def main():
         # the single-GPU legs (configs[3], configs[4]) and the CPU baselines belong to the N = 1 line only
         if args.long_video_windows > 0 and world == 1:
             out["long_video"] = bench_long_video(dev, args.long_video_windows)
+            # the reference's default batch (scripts/video_sample.py:171): eight videos per window, the same bounded leg
+            out["long_video"]["batch8"] = bench_long_video(dev, args.long_video_windows, batch=8)
         if args.pixel_steps > 0 and world == 1:
             del sampler
             diffusion._samplers.clear()

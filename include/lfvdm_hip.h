@@ -610,6 +610,15 @@ int lfvdm_compose_rows(const float* x, const float* x0, const float* obs, float*
  * ------------------------------------------------------------------------------------- */
 #define LFVDM_CHAIN_CONV 0
 #define LFVDM_CHAIN_GN 1
+/* Round 6 - SAMPLE-LOCAL stage (csrc/conv_local_body.h): the same lfvdm_conv_args, decomposed for maps of <= 16 pixels
+ * (Ho * Wo a power of two) where a 3x3 convolution only mixes the pixels of ONE sample and GroupNorm32 is per sample and
+ * group (unet.py:194-207, nn.py:17-19): work item = (16 * cfg output rows = whole samples, 16 filters = whole groups, ALL
+ * of K) - no split-K over workgroups, no slab / ticket seam, no cross-wave normalisation.  The item's filter slice
+ * [16][K] depends on nothing the chain computes and is fetched into LDS before the item waits (for a workgroup's next item:
+ * while it finishes the current one); only the item's activation rows are read behind the flag hop.  K order differs
+ * from the tile kernels: results agree to rounding, not bitwise.  cfg = row tiles per item (1 | 2); conv.tune is ignored.
+ * Needs Cout % 16 == 0, (C0 + C1) % 64 == 0, (s2C0 + s2C1) % 64 == 0, front + filter slice <= 159.5 KB of LDS. */
+#define LFVDM_CHAIN_LOCAL 2
 #define LFVDM_CHAIN_MAX_DEPS 64
 #define LFVDM_CHAIN_CTL_EPOCH 0    /* int index: generation of the last completed launch */
 #define LFVDM_CHAIN_CTL_EXIT 32    /* workgroups that have left the current launch */
@@ -635,18 +644,28 @@ typedef struct lfvdm_gn_args {       /* lfvdm_gn_apply's arguments (one-wave for
 } lfvdm_gn_args;
 
 typedef struct lfvdm_chain_stage {
-    int32_t kind;            /* LFVDM_CHAIN_CONV | LFVDM_CHAIN_GN */
+    int32_t kind;            /* LFVDM_CHAIN_CONV | LFVDM_CHAIN_GN | LFVDM_CHAIN_LOCAL (caller also sets cfg = row tiles) */
     /* filled by lfvdm_chain_plan: */
     int32_t n_items;         /* work items (conv: the XCD-aware flat grid of the stand-alone launch, padding included) */
     int32_t flag_base;       /* flags[flag_base + output unit] (conv: output tile; gn: work item) */
     int32_t n_flags;
-    int32_t dep_base;        /* deps[dep_base + item * dep_stride] = count, followed by `count` flag indices */
+    int32_t dep_base;        /* deps[dep_base + item * dep_stride] = count, followed by `count` flag indices;  local: SIX counts -
+                              * one list per wave (the producers of the channel quarter that wave stages and multiplies) and one
+                              * per row tile (the producers of its residual rows) - followed by the six lists */
     int32_t dep_stride;
-    int32_t cfg;             /* conv: kernel-body instance */
-    int32_t kz;              /* conv: K slices over workgroups */
-    int32_t nt2;             /* conv: filter tiles */
-    int32_t wg_off;          /* work item i runs on workgroup (i + wg_off) mod grid: stages that depend on nothing inside the
-                              * chain (the skip half of a concat GroupNorm) are put on the workgroups the GEMM stages leave idle */
+    int32_t cfg;             /* conv: kernel-body instance;  local: row tiles of 16 rows per item (1 | 2), set by the caller */
+    int32_t kz;              /* conv: K slices over workgroups;  local: floats of LDS in front of the filter slice */
+    int32_t nt2;             /* conv: filter tiles;  local: filter slices (Cout / 16) */
+    int32_t wg_off;          /* work item i runs on workgroup wg_lo + (i + wg_off) mod wg_count: stages that depend on nothing inside
+                              * the chain (the skip half of a concat GroupNorm) are put on the workgroups the GEMM stages leave
+                              * idle; consecutive sample-local stages are rotated over their workgroups */
+    int32_t side;            /* set by the CALLER: 1 = off the chain's critical path (the skip side of a decoder concat: its operands
+                              * come from earlier launches, its consumer sits deep in the chain).  If a chain has such stages,
+                              * lfvdm_chain_plan reserves the top 5/16 of the grid for them: a workgroup walks its items in stage
+                              * order and waits where an item's producers are not done - side work must not sit in front of a
+                              * main-path item on the same workgroup */
+    int32_t wg_lo;           /* planner: the stage's workgroups are [wg_lo, wg_lo + wg_count) */
+    int32_t wg_count;
     int64_t ws_off;          /* conv: this stage's slab region (floats) and ticket region (ints) in the chain's workspace */
     int64_t cnt_off;
     lfvdm_conv_args conv;
@@ -654,12 +673,20 @@ typedef struct lfvdm_chain_stage {
 } lfvdm_chain_stage;
 
 /* Host-side planning (no GPU work).  deps: caller's array of deps_cap ints.  -> LFVDM_E_UNSUPPORTED if a stage cannot run
- * in a chain (tile configuration, layout, more than LFVDM_CHAIN_MAX_DEPS producers for an item, a buffer written twice). */
+ * in a chain (tile configuration, layout, more than LFVDM_CHAIN_MAX_DEPS producers for an item, a buffer written twice).
+ * *grid on ENTRY: the most workgroups the device can keep resident for this chain (lfvdm_chain_capacity; <= 0: the 256 of
+ * a whole MI355X) - the planned grid never exceeds it (work items stride over the grid, so any grid is legal). */
 int lfvdm_chain_plan(lfvdm_chain_stage* stages, int n_stages, int32_t* deps, int64_t deps_cap, int64_t* deps_used,
                      int32_t* n_flags, int64_t* ws_floats, int64_t* cnt_ints, int32_t* grid, int32_t* lds_bytes);
 /* LFVDM_OK if this launch could be a chain stage with this tune code (tile / chunk / split-K family the chain kernel holds) */
 int lfvdm_chain_conv_ok(const lfvdm_conv_args* a);
 int lfvdm_chain_gn_ok(int C0, int C1, int N, int P);
+/* LFVDM_OK if this launch could be a LFVDM_CHAIN_LOCAL stage with `row_tiles` (1 | 2) tiles of 16 rows per item */
+int lfvdm_chain_local_ok(const lfvdm_conv_args* a, int row_tiles);
+/* Workgroups of the chain kernel the CURRENT device can hold at once with lds_bytes of dynamic LDS (CU count x occupancy):
+ * the bound of a chain's grid - its waits only end if every workgroup is running.  < 0: the query failed.
+ * lfvdm_level_chain refuses (LFVDM_E_UNSUPPORTED) a grid above it. */
+int lfvdm_chain_capacity(int lds_bytes);
 int lfvdm_level_chain(const lfvdm_chain_stage* stages_dev, int n_stages, const int32_t* deps_dev, int32_t* flags, int32_t* ctl,
                       int grid, int lds_bytes, double timeout_s, void* stream);
 

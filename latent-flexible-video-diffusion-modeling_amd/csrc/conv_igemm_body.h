@@ -86,6 +86,9 @@ struct ChainCtx {
     int stage;                // stage index (diagnostic stamps only)
 };
 
+#ifndef LFVDM_POLL_SLEEP
+#define LFVDM_POLL_SLEEP 1      // s_sleep units (64 cycles) between two polls of a wave (A/B builds: -DLFVDM_POLL_SLEEP=n)
+#endif
 // Poll (lanes < ndeps of the calling wave, one line each) until every dependency carries this launch's generation.
 // -> false: gave up (own timeout, or the abort word was raised elsewhere).  Bounded: the loop always ends.
 __device__ __forceinline__ bool chain_poll(const ChainCtx& c, int lane) {
@@ -95,7 +98,7 @@ __device__ __forceinline__ bool chain_poll(const ChainCtx& c, int lane) {
     for (;;) {
         const int v = lane < c.ndeps ? __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : c.gen;
         if (__builtin_amdgcn_ballot_w64(v != c.gen) == 0) return true;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(LFVDM_POLL_SLEEP);
         if ((++spins & 31) == 0) {
             if (__hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
             if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > c.timeout_ticks) {

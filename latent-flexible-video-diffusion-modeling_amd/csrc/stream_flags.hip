@@ -34,6 +34,12 @@ __global__ void flag_wait_kernel(const int* flag, int target, long long timeout_
                 break;
             }
         }
+        // The int word is STICKY (cleared only by the host's reset): while it is up, EVERY wait raises the riding word again -
+        // the gradient arena's copy is cleared by zero_grad each step, and a rank whose own optimizer launch keeps skipping
+        // on the sticky word must make its peers skip with it (a one-off timeout would otherwise leave the replicas one
+        // update apart until the host has examined the word, one step late).
+        if (timed_out_f32 && __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            atomicExch(timed_out_f32, 0x3f800000);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }

@@ -48,6 +48,13 @@ def level_chain_enabled():
     return os.environ.get("LFVDM_LEVEL_CHAIN", "1") != "0"
 
 
+def chain_local_enabled():
+    """LFVDM_CHAIN_LOCAL=0: the chains keep the split-K tile body of round 5 for every stage (A/B aid).  Default: stages on
+    maps of <= 16 pixels run SAMPLE-LOCAL (csrc/conv_local_body.h: whole samples x 16 filters x all of K per work item, filter
+    slice resident in LDS before the item's flags arrive, no split-K seam, GroupNorm inside one wave)."""
+    return os.environ.get("LFVDM_CHAIN_LOCAL", "1") != "0"
+
+
 CHAIN_MAX_M = int(os.environ.get("LFVDM_CHAIN_MAX_M", "640"))
 CHAIN_TIMEOUT_S = float(os.environ.get("LFVDM_CHAIN_TIMEOUT_S", "2.0"))
 
@@ -144,10 +151,13 @@ class Plan:
             self.add(L.lfvdm_gn_apply, *args)
         return out
 
-    def packed(self, weight):
+    def packed(self, weight, c0=0, c1=None):
+        """Packed [Cout][tap][Cin] copy of an OIHW conv weight, or of its input channels [c0, c1) (one half of a conv over a
+        channel concat run as two convolutions)."""
         Cout, Cin, k, _ = weight.shape
-        out = self.buf(Cout, k * k, Cin)
-        self.packs.append((weight, out))
+        c1 = Cin if c1 is None else c1
+        out = self.buf(Cout, k * k, c1 - c0)
+        self.packs.append((weight, out) if (c0, c1) == (0, Cin) else (weight, out, c0, c1))
         return out
 
     def add(self, fn, *args):
@@ -469,6 +479,24 @@ class Plan:
         if (not level_chain_enabled() or M > CHAIN_MAX_M or gn.weight.shape[0] != Ccat or Ccat % 32 or C0 % gw or C1 % gw
                 or gw not in (2, 4, 8, 16) or C1 % 64 or P > 256 or skip["H"] * skip["W"] != P):
             return False
+        if self._cat_split_ok(rb, C0, C1, N, kw["Ho"], kw["Wo"]):
+            # SAMPLE-LOCAL chains: the consumer's first convolution over the concat (K = 9 (C0 + C1): its filter slice does not
+            # fit the LDS next to the activations) runs as TWO convolutions - the skip half, which depends on nothing the
+            # decoder computes, ahead of time into a partial tensor; the decoder half with that partial as its residual.  The
+            # two halves of the normalised concat are then two dense operands.
+            actL, actR = self.buf(M, C0), self.buf(M, C1)
+            a = self.conv_args(gn=gn, gn_out=actL, gn_act=nat.ACT_SILU, gn_skip_raw=0, gn_gw=gw, gn_ld=C0, **kw)
+            nt, nw = C.c_int(), C.c_int()
+            if GN_EPILOGUE and L.lfvdm_conv_igemm_config(C.byref(a), C.byref(nt), C.byref(nw)) == 0:
+                self.part_bases = getattr(self, "part_bases", {})
+                self.part_bases[_p(actR)] = (_p(actR), 0)
+                self.add(L.lfvdm_gn_apply_part, _p(sb), C1, N, P, gw, _p(gn.weight) + 4 * C0, _p(gn.bias) + 4 * C0, gn.eps,
+                         nat.ACT_SILU, _p(actR), C1)
+                self.skip_side = getattr(self, "skip_side", [])
+                self.skip_side.append((self.steps[-1], _p(sb)))         # (step, the tensor it waits for)
+                self.add_conv_args(a)
+                self._cat_done = (actL, actR)
+                return True
         act = self.buf(M, Ccat)
         a = self.conv_args(gn=gn, gn_out=act, gn_act=nat.ACT_SILU, gn_skip_raw=0, gn_gw=gw, gn_ld=Ccat, **kw)
         nt, nw = C.c_int(), C.c_int()
@@ -482,6 +510,22 @@ class Plan:
         self.add_conv_args(a)
         self._cat_done = act
         return True
+
+    def _cat_split_ok(self, rb, C0, C1, N, H, W):
+        """Should the first convolution of decoder ResBlock ``rb`` over concat(h [C0], skip [C1]) run as two convolutions?
+        Only where the sample-local chain stage takes the halves but not the whole (LDS)."""
+        if not (chain_local_enabled() and level_chain_enabled()) or os.environ.get("LFVDM_CAT_SPLIT", "1") == "0":
+            return False
+        L = nat.lib()
+
+        def ok(Cin):
+            a = nat.ConvArgs()
+            a.src0, a.W, a.out = 0x1000, 0x1000, 0x1000
+            a.C0, a.N, a.Hs, a.Ws, a.Ho, a.Wo, a.stride, a.ksize, a.Cout, a.ldo, a.ldr = Cin, N, H, W, H, W, 1, 3, rb.out_channels, rb.out_channels, rb.out_channels
+            a.out_mode = nat.OUT_ROWS
+            return any(L.lfvdm_chain_local_ok(C.byref(a), rt) == 0 for rt in (1, 2))
+
+        return N * H * W <= CHAIN_MAX_M and not ok(C0 + C1) and ok(C0) and ok(C1)
 
     def _res(self, rb, cur, next_gn=None):
         L = nat.lib()
@@ -505,8 +549,19 @@ class Plan:
         act1 = cur.get("act1")          # already evaluated by the producer's epilogue?
         if act1 is None:
             act1 = self.gn_apply(a, b, C0, C1, N, P, gn1, None, nat.ACT_SILU, "act1")
-        c1 = dict(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight), bias=conv1.bias,
-                  Cout=Cout, out=h1, ldo=Cout)
+        if isinstance(act1, tuple):
+            # the two halves of the normalised concat as dense operands (_final_conv_cat, split form): the skip half first,
+            # into a partial tensor that the decoder half takes as its residual
+            actL, actR = act1
+            part = self.buf(N * P, Cout)
+            self.add_conv(src0=actR, C0=C1, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight, C0, C0 + C1), Cout=Cout,
+                          out=part, ldo=Cout)
+            self.skip_side.append((self.steps[-1], _p(actR)))
+            c1 = dict(src0=actL, C0=C0, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight, 0, C0), bias=conv1.bias,
+                      Cout=Cout, out=h1, ldo=Cout, res=part, ldr=Cout)
+        else:
+            c1 = dict(src0=act1, C0=Cin, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=self.packed(conv1.weight), bias=conv1.bias,
+                      Cout=Cout, out=h1, ldo=Cout)
         # low-resolution levels: GroupNorm-2 + FiLM + SiLU in the epilogue of conv1 (whole samples per tile);
         # the raw h1 is not needed by anything else and is not written
         act2 = self.scratch("act2", N * P, Cout)
@@ -728,7 +783,8 @@ class Plan:
                 continue
             a = args[0]._obj
             key = nat.tune_key(a)
-            if level_chain_enabled() and a.N * a.Ho * a.Wo <= CHAIN_MAX_M and a.out_mode == nat.OUT_ROWS:
+            if (level_chain_enabled() and a.N * a.Ho * a.Wo <= CHAIN_MAX_M and a.out_mode == nat.OUT_ROWS
+                    and self._local_tiles(a) == 0):
                 # candidate stage of a persistent level chain: the fastest code among the variants the chain kernel holds
                 # (own cache entry: the unrestricted choice of the same shape stays what the other callers get)
                 ckey = key + (nat.TUNE_CHAIN,)
@@ -744,11 +800,37 @@ class Plan:
             tuned += 1
         self.tuned = True
         nat.tune_cache_save()
-        if self.build_chains() and os.environ.get("LFVDM_CHAIN_TUNE", "1") != "0":
+        n_chains = self.build_chains()
+        # low-resolution launches that did not end up in a chain (a run of one, a refused plan) were given the fastest code
+        # among the variants the CHAIN kernel holds: they run per launch, so they get the unrestricted choice back
+        for fn, args in self.steps:
+            if fn is L.lfvdm_conv_igemm:
+                a = args[0]._obj
+                key = nat.tune_key(a)
+                if cache.get(key + (nat.TUNE_CHAIN,)) and a.tune == cache[key + (nat.TUNE_CHAIN,)]:
+                    if key not in cache:
+                        cache[key] = nat.autotune_launch(a, rounds, reps)
+                    a.tune = cache[key]
+        nat.tune_cache_save()
+        if n_chains and os.environ.get("LFVDM_CHAIN_TUNE", "1") != "0":
             self.tune_chains()
         return tuned
 
     # ------------------------------------------------------------------ persistent level chains
+    def _local_tiles(self, a):
+        """Row tiles per work item (1 | 2) if this launch runs as a SAMPLE-LOCAL chain stage, else 0.  One tile of 16 rows
+        per item while the stage then fits one round of 256 workgroups, else two."""
+        L = nat.lib()
+        if not (chain_local_enabled() and level_chain_enabled()) or a.N * a.Ho * a.Wo > CHAIN_MAX_M or a.out_mode != nat.OUT_ROWS:
+            return 0
+        forced = int(os.environ.get("LFVDM_CHAIN_LOCAL_RT", "0")) or int(nat.tune_cache().get(nat.tune_key(a) + (nat.TUNE_LOCAL_RT,), 0))
+        M, NS = a.N * a.Ho * a.Wo, a.Cout // 16
+        order = (1, 2) if -(-M // 16) * NS <= 256 else (2, 1)
+        for rt in ((forced,) if forced else order):
+            if L.lfvdm_chain_local_ok(C.byref(a), rt) == 0:
+                return rt
+        return 0
+
     def _chain_stage(self, step):
         """-> ChainStage for a step that can run inside a persistent level chain, else None."""
         L = nat.lib()
@@ -756,6 +838,11 @@ class Plan:
         st = nat.ChainStage()
         if fn is L.lfvdm_conv_igemm:
             a = args[0]._obj
+            rt = self._local_tiles(a)
+            if rt:
+                st.kind, st.cfg = nat.CHAIN_LOCAL, rt
+                C.memmove(C.byref(st.conv), C.byref(a), C.sizeof(nat.ConvArgs))
+                return st
             if a.N * a.Ho * a.Wo > CHAIN_MAX_M or L.lfvdm_chain_conv_ok(C.byref(a)) != 0:
                 return None
             st.kind = nat.CHAIN_CONV
@@ -790,12 +877,28 @@ class Plan:
         n = len(run)
         # stages that read nothing the chain produces (the skip half of a concat GroupNorm) first: the planner puts them on
         # idle workgroups, and a workgroup walks the stages in list order - at the front they run at once
+        def outs_of(st):
+            return ({st.conv.out, st.conv.gn_out} if st.kind != nat.CHAIN_GN else {st.gn.out_base or st.gn.out}) - {None}
+
+        def srcs_of(st):
+            if st.kind == nat.CHAIN_GN:
+                return {st.gn.src0, st.gn.src1} - {None}
+            cv = st.conv
+            return {cv.src0, cv.src1, cv.s2src0, cv.s2src1, cv.res} - {None}
+
+        # free-standing stages: GroupNorms of tensors from earlier launches (the skip half of a concat normalisation) and
+        # sample-local convolutions that read nothing else (the skip half of a split concat convolution)
         produced = set()
         for _, st in run:
-            produced |= ({st.conv.out, st.conv.gn_out} if st.kind == nat.CHAIN_CONV else {st.gn.out_base or st.gn.out})
-        produced.discard(None)
-        free = [(sp, st) for sp, st in run if st.kind == nat.CHAIN_GN and st.gn.src0 not in produced and st.gn.src1 not in produced]
-        run = free + [(sp, st) for sp, st in run if not any(st is f for _, f in free)]
+            produced |= outs_of(st)
+        free_gn = [st for _, st in run if st.kind == nat.CHAIN_GN and not (srcs_of(st) & produced)]
+        gn_outs = set()
+        for st in free_gn:
+            gn_outs |= outs_of(st)
+        free_ids = {id(st) for st in free_gn}
+        free_ids |= {id(st) for _, st in run if st.kind == nat.CHAIN_LOCAL and srcs_of(st) and srcs_of(st) <= gn_outs}
+        free_ids |= {id(st) for _, st in run if st.side}
+        run = [e for e in run if id(e[1]) in free_ids] + [e for e in run if id(e[1]) not in free_ids]
         stages = (nat.ChainStage * n)(*[st for _, st in run])
         cap = 1 << 20
         deps = (C.c_int32 * cap)()
@@ -805,10 +908,23 @@ class Plan:
                                 C.byref(grid), C.byref(lds))
         if rc != 0:
             return None
+        # the chain's waits only end if ALL its workgroups are resident: ask the device how many it holds with this much
+        # LDS (a partitioned / CU-masked / smaller part than the 256 CUs of a whole MI355X) and plan again under that cap
+        if self.dev.type == "cuda":
+            room = int(L.lfvdm_chain_capacity(lds.value))
+            if room < max(8, min(64, grid.value)):
+                _table_budget.log(f"persistent level chain refused: the device holds {room} of its workgroups at once")
+                return None
+            if grid.value > room:
+                grid = C.c_int32(room // 8 * 8)
+                rc = L.lfvdm_chain_plan(stages, n, deps, cap, C.byref(used), C.byref(n_flags), C.byref(ws_f), C.byref(cnt_i),
+                                        C.byref(grid), C.byref(lds))
+                if rc != 0 or grid.value > room:
+                    return None
         ws = th.empty(max(1, ws_f.value), device=self.dev)
         cnt = th.zeros(max(1, cnt_i.value), dtype=th.int32, device=self.dev)
         for i in range(n):
-            if stages[i].kind == nat.CHAIN_CONV:
+            if stages[i].kind != nat.CHAIN_GN:
                 cv = stages[i].conv
                 cv.splitk_ws, cv.splitk_cnt = _p(ws) + 4 * stages[i].ws_off, _p(cnt) + 4 * stages[i].cnt_off
                 cv.splitk_ws_floats, cv.splitk_cnt_ints = ws.numel() - stages[i].ws_off, cnt.numel() - stages[i].cnt_off
@@ -818,6 +934,7 @@ class Plan:
         ctl = th.zeros(nat.CHAIN_CTL_INTS, dtype=th.int32, device=self.dev)
         ch = dict(steps=[st for st, _ in self._launch_order(run)], run=list(run), n=n, ctl=ctl, grid=grid.value, lds=lds.value,
                   items=[s.n_items for s in stages], kinds=[s.kind for s in stages], codes=[s.conv.tune for s in stages],
+                  room=(room if self.dev.type == "cuda" else None),
                   tensors=[ws, cnt, stages_dev, deps_dev, flags, ctl])
         ch["step"] = (L.lfvdm_level_chain, (_p(stages_dev), n, _p(deps_dev), _p(flags), _p(ctl), grid.value, lds.value,
                                             CHAIN_TIMEOUT_S))
@@ -866,16 +983,48 @@ class Plan:
             ch = self.chains[ci]
             run, cur, cur_t = ch["run"], ch, None
             for si, (step, st) in enumerate(run):
+                if st.kind == nat.CHAIN_LOCAL:
+                    # row tiles per item (1 | 2) of a sample-local stage, measured in the chain: one tile = more items (a second
+                    # round where they outnumber the workgroups), two = half the filter fetches per output row
+                    a = step[1][0]._obj
+                    key = nat.tune_key(a) + (nat.TUNE_LOCAL_RT,)
+                    if os.environ.get("LFVDM_CHAIN_LOCAL_RT"):
+                        continue
+                    if key in cache:                   # (measured on an earlier stage of the same shape, or in another plan)
+                        if cache[key] != st.cfg and L.lfvdm_chain_local_ok(C.byref(st.conv), cache[key]) == 0:
+                            old_rt, st.cfg = st.cfg, cache[key]
+                            nxt = self._make_chain(run, keep=False)
+                            if nxt is not None:
+                                cur, cur_t = nxt, None
+                            else:
+                                st.cfg = old_rt
+                        continue
+                    other = 3 - st.cfg
+                    best_rt = st.cfg
+                    if L.lfvdm_chain_local_ok(C.byref(st.conv), other) == 0:
+                        if cur_t is None:
+                            cur_t = self._time_chain(cur, reps, rounds)
+                        st.cfg = other
+                        cand = self._make_chain(run, keep=False)
+                        t = self._time_chain(cand, reps, rounds) if cand is not None else float("inf")
+                        if t < cur_t * 0.995:
+                            cur, cur_t, best_rt = cand, t, other
+                        st.cfg = best_rt
+                    cache[key] = best_rt
+                    continue
                 if st.kind != nat.CHAIN_CONV:
                     continue
                 a = step[1][0]._obj
                 key = nat.tune_key(a) + (nat.TUNE_IN_CHAIN,)
                 if key in cache:
                     if cache[key] != st.conv.tune:
+                        old_code = st.conv.tune
                         st.conv.tune = a.tune = cache[key]
                         nxt = self._make_chain(run, keep=False)
                         if nxt is not None:
                             cur, cur_t = nxt, None
+                        else:       # the cached code does not plan in THIS chain: the stage keeps the code it runs with
+                            st.conv.tune = a.tune = old_code
                     continue
                 if cur_t is None:
                     cur_t = self._time_chain(cur, reps, rounds)
@@ -911,26 +1060,46 @@ class Plan:
         if not level_chain_enabled() or self.chains or getattr(self, "chains_off", False):
             return 0
         head_last = self.head["step"] == len(self.steps) - 1
-        out, run = [], []
         self._step_pos = {id(sp): i for i, sp in enumerate(self.steps)}
-
-        def flush():
-            ch = self._make_chain(run) if len(run) >= 2 else None
-            if ch is None:
-                out.extend(st for st, _ in run)
-            else:
-                self.chains.append(ch)
-                out.append(ch["step"])
-            run.clear()
-
-        for step in self.steps:
+        # runs of consecutive chainable steps
+        runs, lone = [], []           # runs: [(first position, [(step, stage)...])]; lone: (position, step)
+        run = []
+        for i, step in enumerate(self.steps):
             st = self._chain_stage(step)
             if st is not None:
                 run.append((step, st))
             else:
-                flush()
-                out.append(step)
-        flush()
+                if run:
+                    runs.append((self._step_pos[id(run[0][0])], run))
+                    run = []
+                lone.append((i, step))
+        if run:
+            runs.append((self._step_pos[id(run[0][0])], run))
+        # The SKIP SIDE of the decoder's split concat convolutions (GroupNorm of the encoder's skip tensor, then the skip half
+        # of the convolution: _final_conv_cat / _res) depends on nothing the decoder computes: SIDE stages of their chain
+        # (lfvdm_chain_stage.side: the planner reserves part of the grid for them), listed first and in the order in which the
+        # main path needs them, they run beside it from the first microsecond - their operands come from earlier launches.
+        # Measured alternatives: on shared workgroups at the front of the chain they kept the main path's first workgroups
+        # busy for ~20 us; moved into the encoder-side chain (tail, shared workgroups) they started when that chain's main
+        # path had ended (+34 us), and on a reserved quarter of that chain's grid they took 100 us for its 64.
+        if os.environ.get("LFVDM_SKIP_SIDE", "1") != "0":
+            for step, _ in getattr(self, "skip_side", []):
+                for _, r in runs:
+                    for sp, st in r:
+                        if sp is step and any(not x.side and x is not st for _, x in r):
+                            st.side = 1
+        out = []
+        for pos, step in sorted([(p, ("run", r)) for p, r in runs if r] + [(p, ("step", sp)) for p, sp in lone], key=lambda e: e[0]):
+            if step[0] == "step":
+                out.append(step[1])
+                continue
+            r = step[1]
+            ch = self._make_chain(r) if len(r) >= 2 else None
+            if ch is None:
+                out.extend(sp for sp, _ in r)
+            else:
+                self.chains.append(ch)
+                out.append(ch["step"])
         self.steps = out
         if head_last:
             self.head["step"] = len(self.steps) - 1
@@ -951,15 +1120,42 @@ class Plan:
         if head_last:
             self.head["step"] = len(self.steps) - 1
 
+    def split_chains(self):
+        """Every stage of every chain as a chain of its own (one launch per stage, the SAME kernel bodies and work items: no
+        flag is waited for, the launch boundary orders the stages).  Bitwise the chained plan - the guard that a hand-off
+        inside a chain never delivers a stale byte; also what a plan falls back to where it must not depend on co-residency
+        but wants the same numerics."""
+        if not self.chains:
+            return 0
+        head_last = self.head["step"] == len(self.steps) - 1
+        by_step = {id(ch["step"]): ch for ch in self.chains}
+        out, n = [], 0
+        for step in self.steps:
+            ch = by_step.get(id(step))
+            if ch is None:
+                out.append(step)
+                continue
+            for sp, st in self._launch_order(ch["run"]):
+                one = self._make_chain([(sp, st)])
+                assert one is not None
+                out.append(one["step"])
+                n += 1
+        self.steps, self.chains, self.chains_off = out, [], True
+        if head_last:
+            self.head["step"] = len(self.steps) - 1
+        return n
+
     def chains_aborted(self):
-        """Did a wait inside a persistent level chain time out?  (synchronises)"""
-        return any(int(ch["ctl"][nat.CHAIN_CTL_ABORT].item()) != 0 for ch in self.chains)
+        """Did a wait inside a persistent level chain time out?  (synchronises: ONE read-back for all chains)"""
+        if not self.chains:
+            return False
+        return bool(th.stack([ch["ctl"][nat.CHAIN_CTL_ABORT] for ch in self.chains]).ne(0).any().item())
 
     # ------------------------------------------------------------------ run
     def weight_signature(self):
         # parameter versions catch torch-side in-place updates (optimizers, load_state_dict); the engine
         # epoch is bumped explicitly by code that rewrites parameters through raw pointers (fused AdamW)
-        return (self.engine.epoch,) + tuple(w._version for w, _ in self.packs)
+        return (self.engine.epoch,) + tuple(e[0]._version for e in self.packs)
 
     def time_signature(self):
         """Signature of what the timestep tables were computed from: the conv-weight signature plus the versions of the
@@ -970,7 +1166,9 @@ class Plan:
         """(Re)pack the OIHW conv weights into the [Cout][tap][Cin] layout the kernels read."""
         s = nat.stream()
         L = nat.lib()
-        for w, out in self.packs:
+        for w, out, *part in self.packs:
+            if part:        # input channels [c0, c1): a contiguous OIHW copy first (released in stream order)
+                w = w.detach()[:, part[0]:part[1]].contiguous()
             nat.check(L.lfvdm_pack_conv_weight(_p(w), _p(out), w.shape[0], w.shape[1], w.shape[2], s), "pack")
         self._sig = self.weight_signature()
 

@@ -152,10 +152,9 @@ class GradExchange:
             # its peers against the same collectives.  MIN over the ranks: overlap only if every rank's probe passed.
             ok = bool(self.overlap_probe["ok"])
             if dist.is_initialized() and dist.get_world_size() > 1:
-                t = th.tensor([1 if ok else 0], device=arena.g.device, dtype=th.int32)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                self.overlap_probe["ok_on_every_rank"] = bool(t.item())
-                ok = ok and bool(t.item())
+                everyone = self.agree(ok, arena.g.device)
+                self.overlap_probe["ok_on_every_rank"] = everyone
+                ok = ok and everyone
             if ok:
                 self.flags = nat.StreamFlags(self.n_early, arena.g.device)
             else:               # a stream shares main's hardware queue (or a wait gave up) on some rank: exchange behind the graph's end
@@ -164,6 +163,14 @@ class GradExchange:
         self._timing = []              # (start, end) event pairs of the exposed waits, read lazily
         self.exposed_ms = []
         self.stats = {"exchanges": 0, "buckets_behind_event": 0, "buckets_behind_graph_end": 0}
+
+    @staticmethod
+    def agree(ok, device):
+        """True iff ``ok`` holds on EVERY rank (MIN all-reduce): decisions that change what a rank enqueues against the shared
+        sequence of collectives must be the same everywhere."""
+        t = th.tensor([1 if ok else 0], device=device, dtype=th.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     # ------------------------------------------------------------------ overlap: probe and failure handling
     def _probe_overlap(self):
@@ -203,7 +210,7 @@ class GradExchange:
         non-zero on EVERY rank before the optimizer launch reads it (lfvdm_adamw_args.skip_flag2), ``zero_grad`` clears it
         with the gradients.  No collective of its own (round 4 spent a separate MAX all-reduce per step on this)."""
         gf = getattr(self.arena, "g_full", None)
-        return gf[self.arena.numel:self.arena.numel + 1] if gf is not None and self.on_gpu else None
+        return gf[self.arena.numel:self.arena.numel + 1] if gf is not None else None
 
     def skip_word_ptr(self):
         w = self.skip_word()
@@ -211,12 +218,15 @@ class GradExchange:
 
     def poll_timeout(self, sync=False):
         """Once per optimizer step, after the optimizer launch: raises if a bucket's wait on the backward graph timed out
-        on ANY rank in the PREVIOUS step (sync=True: in any step so far).  The decision is collective: ``launch`` ends
-        with a MAX all-reduce of the timed-out word behind the bucket collectives, so the word the optimizer launch reads
-        (``skip_flag``) is the same on every rank - either every replica applies the step or none does - and the word of
-        step s is examined by every rank at exactly step s + 1 (fixed lag: its event is normally long complete when the
-        host gets here, the host runs at most one step ahead of the GPU anyway), so all ranks raise in the same step and
-        nobody is left alone in a collective.  Parameters, moments and EMA are then those of the last good step."""
+        on ANY rank in the PREVIOUS step (sync=True: in any step so far).  The decision is collective without a collective
+        of its own: a wait that gives up raises this rank's STICKY int word (``skip_flag`` of its optimizer launch) and the
+        float word behind the last gradient bucket, which rides in that bucket's SUM all-reduce and is ``skip_flag2`` of
+        EVERY rank's optimizer launch; while the sticky word is up every later wait of that rank raises the riding word
+        again (``zero_grad`` clears it each step), so the replicas skip TOGETHER until the word has been examined - by every
+        rank at exactly step s + 1 for the word of step s (fixed lag: its event is normally long complete when the host gets
+        here, the host runs at most one step ahead of the GPU anyway) - and ``reset_timeout`` has cleared it.  All ranks
+        raise in the same step, nobody is left alone in a collective; parameters, moments and EMA are those of the last good
+        step."""
         if self.flags is None:
             return
         if sync:
@@ -289,9 +299,10 @@ class GradExchange:
         self.stats["exchanges"] += 1
         g = self.arena.g
         if not self.on_gpu:
-            for lo, hi in self.ranges:
-                if hi > lo:
-                    dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM)
+            for k, (lo, hi) in enumerate(self.ranges):
+                if hi > lo:     # (the last bucket carries the skip word here too: the same sequence of collectives as on the GPU)
+                    last = k == len(self.ranges) - 1 and self.skip_word() is not None
+                    dist.all_reduce(self.arena.g_full[lo:self.arena.numel + 4] if last else g[lo:hi], op=dist.ReduceOp.SUM)
             return
         if self.comm is None:
             self.comm = th.cuda.Stream(priority=_comm_priority())

@@ -51,10 +51,10 @@ class ChainStage(C.Structure):
     """lfvdm_chain_stage (include/lfvdm_hip.h): one stage of a persistent level chain."""
     _fields_ = [("kind", C.c_int32), ("n_items", C.c_int32), ("flag_base", C.c_int32), ("n_flags", C.c_int32),
                 ("dep_base", C.c_int32), ("dep_stride", C.c_int32), ("cfg", C.c_int32), ("kz", C.c_int32), ("nt2", C.c_int32),
-                ("wg_off", C.c_int32), ("ws_off", C.c_int64), ("cnt_off", C.c_int64), ("conv", ConvArgs), ("gn", GnArgs)]
+                ("wg_off", C.c_int32), ("side", C.c_int32), ("wg_lo", C.c_int32), ("wg_count", C.c_int32), ("ws_off", C.c_int64), ("cnt_off", C.c_int64), ("conv", ConvArgs), ("gn", GnArgs)]
 
 
-CHAIN_CONV, CHAIN_GN = 0, 1
+CHAIN_CONV, CHAIN_GN, CHAIN_LOCAL = 0, 1, 2
 CHAIN_CTL_EPOCH, CHAIN_CTL_EXIT, CHAIN_CTL_ABORT, CHAIN_CTL_INTS = 0, 32, 64, 96
 
 
@@ -178,6 +178,8 @@ _SIGS = {
                           C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)], c_i),
     "lfvdm_chain_conv_ok": ([C.POINTER(ConvArgs)], c_i),
     "lfvdm_chain_gn_ok": ([c_i, c_i, c_i, c_i], c_i),
+    "lfvdm_chain_local_ok": ([C.POINTER(ConvArgs), c_i], c_i),
+    "lfvdm_chain_capacity": ([c_i], c_i),
     "lfvdm_level_chain": ([c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, C.c_double, c_fp], c_i),
     "lfvdm_flag_add": ([c_fp, c_fp], c_i),
     "lfvdm_flag_wait": ([c_fp, c_i, C.c_double, c_fp, c_fp], c_i),
@@ -266,7 +268,7 @@ _tune_saved = 0
 
 # markers appended to a launch-shape key (integers: the table is stored as JSON lists of ints): the fastest code among the
 # variants the persistent level chain holds, measured per launch / measured inside its chain
-TUNE_CHAIN, TUNE_IN_CHAIN = -101, -102
+TUNE_CHAIN, TUNE_IN_CHAIN, TUNE_LOCAL_RT = -101, -102, -103      # (-103: row tiles per item of a sample-local chain stage)
 
 
 def tune_key(a):
@@ -433,6 +435,12 @@ def _wgrad_codes(a):
     return codes
 
 
+def _capturing():
+    """Is the current stream being captured?  (False on a host without a device: the rank-agreement logic also runs in the
+    CPU tests of the exchange)"""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _tuned_wgrad_code(a, out_floats):
     """Cached launch code of this weight-gradient shape; measured on first sight (outside stream capture) on SCRATCH
     outputs - the real launch accumulates.  The weight-gradient kernels are a quarter of a training step and how their
@@ -459,7 +467,7 @@ def _tuned_wgrad_code(a, out_floats):
         # one rank tuning while its peers sit in a bucket all-reduce): rank 0 decides, the others read its choice from
         # the rendezvous store (once per shape and process; no collective that could mismatch).  Bounded: if rank 0 does
         # not publish within LFVDM_WGRAD_AGREE_S seconds the cached / heuristic code is used and said on stderr
-        if torch.cuda.is_current_stream_capturing():
+        if _capturing():
             return cache.get(key, 0)
         import datetime
         try:
@@ -474,7 +482,7 @@ def _tuned_wgrad_code(a, out_floats):
         return code
     code = cache.get(key)
     if code is None:
-        if torch.cuda.is_current_stream_capturing() or os.environ.get("LFVDM_AUTOTUNE", "1") == "0" or deterministic():
+        if _capturing() or os.environ.get("LFVDM_AUTOTUNE", "1") == "0" or deterministic():
             code = 0                    # the heuristic (nothing may be measured inside a capture): kept for the process and
                                         # published below, so that every rank runs it and nobody waits
         else:

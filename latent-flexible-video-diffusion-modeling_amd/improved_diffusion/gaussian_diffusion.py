@@ -311,8 +311,18 @@ class GaussianDiffusion:
                     out = sampler.run(self.num_timesteps - 1, self.num_timesteps)
                 yield out
                 return
-            for i in indices:
+            for n, i in enumerate(indices):
                 out = sampler.step(i)
+                # a persistent level chain that gave up a wait leaves garbage behind and its abort word is sticky: every
+                # later step of this chain would abort as well.  The states already yielded cannot be taken back, so this
+                # path RAISES (checked every 64 steps and behind the last one; p_sample_loop's final-only path reruns the
+                # chain instead) - after switching the plan to one launch per stage, so that the caller's retry works
+                if (n & 63) == 63 or i == 0:
+                    if sampler.chain_timed_out():
+                        sampler.fall_back()
+                        raise RuntimeError("a persistent level chain timed out during this sampling chain (lfvdm_level_chain): "
+                                           "the states yielded since the last check are not valid; the plan now runs one "
+                                           "launch per stage - run the chain again")
                 if not _reuse_buffers:
                     out = {k: (v.clone() if isinstance(v, th.Tensor) else v) for k, v in out.items()}
                 yield out
@@ -499,6 +509,7 @@ class GraphSampler:
             self.K = min(self.K, self.plan.time_ring // 2)     # a graph launch must not walk more than half the R ring
         self.graph_k = None
         self.expected_t = None
+        self._abort_unchecked = False       # steps have run since the chains' abort words were last read
 
     @property
     def table_build_ms(self):
@@ -546,8 +557,10 @@ class GraphSampler:
     def begin(self, img, model_kwargs):
         pl = self.plan
         B, T = pl.B, pl.T
-        if self.chain_timed_out():
-            self.fall_back()        # (callers that drive step() / run() themselves: checked once per chain, here)
+        # callers that drive step() / run() themselves: checked once per chain, here - unless whoever ran the previous
+        # chain has looked already (p_sample_loop does, behind run(): one host synchronisation per chain, not two)
+        if self._abort_unchecked and self.chain_timed_out():
+            self.fall_back()
         if pl._sig != pl.weight_signature():
             pl.refresh_weights()  # parameters changed since the last chain
         with th.no_grad():
@@ -595,7 +608,9 @@ class GraphSampler:
         self.expected_t = self.diffusion.num_timesteps - 1
 
     def chain_timed_out(self):
-        """Did a wait inside one of the plan's persistent level chains give up (LFVDM_CHAIN_TIMEOUT_S)?  Synchronises."""
+        """Did a wait inside one of the plan's persistent level chains give up (LFVDM_CHAIN_TIMEOUT_S)?  Synchronises (one
+        read-back for all chains of the plan)."""
+        self._abort_unchecked = False
         return bool(self.plan.chains) and self.plan.chains_aborted()
 
     def fall_back(self):
@@ -630,6 +645,7 @@ class GraphSampler:
             self.t_buf.fill_(i + 1)
         self.plan.ensure_R(i)
         self.graph.replay()
+        self._abort_unchecked = True
         self.expected_t = max(i - 1, 0)
         return {"sample": self.plan.x_in, "pred_xstart": self.pred, "attn": None}
 
@@ -658,6 +674,7 @@ class GraphSampler:
             self.plan.ensure_R(t)
             self.graph.replay()
             t = max(t - 1, 0)
+        self._abort_unchecked = True
         self.expected_t = max(int(i) - int(n), 0)
         return {"sample": self.plan.x_in, "pred_xstart": self.pred, "attn": None}
 

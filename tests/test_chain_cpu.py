@@ -171,3 +171,94 @@ def test_concat_operand_written_half_by_half():
     again = gn_stage(SKIP, 0, Ch, 0, N, H * H, ACT + 4 * Ch)
     again.gn.cg, again.gn.ldo, again.gn.out_base, again.gn.out_col = 8, 2 * Ch, ACT, Ch
     assert plan([part, again])[0] == 3
+
+
+def local_item_deps(st, deps, item):
+    """The lists of a LOCAL item: [n0, n1, n2, n3, r0, r1 | operand producers per wave | residual producers per row tile] ->
+    the four per-wave lists, the residual producers merged into the list of the wave that finishes their row tile."""
+    row = deps[st.dep_base + item * st.dep_stride: st.dep_base + (item + 1) * st.dep_stride]
+    lists, off = [], 6
+    for w in range(6):
+        lists.append(list(row[off:off + row[w]]))
+        off += row[w]
+    return [sorted(lists[w] + (lists[4 + w] if w < 2 else [])) for w in range(4)]
+
+
+def local_stage(src, out, Cin, Cout, N, Hs, Ho, rt, gn_out=0, skip_raw=0, res=0, stride=1, up=0, s2=(0, 0, 0, 0), ksize=3):
+    st = conv_stage(src, out, Cin, Cout, N, Hs, 0, gn_out=gn_out, skip_raw=skip_raw, res=res, ksize=ksize)
+    st.kind, st.cfg = nat.CHAIN_LOCAL, rt
+    a = st.conv
+    a.Ho, a.Wo, a.stride, a.up = Ho, Ho, stride, up
+    if s2[0]:
+        a.s2src0, a.s2C0, a.s2src1, a.s2C1, a.W2, a.bias2 = s2[0], s2[1], s2[2] or None, s2[3], 0x50, 0x60
+    return st
+
+
+def test_sample_local_stages_items_flags_dependencies_and_rotation():
+    """LFVDM_CHAIN_LOCAL (csrc/conv_local_body.h): item = (row group of 16 * rt rows = whole samples, slice of 16 filters),
+    id = row group * slices + slice, flag = base + slice * row groups + row group.  An item reads ALL channels of its samples'
+    source pixels (a stride-2 stage: the 4x larger source maps), the rows of its own tile of the 1x1 skip segment and its
+    residual tile; consecutive LOCAL stages are rotated over the whole grid; the LDS request is front region + filter slice."""
+    N, Ch = 40, 128
+    X, A1, R1, A2, OUT, A3 = 0x100000, 0x200000, 0x300000, 0x400000, 0x500000, 0x600000
+    s0 = local_stage(X, R1, Ch, Ch, N, 4, 2, 1, gn_out=A1, stride=2)                        # 4x4 -> 2x2: raw R1 + normalised A1
+    s1 = local_stage(A1, 0x700000, Ch, Ch, N, 2, 2, 1, gn_out=A2, skip_raw=1)              # conv1 of a ResBlock
+    s2 = local_stage(A2, OUT, Ch, Ch, N, 2, 2, 1, res=R1, gn_out=A3)                         # conv2 + residual
+    s3 = local_stage(A3, 0x800000, Ch, Ch, N, 2, 4, 2, up=1, s2=(0, 0, 0, 0))                # nearest-2x + conv: 4x4, two row tiles
+    rc, st, deps, nflags, ws, cnt, grid, lds = plan([s0, s1, s2, s3])
+    assert rc == 0 and ws == 0 and cnt == 0
+    NS = Ch // 16
+    assert [s.n_items for s in st] == [10 * NS, 10 * NS, 10 * NS, 20 * NS] and [s.nt2 for s in st] == [NS] * 4
+    assert grid == 256 and [s.wg_off for s in st] == [0, 80, 160, 240]
+    front = lambda rows_in, rows, C2=0: 2048 + (rows_in + 1) * Ch + rows * C2          # noqa: E731
+    assert [s.kz for s in st] == [front(64, 16), front(16, 16), front(16, 16), front(8, 32)]
+    assert lds == 4 * (front(64, 16) + 16 * 5 * 256)          # filter rows in whole 1 KiB pieces: 9 * 128 floats -> 5 pieces
+    assert all(local_item_deps(st[0], deps, i) == [[], [], [], []] for i in range(st[0].n_items))
+    # one list per WAVE: wave w stages and multiplies channels [32 w, 32 w + 32) = filter slices 2 w, 2 w + 1 of the producer
+    # (same 4 samples: row group rg); wave 0, which finishes the item's row tile, also waits for its residual tile
+    for k, prod, resprod in ((1, st[0], None), (2, st[1], st[0])):
+        MT = 10
+        for item in range(st[k].n_items):
+            rg, sl = divmod(item, NS)
+            want = [sorted({prod.flag_base + c * MT + rg for c in (2 * w, 2 * w + 1)} |
+                           ({resprod.flag_base + sl * MT + rg} if resprod is not None and w == 0 else set())) for w in range(4)]
+            assert local_item_deps(st[k], deps, item) == want, (k, item)
+    # the upsampling stage: 32 output rows = 2 samples = 8 source rows: half a producer row group (16 rows = 4 samples)
+    for item in range(st[3].n_items):
+        rg, sl = divmod(item, NS)
+        assert local_item_deps(st[3], deps, item) == [sorted(st[2].flag_base + c * 10 + rg // 2 for c in (2 * w, 2 * w + 1))
+                                                      for w in range(4)]
+    # a grid cap (what lfvdm_chain_capacity reports on a smaller device) bounds the plan; rotation follows it
+    L = nat.lib()
+    arr = (nat.ChainStage * 4)(s0, s1, s2, s3)
+    d2 = (C.c_int32 * (1 << 16))()
+    used, wsv, cntv, nfl, g, ldsv = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32(96), C.c_int32()
+    assert L.lfvdm_chain_plan(arr, 4, d2, 1 << 16, C.byref(used), C.byref(nfl), C.byref(wsv), C.byref(cntv), C.byref(g), C.byref(ldsv)) == 0
+    assert g.value == 96 and [s.wg_off for s in arr] == [0, 80, 64, 48]
+
+
+def test_sample_local_stage_acceptance():
+    L = nat.lib()
+    ok = local_stage(0x1000, 0x2000, 128, 128, 40, 2, 2, 1)
+    assert L.lfvdm_chain_local_ok(C.byref(ok.conv), 1) == 0 and L.lfvdm_chain_local_ok(C.byref(ok.conv), 2) == 0
+    assert L.lfvdm_chain_local_ok(C.byref(ok.conv), 3) != 0
+    wide = local_stage(0x1000, 0x2000, 256, 128, 40, 2, 2, 1)             # 16 x 2304 filters + 17 rows of 256: over the LDS
+    assert L.lfvdm_chain_local_ok(C.byref(wide.conv), 1) != 0
+    big = local_stage(0x1000, 0x2000, 128, 128, 40, 8, 8, 1)              # 64-pixel maps: a sample does not fit a row tile
+    assert L.lfvdm_chain_local_ok(C.byref(big.conv), 1) != 0
+    odd = local_stage(0x1000, 0x2000, 96, 128, 40, 2, 2, 1)               # 96 channels: rows of the swizzled image are 64-float multiples
+    assert L.lfvdm_chain_local_ok(C.byref(odd.conv), 1) != 0
+    bad = local_stage(0x1000, 0x2000, 128, 128, 40, 4, 4, 1, stride=2)    # inconsistent geometry
+    assert L.lfvdm_chain_local_ok(C.byref(bad.conv), 1) != 0
+    mixed = plan([local_stage(0x1000, 0x2000, 128, 128, 40, 2, 2, 1, gn_out=0x3000),
+                  conv_stage(0x3000, 0x4000, 128, 128, 40, 2, code(6, 5, 2)),
+                  local_stage(0x4000, 0x5000, 128, 128, 40, 2, 2, 1)])
+    assert mixed[0] == 0 and [s.kind for s in mixed[1]] == [nat.CHAIN_LOCAL, nat.CHAIN_CONV, nat.CHAIN_LOCAL]
+    # the tile stage waits for the LOCAL producer's (row group, slice) flags that cover its rows and channel chunks ...
+    st, deps = mixed[1], mixed[2]
+    some = [item_deps(st[1], deps, i) for i in range(st[1].n_items)]
+    assert any(d for d in some) and all(st[0].flag_base <= f < st[0].flag_base + st[0].n_flags for d in some for f in d)
+    # ... and the LOCAL consumer for the tile stage's 32 x 32 tiles: wave w for column tile w, the row tile of its 4 samples
+    for item in range(st[2].n_items):
+        rg = item // 8
+        assert local_item_deps(st[2], deps, item) == [[st[1].flag_base + w * 5 + rg // 2] for w in range(4)]

@@ -89,22 +89,25 @@ def main():
                     d["poll"].append((g(17) - g(16)) / 100.0)
                 if g(2) and g(17):
                     d["loop"].append((g(2) - g(17)) / 100.0)
-                if g(15) and g(17):
-                    d["fa"].append((g(15) - g(17)) / 100.0)
+                if (g(15) or g(1)) and g(17):       # tile body: first activation piece landed; sample-local body: rows staged
+                    d["fa"].append(((g(15) or g(1)) - g(17)) / 100.0)
                 if g(3) and g(2):
                     d["red"].append((g(3) - g(2)) / 100.0)
                 if g(6) and g(3):
                     d["seam"].append((g(6) - g(3)) / 100.0)
                 if g(7) and (g(6) or g(3)):
                     d["epi"].append((g(7) - (g(6) or g(3))) / 100.0)
-                if g(8) and g(7) and g(12):
+                if g(8) and g(7) and (g(12) or ch["kinds"][sg] == 2):
                     d["gn"].append((g(8) - g(7)) / 100.0)
                 if g(18) and (g(8) or g(17)):
                     d["pub"].append((g(18) - (g(8) or g(17))) / 100.0)
             a17 = med([us(at(sg, w, 17)) for w in wgs if at(sg, w, 17)])
             a18 = [us(at(sg, w, 18)) for w in wgs if at(sg, w, 18)]
             a18m, a18x = med(a18), (max(a18) if a18 else float("nan"))
-            kind = "conv" if ch["kinds"][sg] == 0 else "gn"
+            kind = {0: "conv", 1: "gn", 2: "loc"}[ch["kinds"][sg]]
+            stg = med([(at(sg, w, 4) - at(sg, w, 17)) / 100.0 for w in wgs if at(sg, w, 4) and at(sg, w, 17)])
+            dma = med([(at(sg, w, 1) - at(sg, w, 4)) / 100.0 for w in wgs if at(sg, w, 4) and at(sg, w, 1)])
+            kind = kind + (f" stage {stg:4.2f} dma-wait {dma:4.2f}" if ch["kinds"][sg] == 2 else "")
             print(f"  {sg:3d}  {kind:4s} {ch['items'][sg]:5d} | {beg:6.2f} {end:6.2f} {end - beg:5.2f} | "
                   f"{med(d['pro']):4.2f} {med(d['poll']):5.2f} {med(d['loop']):5.2f} {med(d['red']):5.2f} {med(d['seam']):5.2f} "
                   f"{med(d['epi']):5.2f} {med(d['gn']):5.2f} {med(d['pub']):5.2f} | {med(d['fa']):5.2f} | polled {a17:6.2f} published {a18m:6.2f} / {a18x:6.2f}")
