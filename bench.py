@@ -415,7 +415,21 @@ def exchange_machinery_probe(dev, steps=12):
     try:
         # (8 untimed steps: the first replays next to a freshly created communicator run 0.2-0.3 ms slow - round 5 measured
         # 7.64 ms over steps 5-16 and 7.38 over steps 6-25 of the same job, tools/exchange_probe.py)
-        return bench_train(0, 1, dev, steps, 8, probe_only=True)
+        probe = bench_train(0, 1, dev, steps, 8, probe_only=True)
+        # The same step with ONE bucket behind the graph's end and no device-side waits: what is left is the collective
+        # itself - at world size 1 RCCL's "all-reduce" is a device copy of the 122 MB arena - i.e. the share of the figure
+        # above that is RCCL's, not the machinery's (markers, folds, counters, polling kernels, five launches)
+        saved = {k: os.environ.get(k) for k in ("LFVDM_GRAD_BUCKETS", "LFVDM_OVERLAP_EXCHANGE")}
+        os.environ.update(LFVDM_GRAD_BUCKETS="1", LFVDM_OVERLAP_EXCHANGE="0")
+        try:
+            probe["one_bucket_behind_the_graph_ms_per_step"] = bench_train(0, 1, dev, steps, 8, probe_only=True)["ms_per_step"]
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        return probe
     finally:
         os.environ.pop("LFVDM_FORCE_EXCHANGE", None)
 
@@ -937,7 +951,14 @@ def main():
         # one GPU can report what the exchange machinery costs with today's code (before any byte crosses xGMI)
         probe = exchange_machinery_probe(dev, args.machinery_steps)
         train["exchange"]["machinery_ms_per_step"] = round(probe["ms_per_step"] - train["ms_per_step"], 3)
+        one = probe.get("one_bucket_behind_the_graph_ms_per_step")
+        if one is not None:
+            # of which the collective itself (one 122 MB "all-reduce" over one rank = a device copy by RCCL) ...
+            train["exchange"]["rccl_world1_copy_ms_per_step"] = round(one - train["ms_per_step"], 3)
+            # ... and the exchange's own machinery on top of it (5 buckets, 4 of them behind counters inside the backward)
+            train["exchange"]["machinery_minus_rccl_copy_ms_per_step"] = round(probe["ms_per_step"] - one, 3)
         train["exchange"]["machinery"] = {"forced_exchange_ms_per_step": probe["ms_per_step"],
+                                          "one_bucket_behind_the_graph_ms_per_step": one,
                                           "plain_ms_per_step": train["ms_per_step"], **{k: probe[k] for k in (
                                               "buckets", "buckets_started_inside_the_backward", "buckets_started_after_the_backward",
                                               "overlap_with_backward", "exposed_ms_per_step", "backend", "steps")}}
@@ -952,7 +973,8 @@ def main():
         out["exposed_allreduce_ms_per_step"] = train["exchange"]["exposed_ms_per_step"]
         out["exchange"] = {k: train["exchange"].get(k) for k in ("bucket_bytes", "exposed_ms_per_step",
                                                                     "buckets_started_inside_the_backward", "overlap_probe",
-                                                                    "machinery_ms_per_step")}
+                                                                    "machinery_ms_per_step", "rccl_world1_copy_ms_per_step",
+                                                                    "machinery_minus_rccl_copy_ms_per_step")}
     if rank == 0:
         # the single-GPU legs (configs[3], configs[4]) and the CPU baselines belong to the N = 1 line only
         if args.long_video_windows > 0 and world == 1:

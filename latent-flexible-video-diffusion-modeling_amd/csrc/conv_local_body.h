@@ -417,6 +417,9 @@ __device__ __forceinline__ bool conv_local_body(const lfvdm_conv_args& p, int fr
             auto unit_sum = [&](float& a, float& b) {
                 a = rows_sum(a);
                 if (two) b = rows_sum(b);
+                // channel quads of a wider group: the other DPP rows (ds_bpermute; v_permlane16_swap / v_permlane32_swap with both
+                // operands the same value did NOT give the xor-16 / xor-32 all-reduce here - four op-level cases failed - and
+                // the step is worth ~1 us per denoising step: left as a shuffle)
                 if (gw >= 8) a += __shfl_xor(a, 16, 64);
                 if (gw >= 16) a += __shfl_xor(a, 32, 64);
             };

@@ -1094,7 +1094,11 @@ class Plan:
                 out.append(step[1])
                 continue
             r = step[1]
-            ch = self._make_chain(r) if len(r) >= 2 else None
+            # (LFVDM_CHAIN_SINGLE=1: a lone sample-local launch - the 1x1 projections between the attention kernels of the middle
+            # block - as a one-stage "chain".  Measured and left off: 7.7 us per launch against 5.6 for the tile kernel on
+            # those 160-row, K = 128 GEMMs - with nothing to wait for, the filter fetch in front of the K loop is exposed)
+            single = len(r) == 1 and r[0][1].kind == nat.CHAIN_LOCAL and os.environ.get("LFVDM_CHAIN_SINGLE", "0") == "1"
+            ch = self._make_chain(r) if len(r) >= 2 or single else None
             if ch is None:
                 out.extend(sp for sp, _ in r)
             else:

@@ -262,3 +262,39 @@ def test_sample_local_stage_acceptance():
     for item in range(st[2].n_items):
         rg = item // 8
         assert local_item_deps(st[2], deps, item) == [[st[1].flag_base + w * 5 + rg // 2] for w in range(4)]
+
+
+def test_cfgB_plan_becomes_two_sample_local_chains_with_a_skip_side():
+    """Host side of round 6 on the headline configuration (BASELINE.json configs[1]; the launch plan is built on CPU tensors,
+    nothing is launched): the 4x4 / 2x2 levels become two chains; every convolution stage is sample-local; the decoder's
+    four convolutions over cat([h, skip]) (unet.py:460, :152-155) are split, their skip side - GroupNorm of the skip tensor,
+    then the skip half of the convolution - are the chain's first stages, marked `side`, on the reserved top 80 workgroups;
+    taken apart again the plan has its 102 launches back (94 + the 8 of the four splits) in a legal order."""
+    import torch as th
+    sys.path.insert(0, ROOT)
+    import bench
+    from improved_diffusion import _engine as eng
+    model, _ = bench.make_model_and_diffusion(64, th.device("cpu"))
+    pl = eng.Plan(eng.Engine(model), 2, 20, 16, 16, False, time_steps=1000)
+    L = nat.lib()
+    n_launches = len(pl.steps)
+    for fn, args in pl.steps:                      # (stand-in for the autotuner: a chain-legal tile code for the tile stages)
+        if fn is L.lfvdm_conv_igemm and args[0]._obj.N * args[0]._obj.Ho * args[0]._obj.Wo <= 640:
+            args[0]._obj.tune = code(6, 4, 2)
+    assert pl.build_chains() == 2 and len(pl.steps) == n_launches - 28 + 2
+    enc, dec = pl.chains
+    assert enc["kinds"] == [nat.CHAIN_LOCAL] * 8 and enc["grid"] == 256
+    assert dec["n"] == 20 and dec["kinds"][:8] == [nat.CHAIN_GN, nat.CHAIN_LOCAL] * 4 and set(dec["kinds"][8:]) == {nat.CHAIN_LOCAL}
+    side = [st.side for _, st in dec["run"]]
+    assert side == [1] * 8 + [0] * 12 and not any(st.side for _, st in enc["run"])
+    # the skip halves are plain convolutions into a partial tensor that the decoder halves take as their residual
+    outs = {st.conv.out for _, st in dec["run"][:8] if st.kind == nat.CHAIN_LOCAL}
+    users = [st for _, st in dec["run"][8:] if st.conv.res in outs]
+    assert len(outs) == 4 and len(users) == 4 and all(st.conv.gn_out and st.conv.gn_film for st in users)
+    assert all(not (st.conv.bias or st.conv.gn_out or st.conv.res) for _, st in dec["run"][:8] if st.kind == nat.CHAIN_LOCAL)
+    assert sum(1 for e in pl.packs if len(e) == 4) == 8              # two packed halves per split convolution
+    pl.disable_chains()
+    assert len(pl.steps) == n_launches and not pl.chains
+    order = [id(s) for s in pl.steps]
+    for step, waits_for in pl.skip_side:                             # producer before consumer in the per-launch order
+        assert id(step) in order

@@ -70,7 +70,7 @@ def test_level_chain_is_bitwise_the_per_launch_plan(local, monkeypatch):
         assert torch.equal(outs[0][2], outs[2][2])
         dev = float((outs[0][0] - outs[2][0]).abs().max())
         print(f"[chain] sample-local chains vs per-launch tile plan after 40 steps: max |d| = {dev:.3g}")
-        assert dev <= 2e-4 * 40
+        assert dev <= 1e-4          # (observed 2.4e-7; a wrong GroupNorm half in one decoder stage gave ~1e-3 here)
 
 
 def test_level_chain_eager_launches_repeat_bitwise():
