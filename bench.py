@@ -96,7 +96,7 @@ def kernel_breakdown(plan, reps=10, inner=4):
     L = nat.lib()
     s = nat.stream()
     n = len(plan.steps)
-    tot = [0.0] * n
+    obs = [[] for _ in range(n)]
     ev = [(th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)) for _ in range(n)]
     for rep in range(reps + 2):
         for i, (fn, args) in enumerate(plan.steps):
@@ -107,7 +107,10 @@ def kernel_breakdown(plan, reps=10, inner=4):
         th.cuda.synchronize()
         if rep >= 2:
             for i in range(n):
-                tot[i] += ev[i][0].elapsed_time(ev[i][1]) / inner
+                obs[i].append(ev[i][0].elapsed_time(ev[i][1]) / inner)
+    # median over the repetitions (x reps, so that the sums below read as before): one stalled repetition - a 40 ms hiccup of
+    # one launch behind a 97-window video was seen once - must not become that kernel's "duration"
+    tot = [sorted(o)[len(o) // 2] * reps for o in obs]
     groups = {}
     for i, (fn, args) in enumerate(plan.steps):
         name = fn.__name__
