@@ -19,18 +19,25 @@ __device__ __forceinline__ f32x4 ld_cat_sc1(const float* s0, const float* s1, in
 
 // CG = channels per group: 2, 4, 8, 16.  One wave: sample n, channels [16 cb, 16 cb + 16).  CHAIN: sources read and the
 // output written with sc1 (write-through) accesses - see ChainCtx in conv_igemm_body.h.
-template <int CG, bool CHAIN>
+// NW = 4 (round 6, maps of >= 128 positions): the FOUR waves of a workgroup share the unit, wave `wsub` takes a quarter of
+// the positions (4 float4 per lane instead of 16: a quarter of the 64 SiLU evaluations and 16 stores a lone wave issues one
+// instruction at a time) and the two group sums are completed through 256 B of LDS - two barriers, partials added in wave
+// order (deterministic).
+template <int CG, bool CHAIN, int NW = 1>
 __device__ __forceinline__ void gn_wave_body(
     int n, int cb, int lane, const float* __restrict__ s0, const float* __restrict__ s1, int C0, int C1, int P,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
     int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats,
-    float* __restrict__ act_out, int act_mode, int ldo = 0) {
-    constexpr int KEEP = 16;
+    float* __restrict__ act_out, int act_mode, int ldo = 0, int wsub = 0) {
+    constexpr int KEEP = 16 / NW;
     const int C = C0 + C1;
     if (ldo == 0) ldo = C;              // row stride of act_out (a part of a wider tensor: lfvdm_gn_apply_part)
     const int q = lane & 3, pl = lane >> 2;
     const int c = cb * 16 + q * 4;
-    const size_t pos0 = (size_t)n * P;
+    const int Pw = NW > 1 ? P / NW : P;                 // positions of this wave (NW > 1: P is a multiple of 16 * NW)
+    const size_t pos0 = (size_t)n * P + (size_t)wsub * Pw;
+    P = Pw;                                             // (below: this wave's share; the divisor is taken from Pall)
+    const int Pall = Pw * NW;
     // coefficient operands first: their latency hides behind the statistics
     const f32x4 gam = ld4(gamma + c), bet = ld4(beta + c);
     f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fsh = fsc;
@@ -60,11 +67,24 @@ __device__ __forceinline__ void gn_wave_body(
         if constexpr (CG == 2) return (f32x4){v.x, v.x, v.z, v.z};
         else return (f32x4){v.x, v.x, v.x, v.x};
     };
-    const float inv = 1.0f / (float)(CG * P);
+    const float inv = 1.0f / (float)(CG * Pall);
+    // NW > 1: the waves' partial group sums -> LDS -> every lane adds the NW partials of its channel quad in wave order
+    auto unit_sum = [&](f32x4 v, int pass) -> f32x4 {
+        v = group_sum(v);
+        if constexpr (NW > 1) {
+            __shared__ f32x4 s_xch[2][NW][4];         // (only in the NW > 1 instances: the chain kernel's LDS budget is tight)
+            if (pl == 0) s_xch[pass][wsub][q] = v;
+            __syncthreads();
+            v = s_xch[pass][0][q];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += s_xch[pass][w][q];
+        }
+        return v;
+    };
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) sum += keep[i];
-    const f32x4 mean = group_sum(sum) * inv;
+    const f32x4 mean = unit_sum(sum, 0) * inv;
     f32x4 sq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
@@ -73,7 +93,7 @@ __device__ __forceinline__ void gn_wave_body(
             sq += d * d;
         }
     }
-    const f32x4 var = group_sum(sq) * inv;
+    const f32x4 var = unit_sum(sq, 1) * inv;
     f32x4 rstd;
     rstd.x = 1.0f / sqrtf(var.x + eps); rstd.y = 1.0f / sqrtf(var.y + eps);
     rstd.z = 1.0f / sqrtf(var.z + eps); rstd.w = 1.0f / sqrtf(var.w + eps);
@@ -84,7 +104,7 @@ __device__ __forceinline__ void gn_wave_body(
         A = A * sc;
         B = B * sc + fsh;
     }
-    if (pl == 0) {
+    if (pl == 0 && wsub == 0) {
         if (coefA) {
             st4(coefA + (size_t)n * C + c, A);
             st4(coefB + (size_t)n * C + c, B);

@@ -167,6 +167,17 @@ __global__ __launch_bounds__(64) void gn_wave_kernel(
                             coefB, stats, act_out, act_mode, ldo);
 }
 
+// the same unit shared by the four waves of a workgroup (gn_wave_body, NW = 4): maps of >= 128 positions
+template <int CG>
+__global__ __launch_bounds__(256) void gn_wave4_kernel(
+    const float* __restrict__ s0, const float* __restrict__ s1, int C0, int C1, int P,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film, int film_div,
+    int film_ld, float eps, float* __restrict__ coefA, float* __restrict__ coefB, float* __restrict__ stats,
+    float* __restrict__ act_out, int act_mode, int ldo) {
+    gn_wave_body<CG, false, 4>(blockIdx.x, blockIdx.y, threadIdx.x & 63, s0, s1, C0, C1, P, gamma, beta, film, film_div, film_ld, eps,
+                               coefA, coefB, stats, act_out, act_mode, ldo, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+
 // one wave per (sample, 16 channels) when the map and the group width allow it; false = use the workgroup kernels
 inline bool gn_wave_launch(const float* src0, const float* src1, int C0, int C1, int N, int P, const float* gamma,
                            const float* beta, const float* film, int film_div, int film_ld, float eps, float* coefA,
@@ -175,6 +186,21 @@ inline bool gn_wave_launch(const float* src0, const float* src1, int C0, int C1,
     const int C = C0 + C1, cg = C / 32;
     if (off || P > 256 || C0 % 16 || (cg != 2 && cg != 4 && cg != 8 && cg != 16) || N > 65535) return false;
     const dim3 grid(N, C / 16);
+    // four waves per unit on the larger maps (LFVDM_GN_WAVE4_MINP: smallest map that takes it, default 128; 0 = never).
+    // Measured at cfg B (12 launches per denoising step, 16x16 maps): 70-74 -> 60-63 us per step, 1157-1160 -> 1170-1175
+    // steps/s; eight waves per unit (512 threads, 2 float4 per lane): equal to four, not kept
+    static const int minp4 = getenv("LFVDM_GN_WAVE4_MINP") ? atoi(getenv("LFVDM_GN_WAVE4_MINP")) : 128;
+    if (minp4 > 0 && P >= minp4 && P % 64 == 0) {
+#define LFVDM_GNW4(G)                                                                                                   \
+    hipLaunchKernelGGL(gn_wave4_kernel<G>, grid, dim3(256), 0, s, src0, src1, C0, C1, P, gamma, beta, film, film_div, film_ld, \
+                       eps, coefA, coefB, stats, out, act, 0)
+        if (cg == 2) LFVDM_GNW4(2);
+        else if (cg == 4) LFVDM_GNW4(4);
+        else if (cg == 8) LFVDM_GNW4(8);
+        else LFVDM_GNW4(16);
+#undef LFVDM_GNW4
+        return true;
+    }
 #define LFVDM_GNW(G)                                                                                                   \
     hipLaunchKernelGGL(gn_wave_kernel<G>, grid, dim3(64), 0, s, src0, src1, C0, C1, P, gamma, beta, film, film_div, film_ld, \
                        eps, coefA, coefB, stats, out, act, 0)
