@@ -189,6 +189,10 @@ LOCAL_CASES = {
     "narrow_64_gw2": (20, 2, 2, 3, 1, 0, 64, 0, 0, 0, 64, True, (True, 0, 0, 0), 1),
     "wide_512_gw16_concat_source": (8, 2, 2, 3, 1, 0, 64, 64, 0, 0, 512, False, (False, 0, 0, 0), 1),
     "map4x1": (12, 2, 2, 1, 1, 0, 192, 0, 0, 0, 64, False, None, 1),
+    "cin192_3x3_runtime_loop": (8, 2, 2, 3, 1, 0, 192, 0, 0, 0, 64, True, (True, 0, 0, 0), 1),      # 3 units per tap and wave: no instance
+    "cin256_1x1": (12, 4, 4, 1, 1, 0, 256, 0, 0, 0, 128, True, (False, 0, 0, 0), 2),
+    "cin512_1x1_runtime_loop": (6, 2, 2, 1, 1, 0, 256, 256, 0, 0, 64, False, None, 1),
+    "cin64_3x3_rt2": (10, 4, 4, 3, 1, 0, 64, 0, 64, 0, 64, False, (True, 1, 0, 0), 2),
 }
 
 
