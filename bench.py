@@ -140,6 +140,10 @@ def kernel_breakdown(plan, reps=10, inner=4):
             nbytes = 2.0 * 4.0 * args[4] * args[5] * (args[2] + args[3])
         elif name == "lfvdm_gn_temporal":                           # (x, gamma, beta, eps, y, B, T, P, C)
             nbytes = 2.0 * 4.0 * args[5] * args[6] * args[7] * args[8]
+        elif name == "lfvdm_gn_temporal_qkv":                       # (x, gamma, beta, eps, xn, W, b, qkv, B, T, P, C)
+            rows, Cc = args[8] * args[9] * args[10], args[11]
+            flops = 2.0 * rows * 3 * Cc * Cc
+            nbytes = 4.0 * (rows * Cc * 2 + rows * 3 * Cc + 3 * Cc * Cc)       # x read, xn + qkv written, the filters once
         gsum = groups.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
         gsum["launches"] += 1
         gsum["ms"] += tot[i] / reps
@@ -256,6 +260,9 @@ def train_step_flops(model, B, T, H, W):
             N, P, C = a[4], a[5], a[6]
             conv += 2.0 * N * P * 3 * C * C
             att += 4.0 * N * P * P * C
+        elif fn is L.lfvdm_gn_temporal_qkv:        # (x, gamma, beta, eps, xn, W, b, qkv, B, T, P, C): the temporal qkv projection
+            Bv, Tv, P, C = a[8], a[9], a[10], a[11]
+            conv += 2.0 * Bv * Tv * P * 3 * C * C
     return {"forward_conv_gemm": conv, "forward_attention": att, "step": 3.0 * (conv + att)}
 
 
@@ -1011,6 +1018,8 @@ def main():
             dom = {"flops": sum(g["flops"] for g in convs.values()), "ms": sum(g["ms"] for g in convs.values()),
                    "launches": sum(g["launches"] for g in convs.values()), "bytes": sum(g["bytes"] for g in convs.values())}
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            # every GEMM FLOP of the step, also the projections that run inside other launches (lfvdm_gn_temporal_qkv)
+            gemm_flops = sum(g["flops"] for g in groups.values())
             tr = [(pmc_traffic(k), g["launches"]) for k, g in convs.items()]
             traffic = (round(sum(t * n for t, n in tr if t is not None) / max(1, sum(n for t, n in tr if t is not None)))
                        if any(t is not None for t, _ in tr) else None)
@@ -1040,8 +1049,8 @@ def main():
             out["breakdown"] = {"eager_sum_ms": round(tot_ms, 4),
                                 "launches": len(sampler.plan.steps) + two_launch + int(getattr(sampler, "extra_launches", 3)),
                                 "all_conv_gemm_tflops": round(ach, 2),
-                                "step_flops_g": round(dom["flops"] / 1e9, 2),
-                                "whole_step_frac_of_mfma_peak": round(dom["flops"] * out["value"] / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                "step_flops_g": round(gemm_flops / 1e9, 2),
+                                "whole_step_frac_of_mfma_peak": round(gemm_flops * out["value"] / world / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                 "kernels": {k: {"n": g["launches"], "us": round(1000 * g["ms"], 1)} for k, g in
                                             sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}}
         if world == 1:

@@ -330,6 +330,19 @@ int lfvdm_gn_temporal_bwd_det(const float* x, const float* dy, const float* gamm
 int lfvdm_gn_temporal(const float* x, const float* gamma, const float* beta, float eps, float* y,
                       int B, int T, int P, int C, void* stream);
 
+/* Temporal GroupNorm + the temporal attention's qkv projection in ONE launch (rpe.py:136 `x = self.norm(x)` + :139
+ * `qkv = self.qkv(x)`, temporal instance): x [(b*T + t)*P + p][C] = the block input, gamma / beta / eps = norm.weight /
+ * norm.bias / norm.eps (GroupNorm32(32, C) over C/32 channels x T frames per (b, pixel), nn.py:93-101), Wqkv [3C][C] /
+ * bqkv [3C] = qkv.weight / qkv.bias (nn.Linear), qkv [B*T*P][3C].  xn_out [B*T*P][C] (may be NULL, must not alias x)
+ * receives the normalised rows - the residual of the block's output projection (rpe.py:172).  Replaces lfvdm_gn_temporal
+ * + lfvdm_conv_igemm (1x1) in the sampler plan; same arithmetic per element as those two (fp32 MFMA, two-pass statistics),
+ * a different summation order.  _ok: LFVDM_OK for C = 64 / 128 / 256, T <= 24, P a multiple of the pixel strip (2 at
+ * C = 64) and - at 128 / 256 channels - a projection of at most 0.5 GFLOP (above that the two launches are faster), else
+ * LFVDM_E_UNSUPPORTED (keep the two launches); the launch itself accepts every covered shape. */
+int lfvdm_gn_temporal_qkv_ok(int B, int T, int P, int C);
+int lfvdm_gn_temporal_qkv(const float* x, const float* gamma, const float* beta, float eps, float* xn_out,
+                          const float* Wqkv, const float* bqkv, float* qkv, int B, int T, int P, int C, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Small-M grouped linear ("row-dot"): out[m][o] = sum_k actin(in[m][k]) * W[o][k] + b[o],
  * m < M <= 8.  One launch evaluates a whole table of jobs (time_embed.{0,2}, every

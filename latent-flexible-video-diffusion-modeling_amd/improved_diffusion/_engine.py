@@ -32,6 +32,8 @@ def _p(t):
 
 # LFVDM_SPATIAL_FUSED=0: keep the qkv projection of the spatial attention as its own GEMM launch (A/B aid)
 SPATIAL_FUSED = os.environ.get("LFVDM_SPATIAL_FUSED", "1") != "0"
+# LFVDM_TEMPORAL_QKV=0: keep the temporal GroupNorm and the temporal qkv projection as two launches (A/B aid)
+TEMPORAL_QKV = os.environ.get("LFVDM_TEMPORAL_QKV", "1") != "0"
 # LFVDM_GN_EPILOGUE=0: never evaluate a GroupNorm in the epilogue of the GEMM that produces its input (A/B aid)
 GN_EPILOGUE = os.environ.get("LFVDM_GN_EPILOGUE", "1") != "0"
 # LFVDM_NEXT_GN_EPILOGUE=0: never evaluate the NEXT ResBlock's first GroupNorm in a producer's epilogue (A/B aid)
@@ -594,9 +596,14 @@ class Plan:
         heads = ab.num_heads
         ta, sa = ab.temporal_attention, ab.spatial_attention
         # --- temporal: GN over (C/32 x T) per (b, pixel); residual on the normalised tensor (rpe.py:136,172)
-        self.add(L.lfvdm_gn_temporal, _p(x), _p(ta.norm.weight), _p(ta.norm.bias), ta.norm.eps, _p(self.s_xn), B, T, P, Cc)
-        self.add_conv(src0=self.s_xn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.qkv.weight, bias=ta.qkv.bias,
-                      Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
+        if TEMPORAL_QKV and L.lfvdm_gn_temporal_qkv_ok(B, T, P, Cc) == 0:
+            # both are local to a (b, pixel) column of T rows: one launch (statistics in registers, qkv on MFMA from an LDS image)
+            self.add(L.lfvdm_gn_temporal_qkv, _p(x), _p(ta.norm.weight), _p(ta.norm.bias), ta.norm.eps, _p(self.s_xn),
+                     _p(ta.qkv.weight), _p(ta.qkv.bias), _p(self.s_qkv), B, T, P, Cc)
+        else:
+            self.add(L.lfvdm_gn_temporal, _p(x), _p(ta.norm.weight), _p(ta.norm.bias), ta.norm.eps, _p(self.s_xn), B, T, P, Cc)
+            self.add_conv(src0=self.s_xn, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=ta.qkv.weight, bias=ta.qkv.bias,
+                          Cout=3 * Cc, out=self.s_qkv, ldo=3 * Cc)
         at = None
         if self.want_attn:
             at = self.buf(B * P, heads, T, T)

@@ -334,6 +334,60 @@ def _temporal_core_f64(qkv, Rq, Rk, Rv, mask, B, T, P, Cc, heads):
     return out.permute(0, 3, 1, 2, 4).reshape(B * T * P, Cc)
 
 
+@pytest.mark.parametrize("B,T,P,Cc", [(2, 20, 256, 64), (2, 20, 64, 128), (2, 20, 4, 128), (1, 20, 16, 128), (2, 7, 6, 64), (1, 24, 3, 256),
+                                      (3, 5, 1, 128), (1, 20, 256, 64), (8, 20, 64, 128)])
+def test_temporal_groupnorm_with_the_qkv_projection_inside(nat, B, T, P, Cc):
+    """lfvdm_gn_temporal_qkv (temporal GroupNorm + qkv Linear of the temporal attention in one launch, rpe.py:136 + :139):
+    the normalised rows == lfvdm_gn_temporal's, qkv == lfvdm_gn_temporal + the 1x1 lfvdm_conv_igemm within fp32
+    re-association, both == torch's group_norm + linear (fp64) on the (b, pixel) columns; bitwise reproducible."""
+    L = nat.lib()
+    M = B * T * P
+    assert (L.lfvdm_gn_temporal_qkv_ok(B, T, P, Cc) == 0) == (Cc == 64 or 6.0 * M * Cc * Cc <= 0.5e9)     # (big projections: two launches)
+    x = (rnd("tq/x", M, Cc) * 1.3 + 0.25).cuda()                     # rows (b, t, pixel); off-centre on purpose
+    gam, bet = (rnd("tq/g", Cc) * 0.3 + 1.0).cuda(), (rnd("tq/b", Cc) * 0.2).cuda()
+    W, bias = (rnd("tq/w", 3 * Cc, Cc) * (Cc ** -0.5)).cuda(), (rnd("tq/bias", 3 * Cc) * 0.1).cuda()
+    xn = torch.empty(M, Cc, device="cuda")
+    nat.gn_temporal(x, gam, bet, 1e-5, xn, B, T, P, Cc)
+    qkv = torch.empty(M, 3 * Cc, device="cuda")
+    nat.conv_igemm(src0=xn, C0=Cc, N=B * T, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=W, bias=bias, Cout=3 * Cc, out=qkv, ldo=3 * Cc)
+    x0 = x.clone()
+    xn1 = torch.full((M, Cc), float("nan"), device="cuda")
+    qkv1 = torch.full((M, 3 * Cc), float("nan"), device="cuda")
+    run = lambda: nat.check(L.lfvdm_gn_temporal_qkv(nat.ptr(x), nat.ptr(gam), nat.ptr(bet), 1e-5, nat.ptr(xn1), nat.ptr(W), nat.ptr(bias),
+                                                    nat.ptr(qkv1), B, T, P, Cc, nat.stream()), "lfvdm_gn_temporal_qkv")
+    run()
+    assert torch.equal(x, x0), "the input is left alone"
+    close(xn1, xn, 1e-5)
+    close(qkv1, qkv, 2e-5)
+    # torch (fp64): columns (b, pixel) as samples of a (C, T) GroupNorm
+    xc = x.view(B, T, P, Cc).permute(0, 2, 3, 1).reshape(B * P, Cc, T).double().cpu()
+    ref_n = F.group_norm(xc, 32, gam.double().cpu(), bet.double().cpu(), 1e-5)
+    ref_n = ref_n.view(B, P, Cc, T).permute(0, 3, 1, 2).reshape(M, Cc)
+    ref_q = ref_n @ W.double().cpu().t() + bias.double().cpu()
+    close(xn1, ref_n, 1e-5)
+    close(qkv1, ref_q, 2e-5)
+    a, b2 = xn1.clone(), qkv1.clone()
+    run()
+    assert torch.equal(xn1, a) and torch.equal(qkv1, b2), "bitwise reproducible"
+    # without the normalised rows (NULL) the projection is unchanged; aliasing them with the input is refused
+    qkv2 = torch.empty_like(qkv1)
+    nat.check(L.lfvdm_gn_temporal_qkv(nat.ptr(x), nat.ptr(gam), nat.ptr(bet), 1e-5, None, nat.ptr(W), nat.ptr(bias), nat.ptr(qkv2),
+                                      B, T, P, Cc, nat.stream()), "lfvdm_gn_temporal_qkv")
+    assert torch.equal(qkv2, qkv1)
+    assert L.lfvdm_gn_temporal_qkv(nat.ptr(x), nat.ptr(gam), nat.ptr(bet), 1e-5, nat.ptr(x), nat.ptr(W), nat.ptr(bias), nat.ptr(qkv2),
+                                   B, T, P, Cc, nat.stream()) != 0
+
+
+def test_temporal_groupnorm_qkv_refuses_what_it_does_not_cover(nat):
+    L = nat.lib()
+    assert L.lfvdm_gn_temporal_qkv_ok(2, 20, 5, 64) != 0        # two pixels per workgroup at 64 channels: odd pixel count
+    assert L.lfvdm_gn_temporal_qkv_ok(2, 25, 16, 128) != 0      # more than 24 frames
+    assert L.lfvdm_gn_temporal_qkv_ok(2, 20, 16, 96) != 0       # channel counts other than 64 / 128 / 256
+    assert L.lfvdm_gn_temporal_qkv_ok(2, 20, 16, 256) == 0
+    assert L.lfvdm_gn_temporal_qkv_ok(2, 20, 256, 128) != 0     # covered, but a 1 GFLOP projection is faster as its own GEMM
+    assert L.lfvdm_gn_temporal_qkv_ok(8, 20, 256, 64) == 0
+
+
 @pytest.mark.parametrize("B,T,P,Cc,heads", [(2, 20, 16, 64, 4), (2, 5, 4, 128, 4), (1, 14, 9, 64, 4), (2, 32, 3, 32, 2), (2, 4, 16, 32, 4),
                                                    (1, 20, 7, 384, 4), (1, 3, 5, 512, 4), (2, 24, 2, 64, 4), (1, 27, 3, 96, 4),
                                                    (1, 8, 37, 64, 2), (2, 1, 6, 32, 4), (2, 20, 70, 128, 4)])
