@@ -343,6 +343,17 @@ int lfvdm_gn_temporal_qkv_ok(int B, int T, int P, int C);
 int lfvdm_gn_temporal_qkv(const float* x, const float* gamma, const float* beta, float eps, float* xn_out,
                           const float* Wqkv, const float* bqkv, float* qkv, int B, int T, int P, int C, void* stream);
 
+/* 1x1 projection + bias + residual + the next GroupNorm in ONE launch, for frames of 256 positions (the 16x16 level): the
+ * temporal attention's `x + self.proj_out(out)` (rpe.py:171-172; o [N*P][C] = the attention output, W [C][C] / bias [C] =
+ * proj_out.weight / .bias, res [N*P][C] = the temporally normalised tokens) followed by the spatial attention's
+ * `self.norm` (rpe.py:136; GroupNorm32(32, C) per frame in fp32, nn.py:93-101; gamma / beta / eps).  out [N*P][C] = the
+ * NORMALISED sum (the un-normalised one is read by nothing else and is not written; out must not alias o or res).
+ * Replaces lfvdm_conv_igemm (1x1) + lfvdm_gn_apply where the GroupNorm does not fit the GEMM's epilogue (a frame is more
+ * rows than a tile).  _ok: LFVDM_OK for P = 256 and C = 64 / 128, else LFVDM_E_UNSUPPORTED. */
+int lfvdm_proj_gn_ok(int N, int P, int C);
+int lfvdm_proj_gn(const float* o, const float* W, const float* bias, const float* res, const float* gamma, const float* beta,
+                  float eps, float* out, int N, int P, int C, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Small-M grouped linear ("row-dot"): out[m][o] = sum_k actin(in[m][k]) * W[o][k] + b[o],
  * m < M <= 8.  One launch evaluates a whole table of jobs (time_embed.{0,2}, every

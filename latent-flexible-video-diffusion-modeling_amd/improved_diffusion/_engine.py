@@ -32,6 +32,8 @@ def _p(t):
 
 # LFVDM_SPATIAL_FUSED=0: keep the qkv projection of the spatial attention as its own GEMM launch (A/B aid)
 SPATIAL_FUSED = os.environ.get("LFVDM_SPATIAL_FUSED", "1") != "0"
+# LFVDM_PROJ_GN=0: keep the temporal output projection and the spatial GroupNorm of the 16x16 level as two launches (A/B aid)
+PROJ_GN = os.environ.get("LFVDM_PROJ_GN", "1") != "0"
 # LFVDM_TEMPORAL_QKV=0: keep the temporal GroupNorm and the temporal qkv projection as two launches (A/B aid)
 TEMPORAL_QKV = os.environ.get("LFVDM_TEMPORAL_QKV", "1") != "0"
 # LFVDM_GN_EPILOGUE=0: never evaluate a GroupNorm in the epilogue of the GEMM that produces its input (A/B aid)
@@ -622,8 +624,14 @@ class Plan:
         # projection (whole frames per tile; the raw block output is read by nothing else)
         ysn = self.scratch("act1", M, Cc)
         if not self.conv_fused_gn(gn=sa.norm, gn_out=ysn, gn_act=nat.ACT_NONE, gn_skip_raw=1, **proj):
-            self.add_conv(**proj)
-            ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
+            if PROJ_GN and L.lfvdm_proj_gn_ok(N, P, Cc) == 0:
+                # 16x16: a frame is more rows than a GEMM tile, but GroupNorm units are independent - one launch of
+                # (frame, 16 channels) workgroups projects, adds the residual and normalises (the raw sum is not needed)
+                self.add(L.lfvdm_proj_gn, _p(self.s_o), _p(ta.proj_out.weight), _p(ta.proj_out.bias), _p(self.s_xn),
+                         _p(sa.norm.weight), _p(sa.norm.bias), sa.norm.eps, _p(ysn), N, P, Cc)
+            else:
+                self.add_conv(**proj)
+                ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
         # qkv projection inside the attention launch where a frame, the head's filters and its q / k / v fit the LDS
         fused_sa = (SPATIAL_FUSED and not self.want_attn and L.lfvdm_attn_spatial_fused_ok(N, P, Cc, heads) == 0)
         if fused_sa:

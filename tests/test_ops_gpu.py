@@ -378,6 +378,43 @@ def test_temporal_groupnorm_with_the_qkv_projection_inside(nat, B, T, P, Cc):
                                    B, T, P, Cc, nat.stream()) != 0
 
 
+@pytest.mark.parametrize("N,Cc", [(40, 64), (3, 64), (9, 128), (20, 128)])
+def test_projection_with_the_next_groupnorm_inside(nat, N, Cc):
+    """lfvdm_proj_gn (1x1 projection + bias + residual + GroupNorm32 of the sum in one launch, frames of 256 positions:
+    rpe.py:171-172 then the next attention's rpe.py:136) == lfvdm_conv_igemm (1x1, res) + lfvdm_gn_apply within fp32
+    re-association, == torch linear + group_norm in fp64; bitwise reproducible; aliased outputs are refused."""
+    L = nat.lib()
+    P = 256
+    assert L.lfvdm_proj_gn_ok(N, P, Cc) == 0
+    M = N * P
+    o = (rnd("pg/o", M, Cc) * 0.8).cuda()
+    res = (rnd("pg/res", M, Cc) * 1.2 + 0.3).cuda()
+    W, bias = (rnd("pg/w", Cc, Cc) * (Cc ** -0.5)).cuda(), (rnd("pg/bias", Cc) * 0.1).cuda()
+    gam, bet = (rnd("pg/g", Cc) * 0.3 + 1.0).cuda(), (rnd("pg/b", Cc) * 0.2).cuda()
+    y = torch.empty(M, Cc, device="cuda")
+    nat.conv_igemm(src0=o, C0=Cc, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=W, bias=bias, Cout=Cc, res=res, ldr=Cc, out=y, ldo=Cc)
+    yn = torch.empty(M, Cc, device="cuda")
+    nat.check(L.lfvdm_gn_apply(nat.ptr(y), None, Cc, 0, N, P, nat.ptr(gam), nat.ptr(bet), None, 1, 0, 1e-5, nat.ACT_NONE, nat.ptr(yn),
+                               None, None, None, nat.stream()), "lfvdm_gn_apply")
+    o0, r0 = o.clone(), res.clone()
+    out = torch.full((M, Cc), float("nan"), device="cuda")
+    run = lambda: nat.check(L.lfvdm_proj_gn(nat.ptr(o), nat.ptr(W), nat.ptr(bias), nat.ptr(res), nat.ptr(gam), nat.ptr(bet), 1e-5,
+                                            nat.ptr(out), N, P, Cc, nat.stream()), "lfvdm_proj_gn")
+    run()
+    assert torch.equal(o, o0) and torch.equal(res, r0), "the operands are left alone"
+    close(out, yn, 2e-5)
+    y64 = o.double().cpu() @ W.double().cpu().t() + bias.double().cpu() + res.double().cpu()
+    ref = F.group_norm(y64.view(N, P, Cc).permute(0, 2, 1), 32, gam.double().cpu(), bet.double().cpu(), 1e-5).permute(0, 2, 1).reshape(M, Cc)
+    close(out, ref, 2e-5)
+    a = out.clone()
+    run()
+    assert torch.equal(out, a), "bitwise reproducible"
+    for bad in (o, res):
+        assert L.lfvdm_proj_gn(nat.ptr(o), nat.ptr(W), nat.ptr(bias), nat.ptr(res), nat.ptr(gam), nat.ptr(bet), 1e-5, nat.ptr(bad),
+                               N, P, Cc, nat.stream()) != 0
+    assert L.lfvdm_proj_gn_ok(N, 64, Cc) != 0 and L.lfvdm_proj_gn_ok(N, 256, 96) != 0      # other maps: the GEMM's epilogue / two launches
+
+
 def test_temporal_groupnorm_qkv_refuses_what_it_does_not_cover(nat):
     L = nat.lib()
     assert L.lfvdm_gn_temporal_qkv_ok(2, 20, 5, 64) != 0        # two pixels per workgroup at 64 channels: odd pixel count
