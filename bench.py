@@ -140,10 +140,10 @@ def kernel_breakdown(plan, reps=10, inner=4):
             nbytes = 2.0 * 4.0 * args[4] * args[5] * (args[2] + args[3])
         elif name == "lfvdm_gn_temporal":                           # (x, gamma, beta, eps, y, B, T, P, C)
             nbytes = 2.0 * 4.0 * args[5] * args[6] * args[7] * args[8]
-        elif name == "lfvdm_proj_gn":                               # (o, W, b, res, gamma, beta, eps, out, N, P, C)
-            rows, Cc = args[8] * args[9], args[10]
+        elif name == "lfvdm_proj_gn":                               # (o, W, b, res, gamma, beta, eps, act, out, raw, N, P, C)
+            rows, Cc = args[10] * args[11], args[12]
             flops = 2.0 * rows * Cc * Cc
-            nbytes = 4.0 * (rows * Cc * 3 + Cc * Cc)                          # o and the residual read, the normalised sum written
+            nbytes = 4.0 * (rows * Cc * (3 + (args[9] is not None)) + Cc * Cc)   # o, residual read; normalised (+ raw) sum written
         elif name == "lfvdm_gn_temporal_qkv":                       # (x, gamma, beta, eps, xn, W, b, qkv, B, T, P, C)
             rows, Cc = args[8] * args[9] * args[10], args[11]
             flops = 2.0 * rows * 3 * Cc * Cc
@@ -267,8 +267,8 @@ def train_step_flops(model, B, T, H, W):
         elif fn is L.lfvdm_gn_temporal_qkv:        # (x, gamma, beta, eps, xn, W, b, qkv, B, T, P, C): the temporal qkv projection
             Bv, Tv, P, C = a[8], a[9], a[10], a[11]
             conv += 2.0 * Bv * Tv * P * 3 * C * C
-        elif fn is L.lfvdm_proj_gn:                # (o, W, b, res, gamma, beta, eps, out, N, P, C): the temporal output projection
-            N, P, C = a[8], a[9], a[10]
+        elif fn is L.lfvdm_proj_gn:                # (o, W, b, res, gamma, beta, eps, act, out, raw, N, P, C): an attention output projection
+            N, P, C = a[10], a[11], a[12]
             conv += 2.0 * N * P * C * C
     return {"forward_conv_gemm": conv, "forward_attention": att, "step": 3.0 * (conv + att)}
 

@@ -13,8 +13,10 @@
 //   * + bias + residual, then two-pass statistics: over the lane's row tiles in registers, over the 16 tokens of a DPP row
 //     (quad_perm, row_ror), over the four waves through 256 B of LDS in wave order (deterministic), x * A + B as gn_wave_body;
 //   * the four workgroups of a frame sit on one XCD (blockIdx % 8) and share its rows of `o` in that L2.
-// The un-normalised sum is not written: nothing else reads it (the residual of the spatial projection is the NORMALISED
-// tensor, rpe.py:136 + :172).
+// The un-normalised sum is written only on request (`raw_out`): inside an attention block nothing else reads it (the residual
+// of the spatial projection is the NORMALISED tensor, rpe.py:136 + :172).  The same launch serves the block's LAST projection
+// when the consumer normalises its output first: the U-Net head `out = [GroupNorm32, SiLU, conv]` (unet.py:418-422) with
+// act = SiLU.
 #include <cstdlib>
 
 #include "common_hip.h"
@@ -44,7 +46,7 @@ template <int C_>
 __global__ __launch_bounds__(256) void proj_gn_kernel(const float* __restrict__ o, const float* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                      float* __restrict__ out, int N) {
+                                                      float* __restrict__ out, int N, int act, float* __restrict__ raw_out) {
     constexpr int P = 256, KG = C_ / 16, CG = C_ / 32, NCB = C_ / 16, RT = 4;
     __shared__ f32x4 xch[2][4][4];                        // [pass][wave][kk]: the waves' partial group sums
     const int id = blockIdx.x;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(256) void proj_gn_kernel(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k][e], a4[k][e], d, 0, 0, 0);
         acc[rt] = d + bv + rs[rt];                        // token 64 wave + 16 rt + lq, channels c ... c + 3
+        if (raw_out != nullptr) st4(raw_out + (row0 + 16 * rt) * C_ + c, acc[rt]);
     }
     // ---- GroupNorm of the unit: CG = 2: groups (x, y) and (z, w) of the quad; CG = 4: the quad is one group
     const float inv = 1.0f / (float)(CG * P);
@@ -114,7 +117,11 @@ __global__ __launch_bounds__(256) void proj_gn_kernel(const float* __restrict__ 
     const f32x4 A = rstd * gam;
     const f32x4 B = bet - mean * A;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) st4(out + (row0 + 16 * rt) * C_ + c, acc[rt] * A + B);
+    for (int rt = 0; rt < RT; ++rt) {
+        f32x4 v = acc[rt] * A + B;
+        if (act == LFVDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        st4(out + (row0 + 16 * rt) * C_ + c, v);
+    }
 }
 
 }  // namespace
@@ -128,13 +135,16 @@ extern "C" int lfvdm_proj_gn_ok(int N, int P, int C) {
 }
 
 extern "C" int lfvdm_proj_gn(const float* o, const float* W, const float* bias, const float* res, const float* gamma,
-                             const float* beta, float eps, float* out, int N, int P, int C, void* stream) {
+                             const float* beta, float eps, int act, float* out, float* raw_out, int N, int P, int C, void* stream) {
     if (!o || !W || !bias || !res || !gamma || !beta || !out || out == o || out == res) return LFVDM_E_SHAPE;
+    if (raw_out == o || raw_out == res || raw_out == out) return LFVDM_E_SHAPE;     // (NULL: the raw sum is not written)
+    if (act != LFVDM_ACT_NONE && act != LFVDM_ACT_SILU) return LFVDM_E_SHAPE;
     if (int rc = lfvdm_proj_gn_ok(N, P, C)) return rc;
     const unsigned grid = 8u * (unsigned)((N + 7) / 8) * (unsigned)(C / 16);
     hipStream_t s = (hipStream_t)stream;
-    if (C == 64) hipLaunchKernelGGL(proj_gn_kernel<64>, dim3(grid), dim3(256), 0, s, o, W, bias, res, gamma, beta, eps, out, N);
-    else hipLaunchKernelGGL(proj_gn_kernel<128>, dim3(grid), dim3(256), 0, s, o, W, bias, res, gamma, beta, eps, out, N);
+    if (C == 64) hipLaunchKernelGGL(proj_gn_kernel<64>, dim3(grid), dim3(256), 0, s, o, W, bias, res, gamma, beta, eps, out, N, act,
+                                    raw_out);
+    else hipLaunchKernelGGL(proj_gn_kernel<128>, dim3(grid), dim3(256), 0, s, o, W, bias, res, gamma, beta, eps, out, N, act, raw_out);
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -413,29 +413,37 @@ class Plan:
             assert skip["H"] == cur["H"] and len(cur["parts"]) == 1 and len(skip["parts"]) == 1
             cat_act = cur.get("act1cat")            # GroupNorm + SiLU of the concat, already evaluated half by half
             nxt_cat = (outs[i + 1][0], hs[-1]) if i + 1 < len(outs) and hs else None
+            last_blk = i + 1 == len(outs)
             cur = self._stage(blk, dict(parts=cur["parts"] + skip["parts"], H=cur["H"], W=cur["W"],
-                                        **({"act1": cat_act} if cat_act is not None else {})), after_cat=nxt_cat)
-            cur.pop("act1", None)
+                                        **({"act1": cat_act} if cat_act is not None else {})), after_cat=nxt_cat,
+                              after_gn=m.out[0] if last_blk and NEXT_GN_EPILOGUE else None)
+            if not last_blk:
+                cur.pop("act1", None)
         # head: GN + SiLU + 3x3 conv straight into the (B,T,C,H,W) layout
         (hb, hc), = cur["parts"]
         gn, conv = m.out[0], m.out[2]
         self.out = self.buf(B, T, m.out_channels, H, W)
-        act = self.gn_apply(hb, None, hc, 0, N, H * W, gn, None, nat.ACT_SILU, "act1")
+        act = cur.get("act1")       # the last block's final projection may have evaluated the head's GroupNorm + SiLU already
+        if act is None:
+            act = self.gn_apply(hb, None, hc, 0, N, H * W, gn, None, nat.ACT_SILU, "act1")
         wp = self.packed(conv.weight)
         self.add_conv(src0=act, C0=hc, N=N, Hs=H, Ws=W, Ho=H, Wo=W, W=wp, bias=conv.bias,
                       Cout=m.out_channels, out=self.out, ldo=m.out_channels, out_mode=nat.OUT_NCHW)
         self.head = dict(act=act, Wp=wp, bias=conv.bias, C=hc, Cout=m.out_channels, step=len(self.steps) - 1)
         self.head_fused = False
 
-    def _stage(self, blk, cur, after=None, after_cat=None):
+    def _stage(self, blk, cur, after=None, after_cat=None, after_gn=None):
         """after: the layer that consumes the stage's output as it is; after_cat = (ResBlock, skip): the decoder ResBlock that
-        consumes it CONCATENATED with a skip tensor (unet.py:460)."""
+        consumes it CONCATENATED with a skip tensor (unet.py:460); after_gn: the GroupNorm (+ SiLU) the consumer applies first
+        when the consumer is not a ResBlock (the U-Net head, unet.py:418-422)."""
         from .unet import ResBlock, FactorizedAttentionBlock, Downsample, Upsample
         layers = list(blk)
         for i, layer in enumerate(layers):
             last = i + 1 == len(layers)
             nxt = layers[i + 1] if not last else after
             ngn = nxt.in_layers[0] if (isinstance(nxt, ResBlock) and NEXT_GN_EPILOGUE) else None
+            if last and after_gn is not None:
+                ngn = after_gn
             self._cat_next = None
             if last and after_cat is not None and isinstance(after_cat[0], ResBlock) and NEXT_GN_EPILOGUE:
                 self._cat_next = after_cat          # read by _final_conv of this layer's last GEMM
@@ -458,6 +466,15 @@ class Plan:
         if next_gn is not None and next_gn.weight.shape[0] == kw["Cout"]:
             actn = self.scratch("actn", M, kw["Cout"])
             if self.conv_fused_gn(gn=next_gn, gn_out=actn, gn_act=nat.ACT_SILU, gn_skip_raw=0, **kw):
+                return actn
+            # a dense 1x1 projection with a residual on 16x16 frames (an attention block's output projection): projection,
+            # residual and the consumer's GroupNorm + SiLU in one launch of (frame, 16 channels) workgroups
+            P = kw["Ho"] * kw["Wo"]
+            if (PROJ_GN and kw.get("ksize") == 1 and kw.get("res") is not None and kw.get("ldr") == kw["Cout"]
+                    and kw.get("ldo") == kw["Cout"] and kw["C0"] == kw["Cout"] and not kw.get("src1") and not kw.get("s2src0")
+                    and kw["Hs"] * kw["Ws"] == P and nat.lib().lfvdm_proj_gn_ok(kw["N"], P, kw["Cout"]) == 0):
+                self.add(nat.lib().lfvdm_proj_gn, _p(kw["src0"]), _p(kw["W"]), _p(kw["bias"]), _p(kw["res"]), _p(next_gn.weight),
+                         _p(next_gn.bias), next_gn.eps, nat.ACT_SILU, _p(actn), _p(kw["out"]), kw["N"], P, kw["Cout"])
                 return actn
         cat = getattr(self, "_cat_next", None)
         if cat is not None and self._final_conv_cat(kw, cat, M):
@@ -628,7 +645,7 @@ class Plan:
                 # 16x16: a frame is more rows than a GEMM tile, but GroupNorm units are independent - one launch of
                 # (frame, 16 channels) workgroups projects, adds the residual and normalises (the raw sum is not needed)
                 self.add(L.lfvdm_proj_gn, _p(self.s_o), _p(ta.proj_out.weight), _p(ta.proj_out.bias), _p(self.s_xn),
-                         _p(sa.norm.weight), _p(sa.norm.bias), sa.norm.eps, _p(ysn), N, P, Cc)
+                         _p(sa.norm.weight), _p(sa.norm.bias), sa.norm.eps, nat.ACT_NONE, _p(ysn), None, N, P, Cc)
             else:
                 self.add_conv(**proj)
                 ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual

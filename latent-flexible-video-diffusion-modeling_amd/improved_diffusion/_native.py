@@ -149,7 +149,7 @@ _SIGS = {
     "lfvdm_gn_temporal": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_temporal_qkv_ok": ([c_i, c_i, c_i, c_i], c_i),
     "lfvdm_proj_gn_ok": ([c_i, c_i, c_i], c_i),
-    "lfvdm_proj_gn": ([c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_float, c_fp, c_i, c_i, c_i, c_fp], c_i),
+    "lfvdm_proj_gn": ([c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_float, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_gn_temporal_qkv": ([c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp], c_i),
     "lfvdm_rowdot": ([c_fp, c_i, c_i, c_fp], c_i),
     "lfvdm_silu": ([c_fp, c_fp, C.c_int64, c_fp], c_i),

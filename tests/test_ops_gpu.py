@@ -399,7 +399,7 @@ def test_projection_with_the_next_groupnorm_inside(nat, N, Cc):
     o0, r0 = o.clone(), res.clone()
     out = torch.full((M, Cc), float("nan"), device="cuda")
     run = lambda: nat.check(L.lfvdm_proj_gn(nat.ptr(o), nat.ptr(W), nat.ptr(bias), nat.ptr(res), nat.ptr(gam), nat.ptr(bet), 1e-5,
-                                            nat.ptr(out), N, P, Cc, nat.stream()), "lfvdm_proj_gn")
+                                            nat.ACT_NONE, nat.ptr(out), None, N, P, Cc, nat.stream()), "lfvdm_proj_gn")
     run()
     assert torch.equal(o, o0) and torch.equal(res, r0), "the operands are left alone"
     close(out, yn, 2e-5)
@@ -409,9 +409,21 @@ def test_projection_with_the_next_groupnorm_inside(nat, N, Cc):
     a = out.clone()
     run()
     assert torch.equal(out, a), "bitwise reproducible"
+    # with SiLU and the raw sum (the U-Net head's GroupNorm + SiLU behind the last attention block, unet.py:418-422)
+    out2 = torch.full((M, Cc), float("nan"), device="cuda")
+    raw = torch.full((M, Cc), float("nan"), device="cuda")
+    nat.check(L.lfvdm_proj_gn(nat.ptr(o), nat.ptr(W), nat.ptr(bias), nat.ptr(res), nat.ptr(gam), nat.ptr(bet), 1e-5, nat.ACT_SILU,
+                              nat.ptr(out2), nat.ptr(raw), N, P, Cc, nat.stream()), "lfvdm_proj_gn")
+    close(raw, y64, 2e-5)
+    close(raw, y, 2e-5)
+    close(out2, F.silu(ref), 2e-5)
     for bad in (o, res):
-        assert L.lfvdm_proj_gn(nat.ptr(o), nat.ptr(W), nat.ptr(bias), nat.ptr(res), nat.ptr(gam), nat.ptr(bet), 1e-5, nat.ptr(bad),
-                               N, P, Cc, nat.stream()) != 0
+        assert L.lfvdm_proj_gn(nat.ptr(o), nat.ptr(W), nat.ptr(bias), nat.ptr(res), nat.ptr(gam), nat.ptr(bet), 1e-5, nat.ACT_NONE,
+                               nat.ptr(bad), None, N, P, Cc, nat.stream()) != 0
+        assert L.lfvdm_proj_gn(nat.ptr(o), nat.ptr(W), nat.ptr(bias), nat.ptr(res), nat.ptr(gam), nat.ptr(bet), 1e-5, nat.ACT_NONE,
+                               nat.ptr(out), nat.ptr(bad), N, P, Cc, nat.stream()) != 0
+    assert L.lfvdm_proj_gn(nat.ptr(o), nat.ptr(W), nat.ptr(bias), nat.ptr(res), nat.ptr(gam), nat.ptr(bet), 1e-5, nat.ACT_NONE,
+                           nat.ptr(out), nat.ptr(out), N, P, Cc, nat.stream()) != 0
     assert L.lfvdm_proj_gn_ok(N, 64, Cc) != 0 and L.lfvdm_proj_gn_ok(N, 256, 96) != 0      # other maps: the GEMM's epilogue / two launches
 
 

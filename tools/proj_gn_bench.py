@@ -31,7 +31,7 @@ for (N, C) in [(40, 64), (20, 64), (160, 64), (40, 128)]:
     out = th.empty(M, C, device=dev); y = th.empty(M, C, device=dev); yn = th.empty(M, C, device=dev)
     def fused():
         nat.check(L.lfvdm_proj_gn(o.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-5,
-                                  out.data_ptr(), N, P, C, nat.stream()), "proj_gn")
+                                  nat.ACT_NONE, out.data_ptr(), None, N, P, C, nat.stream()), "proj_gn")
     def two():
         nat.conv_igemm(src0=o, C0=C, N=N, Hs=P, Ws=1, Ho=P, Wo=1, ksize=1, W=W, bias=bias, Cout=C, res=res, ldr=C, out=y, ldo=C)
         nat.check(L.lfvdm_gn_apply(y.data_ptr(), None, C, 0, N, P, gam.data_ptr(), bet.data_ptr(), None, 1, 0, 1e-5, nat.ACT_NONE,
