@@ -343,15 +343,15 @@ int lfvdm_gn_temporal_qkv_ok(int B, int T, int P, int C);
 int lfvdm_gn_temporal_qkv(const float* x, const float* gamma, const float* beta, float eps, float* xn_out,
                           const float* Wqkv, const float* bqkv, float* qkv, int B, int T, int P, int C, void* stream);
 
-/* 1x1 projection + bias + residual + the next GroupNorm in ONE launch, for frames of 256 positions (the 16x16 level): the
+/* 1x1 projection + bias + residual + the next GroupNorm in ONE launch, for frames of 256 or 64 positions (16x16, 8x8): the
  * temporal attention's `x + self.proj_out(out)` (rpe.py:171-172; o [N*P][C] = the attention output, W [C][C] / bias [C] =
  * proj_out.weight / .bias, res [N*P][C] = the temporally normalised tokens) followed by the spatial attention's
  * `self.norm` (rpe.py:136; GroupNorm32(32, C) per frame in fp32, nn.py:93-101; gamma / beta / eps), or - act =
  * LFVDM_ACT_SILU - the spatial attention's output projection followed by the U-Net head's GroupNorm + SiLU
  * (unet.py:418-422).  out [N*P][C] = act(GroupNorm(sum)); raw_out [N*P][C] (may be NULL) = the sum itself, for consumers
  * that also read it; out / raw_out must not alias o, res or each other.  Replaces lfvdm_conv_igemm (1x1) + lfvdm_gn_apply
- * where the GroupNorm does not fit the GEMM's epilogue (a frame is more rows than a tile).  _ok: LFVDM_OK for P = 256 and
- * C = 64 / 128, else LFVDM_E_UNSUPPORTED. */
+ * where the GroupNorm does not fit the GEMM's epilogue (a frame is more rows than a tile) or costs more there than here (8x8).  _ok: LFVDM_OK
+ * for P = 256 / 64 and C = 64 / 128, else LFVDM_E_UNSUPPORTED. */
 int lfvdm_proj_gn_ok(int N, int P, int C);
 int lfvdm_proj_gn(const float* o, const float* W, const float* bias, const float* res, const float* gamma, const float* beta,
                   float eps, int act, float* out, float* raw_out, int N, int P, int C, void* stream);

@@ -5,7 +5,8 @@
 // At the 8x8 level and below the GroupNorm already rides in the projection's epilogue (a GEMM tile holds whole frames); at
 // 16x16 a frame is 256 rows and the plan ran lfvdm_conv_igemm (1x1, 84 MFLOP: ~5.3 us, all latency) and then lfvdm_gn_apply
 // (~5.1 us).  GroupNorm units are independent, so the decomposition of gn_wave4 carries over: a workgroup owns (frame n,
-// 16 output channels), wave w the positions [64 w, 64 w + 64):
+// 16 output channels), wave w the positions [64 w, 64 w + 64) (8x8 frames, where the GEMM's GroupNorm epilogue costs 8.5 us
+// for 84 MFLOP: [16 w, 16 w + 16)):
 //   * fp32 MFMA 16x16x4 on the TRANSPOSED tile, D^T = W . o^T: the 16 filter rows of the unit are the A operand, the
 //     attention output rows of the wave the B operand - both read from global memory straight into fragments (16 bytes per
 //     lane and 16-wide K group); a lane ends up with channels 4 kk ... 4 kk + 3 of token l & 15 of each of its four row
@@ -42,12 +43,12 @@ __device__ __forceinline__ float pg_row_sum(float v) {
     return v;
 }
 
-template <int C_>
+template <int C_, int P>
 __global__ __launch_bounds__(256) void proj_gn_kernel(const float* __restrict__ o, const float* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                       float* __restrict__ out, int N, int act, float* __restrict__ raw_out) {
-    constexpr int P = 256, KG = C_ / 16, CG = C_ / 32, NCB = C_ / 16, RT = 4;
+    constexpr int KG = C_ / 16, CG = C_ / 32, NCB = C_ / 16, RT = P / 64, PW = P / 4;      // PW: positions per wave
     __shared__ f32x4 xch[2][4][4];                        // [pass][wave][kk]: the waves' partial group sums
     const int id = blockIdx.x;
     const int xcd = id & 7, r8 = id >> 3;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void proj_gn_kernel(const float* __restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, kk = lane >> 4;
     const int c = 16 * cb + 4 * kk;                       // this lane's channel quad
-    const size_t row0 = (size_t)n * P + 64 * wave + lq;   // + 16 rt
+    const size_t row0 = (size_t)n * P + PW * wave + lq;   // + 16 rt
 
     // ---- operands: the unit's filter rows (A), the wave's attention-output rows (B), bias / residual / affine
     f32x4 wf[KG];
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void proj_gn_kernel(const float* __restrict__ 
         for (int k = 0; k < KG; ++k)
 #pragma unroll
             for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k][e], a4[k][e], d, 0, 0, 0);
-        acc[rt] = d + bv + rs[rt];                        // token 64 wave + 16 rt + lq, channels c ... c + 3
+        acc[rt] = d + bv + rs[rt];                        // token PW wave + 16 rt + lq, channels c ... c + 3
         if (raw_out != nullptr) st4(raw_out + (row0 + 16 * rt) * C_ + c, acc[rt]);
     }
     // ---- GroupNorm of the unit: CG = 2: groups (x, y) and (z, w) of the quad; CG = 4: the quad is one group
@@ -126,10 +127,11 @@ __global__ __launch_bounds__(256) void proj_gn_kernel(const float* __restrict__ 
 
 }  // namespace
 
-// LFVDM_OK: frames of 256 positions, 64 or 128 channels (a GroupNorm unit of 16 channels = 8 or 4 whole groups)
+// LFVDM_OK: frames of 256 or 64 positions (four or one 16-row tile per wave), 64 or 128 channels (a GroupNorm unit of 16
+// channels = 8 or 4 whole groups)
 extern "C" int lfvdm_proj_gn_ok(int N, int P, int C) {
     if (N <= 0 || P <= 0 || C <= 0) return LFVDM_E_SHAPE;
-    if (P != 256 || (C != 64 && C != 128)) return LFVDM_E_UNSUPPORTED;
+    if ((P != 256 && P != 64) || (C != 64 && C != 128)) return LFVDM_E_UNSUPPORTED;
     if ((long)N * P * C * 4 >= (1L << 31)) return LFVDM_E_UNSUPPORTED;
     return LFVDM_OK;
 }
@@ -142,9 +144,13 @@ extern "C" int lfvdm_proj_gn(const float* o, const float* W, const float* bias, 
     if (int rc = lfvdm_proj_gn_ok(N, P, C)) return rc;
     const unsigned grid = 8u * (unsigned)((N + 7) / 8) * (unsigned)(C / 16);
     hipStream_t s = (hipStream_t)stream;
-    if (C == 64) hipLaunchKernelGGL(proj_gn_kernel<64>, dim3(grid), dim3(256), 0, s, o, W, bias, res, gamma, beta, eps, out, N, act,
-                                    raw_out);
-    else hipLaunchKernelGGL(proj_gn_kernel<128>, dim3(grid), dim3(256), 0, s, o, W, bias, res, gamma, beta, eps, out, N, act, raw_out);
+#define LFVDM_PG(CV, PV)                                                                                                      \
+    hipLaunchKernelGGL((proj_gn_kernel<CV, PV>), dim3(grid), dim3(256), 0, s, o, W, bias, res, gamma, beta, eps, out, N, act, raw_out)
+    if (C == 64 && P == 256) LFVDM_PG(64, 256);
+    else if (C == 64) LFVDM_PG(64, 64);
+    else if (P == 256) LFVDM_PG(128, 256);
+    else LFVDM_PG(128, 64);
+#undef LFVDM_PG
     LFVDM_CHECK_LAUNCH();
     return LFVDM_OK;
 }

@@ -640,15 +640,15 @@ class Plan:
         # --- spatial: GN over (C/32 x HW) per frame.  Low-resolution levels: evaluated in the epilogue of the temporal
         # projection (whole frames per tile; the raw block output is read by nothing else)
         ysn = self.scratch("act1", M, Cc)
-        if not self.conv_fused_gn(gn=sa.norm, gn_out=ysn, gn_act=nat.ACT_NONE, gn_skip_raw=1, **proj):
-            if PROJ_GN and L.lfvdm_proj_gn_ok(N, P, Cc) == 0:
-                # 16x16: a frame is more rows than a GEMM tile, but GroupNorm units are independent - one launch of
-                # (frame, 16 channels) workgroups projects, adds the residual and normalises (the raw sum is not needed)
-                self.add(L.lfvdm_proj_gn, _p(self.s_o), _p(ta.proj_out.weight), _p(ta.proj_out.bias), _p(self.s_xn),
-                         _p(sa.norm.weight), _p(sa.norm.bias), sa.norm.eps, nat.ACT_NONE, _p(ysn), None, N, P, Cc)
-            else:
-                self.add_conv(**proj)
-                ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
+        if PROJ_GN and M > CHAIN_MAX_M and L.lfvdm_proj_gn_ok(N, P, Cc) == 0:
+            # 16x16 (a frame is more rows than a GEMM tile) and 8x8 (the tile GEMM's GroupNorm epilogue: 8.5 us for 84 MFLOP):
+            # GroupNorm units are independent - one launch of (frame, 16 channels) workgroups projects, adds the residual and
+            # normalises (the raw sum is read by nothing else).  The chained levels keep the epilogue form (a chain stage).
+            self.add(L.lfvdm_proj_gn, _p(self.s_o), _p(ta.proj_out.weight), _p(ta.proj_out.bias), _p(self.s_xn),
+                     _p(sa.norm.weight), _p(sa.norm.bias), sa.norm.eps, nat.ACT_NONE, _p(ysn), None, N, P, Cc)
+        elif not self.conv_fused_gn(gn=sa.norm, gn_out=ysn, gn_act=nat.ACT_NONE, gn_skip_raw=1, **proj):
+            self.add_conv(**proj)
+            ysn = self.gn_apply(yt, None, Cc, 0, N, P, sa.norm, None, nat.ACT_NONE, "act1")   # also the residual
         # qkv projection inside the attention launch where a frame, the head's filters and its q / k / v fit the LDS
         fused_sa = (SPATIAL_FUSED and not self.want_attn and L.lfvdm_attn_spatial_fused_ok(N, P, Cc, heads) == 0)
         if fused_sa:

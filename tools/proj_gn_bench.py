@@ -23,8 +23,7 @@ def graph_time(f, n=50, reps=10):
         e1.record(s); s.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (n * reps)
 
-P = 256
-for (N, C) in [(40, 64), (20, 64), (160, 64), (40, 128)]:
+for (N, C, P) in [(40, 64, 256), (20, 64, 256), (160, 64, 256), (40, 128, 256), (40, 128, 64), (20, 128, 64), (160, 128, 64)]:
     M = N * P
     o = th.randn(M, C, device=dev); res = th.randn(M, C, device=dev); W = th.randn(C, C, device=dev) * 0.1; bias = th.randn(C, device=dev)
     gam = th.randn(C, device=dev); bet = th.randn(C, device=dev)
@@ -37,4 +36,4 @@ for (N, C) in [(40, 64), (20, 64), (160, 64), (40, 128)]:
         nat.check(L.lfvdm_gn_apply(y.data_ptr(), None, C, 0, N, P, gam.data_ptr(), bet.data_ptr(), None, 1, 0, 1e-5, nat.ACT_NONE,
                                    yn.data_ptr(), None, None, None, nat.stream()), "gn_apply")
     tf, tt = graph_time(fused), graph_time(two)
-    print(f"N={N:4d} C={C:4d}: fused {tf:6.2f} us   1x1 GEMM + gn_apply {tt:6.2f} us   max|d| {float((out - yn).abs().max()):.2e}", flush=True)
+    print(f"N={N:4d} C={C:4d} P={P:4d}: fused {tf:6.2f} us   1x1 GEMM + gn_apply {tt:6.2f} us   max|d| {float((out - yn).abs().max()):.2e}", flush=True)
