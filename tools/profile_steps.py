@@ -17,11 +17,11 @@ def main():
     ch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     dev = th.device("cuda")
     model, diffusion = bench.make_model_and_diffusion(ch, dev)
-    B, T = 2, 20
+    B, T = int(os.environ.get('PROFILE_B', '2')), 20
     inputs = bench.synthetic_inputs(B, T, 0, dev)
     pl = Plan(model.native_engine(), B, T, 16, 16, False)
     pl.refresh_weights()
-    pl.set_inputs(th.randn(B, T, 4, 16, 16, device=dev), inputs["x0"], th.tensor([500.0, 20.0], device=dev),
+    pl.set_inputs(th.randn(B, T, 4, 16, 16, device=dev), inputs["x0"], th.linspace(500.0, 20.0, B, device=dev),
                   inputs["frame_indices"], inputs["obs_mask"], inputs["latent_mask"])
     if os.environ.get('LFVDM_AUTOTUNE', '1') != '0':
         pl.autotune()
@@ -52,7 +52,7 @@ def main():
             v = nt.value
             extra = (f"<{v // 1000},{v // 100 % 10},{v // 10 % 10},{v % 10}> M={M} Cin={a.C0 + a.C1} Cout={a.Cout} k={a.ksize} s2={a.s2C0 + a.s2C1} "
                      f"coef={int(bool(a.coefA))} act={a.act} {fl / 1e6:8.1f} MF {fl / tot[i] / 1e6:6.1f} TF/s")
-        elif name in ("lfvdm_attn_spatial", "lfvdm_attn_temporal", "lfvdm_gn_coef", "lfvdm_gn_temporal"):
+        elif name != "lfvdm_level_chain":
             extra = " ".join(str(a) for a in args if isinstance(a, int) and a < 100000)
         print(f"{i:3d} {tot[i]:8.1f} us  {name:22s} {extra}")
     print("sum", sum(tot))

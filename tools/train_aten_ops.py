@@ -56,7 +56,7 @@ class Log(TorchDispatchMode):
 
 
 with Log():
-    loop.forward_backward()
+    loop.run_step()       # forward + backward AND the optimizer phase
 th.cuda.synchronize()
 tot = 0
 for (name, where), n in sorted(count.items(), key=lambda kv: (-kv[1], kv[0])):
